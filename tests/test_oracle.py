@@ -1,0 +1,172 @@
+"""CPU tests: the C oracle against the committed golden vectors
+(tests/golden/*.npz, produced by tests/golden/make_golden.py from the
+independent numpy/scipy statement in tests/np_ref.py)."""
+import os
+
+import numpy as np
+import pytest
+from scipy.spatial.transform import Rotation
+
+import oracle_lib as O
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name), allow_pickle=False)
+
+
+def pose_err(qt, T):
+    D = np.linalg.inv(T) @ O.se3_matrix(qt)
+    return np.linalg.norm(Rotation.from_matrix(D[:3, :3]).as_rotvec()), np.linalg.norm(D[:3, 3])
+
+
+def test_se3_against_expm_logm():
+    g = load("se3.npz")
+    for i in range(g["A"].shape[0]):
+        qt = O.se3_exp(g["A"][i])
+        assert np.allclose(O.se3_matrix(qt), g["exp_mats"][i], atol=1e-14, rtol=0)
+        assert np.allclose(O.se3_log(qt), g["A"][i], atol=1e-13, rtol=0)
+        qb = O.se3_exp(g["B"][i])
+        assert np.allclose(O.se3_matrix(O.se3_mul(qt, qb)), g["prod"][i], atol=1e-14, rtol=0)
+        assert np.allclose(O.se3_matrix(O.se3_inv(qt)), g["inv"][i], atol=1e-14, rtol=0)
+        assert np.allclose(O.se3_matrix(O.se3_plus(qt, g["B"][i])), g["prod"][i], atol=1e-14, rtol=0)
+        assert np.allclose(O.se3_dx(qt), g["dx"][i], atol=2e-9, rtol=0)  # golden is a central difference
+        assert abs(np.linalg.norm(O.se3_mul(qt, qb)[:4]) - 1) < 1e-15
+
+
+def test_cost_function_literal_and_local():
+    g = load("costfn.npz")
+    n = g["qts"].shape[0]
+    for k in range(n):
+        a = (g["qts"][k], g["ps"][k], g["pt"][k], g["Cs"][k], g["Ct"][k])
+        r, j7 = O.gicp_evaluate(*a)
+        assert np.isclose(r, g["residual"][k], rtol=1e-11, atol=1e-13)
+        assert np.allclose(j7, g["jac7"][k], rtol=1e-10, atol=1e-10 * np.abs(g["jac7"][k]).max())
+        r2, j6 = O.gicp_evaluate_local(*a)
+        assert r2 == r
+        fd = g["jac6_fd"][k]
+        assert np.allclose(j6, fd, rtol=0, atol=2e-7 * max(1.0, np.abs(fd).max()))
+        if g["eps"][k] > 0:  # closed form of SURVEY appendix B == literal chain rule
+            assert np.isclose(r, g["r_closed"][k], rtol=1e-10, atol=1e-12)
+            jc = g["j_closed"][k]
+            assert np.allclose(j6, jc, rtol=0, atol=1e-9 * max(1.0, np.abs(jc).max()))
+        b, v = O.gicp_probability(*a)
+        gv = g["prob"][k]
+        if np.isnan(gv):
+            assert np.isnan(v) and b  # quirk Q1: NaN converts to true
+        else:
+            assert np.isclose(v, gv, rtol=1e-9, atol=0) and b == (gv != 0.0)
+
+
+def test_probability_underflow_gate():
+    # quirk Q1: the "probability" only gates on double underflow (Mahalanobis^2 >~ 1490)
+    Cs = np.eye(3) - 0.999 * np.outer([0, 0, 1], [0, 0, 1])
+    I = np.array([0, 0, 0, 1, 0, 0, 0.0])
+    ps = np.zeros(3)
+    for dz, expect in ((1.0, True), (1.7, True), (1.75, False), (3.0, False)):
+        b, v = O.gicp_probability(I, ps, np.array([0, 0, dz]), Cs, Cs)
+        assert b == expect, (dz, v)
+
+
+def test_knn_brute_kdtree_numpy_identical():
+    g = load("knn.npz")
+    q, t = g["q"], g["t"]
+    for k in (1, 4, 20):
+        ib, db = O.knn(q, t, k)
+        ik, dk = O.knn(q, t, k, kdtree=True)
+        assert np.array_equal(ib, g[f"idx{k}"]) and np.array_equal(db, g[f"d2_{k}"])
+        assert np.array_equal(ik, ib) and np.array_equal(dk, db)
+    # fewer targets than k: tail is (-1, inf)
+    ib, db = O.knn(q[:3], t[:2], 4)
+    assert (ib[:, 2:] == -1).all() and np.isinf(db[:, 2:]).all() and (ib[:, :2] >= 0).all()
+    assert np.array_equal(O.transform_points(g["M"], q), g["q_transformed"])
+
+
+def test_covariances_and_histograms():
+    g = load("cov.npz")
+    cov, nrm, hist = O.covariances(g["p"], g["labels"], int(g["k"]), float(g["eps"]), int(g["C"]))
+    ok = g["gaps"] > 1e-6  # PCA direction is only defined away from degenerate spectra
+    assert ok.mean() > 0.99
+    assert np.allclose(cov[ok], g["cov"][ok], atol=1e-9, rtol=0)
+    dots = np.abs(np.einsum("ni,ni->n", nrm, g["normals"]))
+    assert (1 - dots[ok]).max() < 1e-12
+    assert np.array_equal(hist, g["hist"])
+    assert np.allclose(hist.sum(axis=1), 1.0, atol=1e-12)
+    # C = I - (1-eps) n n^T  
+    eps = float(g["eps"])
+    rebuilt = np.eye(3)[None] - (1 - eps) * np.einsum("ni,nj->nij", nrm, nrm)
+    assert np.allclose(cov, rebuilt, atol=1e-14, rtol=0)
+    ck, _, _ = O.covariances(g["p"], g["labels"], int(g["k"]), eps, int(g["C"]), kdtree=True)
+    assert np.array_equal(ck, cov)
+
+
+def test_sym3_svd_orders_by_absolute_value():
+    Q, _ = np.linalg.qr(np.random.default_rng(5).normal(size=(3, 3)))
+    A = Q @ np.diag([2.0, 3e-4, -5e-4]) @ Q.T  # float-product noise can make cov slightly indefinite
+    U, s = O.sym3_svd_u(A)
+    Un, sn, _ = np.linalg.svd(A)
+    assert np.allclose(s, sn, atol=1e-15)
+    assert np.allclose(np.abs(np.sum(U * Un, axis=0)), 1.0, atol=1e-12)
+
+
+@pytest.mark.parametrize("mode,name", [(O.MODE_GICP, "gicp"), (O.MODE_EM, "em"), (O.MODE_SEMANTIC, "semantic")])
+def test_losses(mode, name):
+    g = load("loss.npz")
+    p = O.default_params(mode)
+    for s, want in zip(g["s"], g[name]):
+        rho = O.loss(p, float(s), float(g["w"]))
+        # Ceres evaluates b*log(1 + s/b) (not log1p): absolute error ~ b*2^-53 near s = 0
+        assert np.isclose(rho[0], want[0], rtol=1e-9, atol=4e-15), (s, rho, want)
+        assert np.allclose(rho[1:], want[1:], rtol=1e-9, atol=1e-300), (s, rho, want)
+        assert rho[2] <= 0  # => Ceres' Corrector always takes the simple branch
+
+
+def test_em_prob():
+    g = load("em.npz")
+    for cm, want in ((g["cm"], g["p1"]), (g["cm2"], g["p2"])):
+        got = np.array([O.em_prob(cm, g["td"][i], g["sd"][i]) for i in range(g["td"].shape[0])])
+        assert np.allclose(got, want, rtol=1e-13, atol=0)
+
+
+def _align(mode, g, eps=1e-3, init=None, kdtree=True):
+    p = O.default_params(mode)
+    p.num_classes = 4
+    p.epsilon = eps
+    p.use_kdtree = int(kdtree)
+    I = np.array([0, 0, 0, 1, 0, 0, 0.0]) if init is None else init
+    return O.align(p, g["src"], g["sl"], g["tgt"], g["tl"], g["cm"], I)
+
+
+@pytest.mark.parametrize("mode,key", [(O.MODE_GICP, "gicp"), (O.MODE_EM, "em"), (O.MODE_SEMANTIC, "sem")])
+def test_align_matches_independent_solver(mode, key):
+    """Full align(): oracle LM (Ceres-style) vs scipy least_squares outer loop."""
+    g = load("align.npz")
+    qt, st = _align(mode, g)
+    assert st["outer_iters"] == int(g[f"{key}_outer"])
+    rot, tr = pose_err(qt, g[f"{key}_T"])
+    assert rot < 1e-6 and tr < 1e-6, (rot, tr)
+    rot, tr = pose_err(qt, g["T_gt"])  # and it actually registers the pair
+    assert rot < 2e-3 and tr < 1e-2
+    qb, sb = _align(mode, g, kdtree=False)
+    assert np.array_equal(qb, qt) and sb["total_evals"] == st["total_evals"]
+
+
+def test_align_em_eps1e2_nonidentity_start():
+    g = load("align.npz")
+    from np_ref import mat_to_qt
+
+    qt, st = _align(O.MODE_EM, g, eps=1e-2, init=mat_to_qt(g["em2_T0"]))
+    assert st["outer_iters"] == int(g["em2_outer"])
+    rot, tr = pose_err(qt, g["em2_T"])
+    assert rot < 1e-6 and tr < 1e-6, (rot, tr)
+
+
+def test_fused_labels_shape_and_range():
+    g = load("align.npz")
+    p = O.default_params(O.MODE_EM)
+    p.num_classes = 4
+    qt, _ = _align(O.MODE_EM, g)
+    lab = O.fused_labels(p, g["src"], g["sl"], g["tgt"], g["tl"], g["cm"], qt)
+    assert lab.shape == g["sl"].shape and lab.min() >= 1 and lab.max() <= 4
+    assert (lab == g["sl"]).mean() > 0.95
