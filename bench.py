@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the semantic-ICP hot path on MI355X.
+
+Metric (BASELINE.json): correspondences/sec (+ ms per outer ICP iteration) for EM-ICP
+(K = 4 correspondences per source point, C = 11 classes) on a synthetic KITTI-like scan pair
+subsampled to exactly 100 000 x 100 000 points -- the metric point of configs[1].
+
+A "step" is one complete align() of one pair (covariances of both clouds + every outer ICP
+iteration: transform -> kNN -> EM weights -> inner LM solve), with both clouds already resident
+in HBM when the timed region starts.  One correspondence = one (source, target) slot that
+went through kNN + weighting + accumulation in one outer iteration.
+
+  python bench.py --gpus N --steps K --warmup W
+For N > 1 launch with:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...
+(one process per GPU; independent scan pairs per rank, no collective on the solve path, so the
+process group is gloo and only carries the barrier and the max-over-ranks of the timings).
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
+VALU_PAIR_PEAK = 9.8e12        # 78.6e12 FP32 lane-ops/s / 8 lane-ops per pair
+N_POINTS = 100_000
+K_CORR = 4
+N_CLASSES = 11
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--points", type=int, default=N_POINTS)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-run", action="store_true", help="exercise the multi-process plumbing without a GPU")
+    return ap.parse_args()
+
+
+class Dist:
+    """torch.distributed (gloo) only when launched with WORLD_SIZE > 1."""
+
+    def __init__(self):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.pg = None
+        if self.world > 1:
+            import torch  # noqa: F401  (imported before libsicp so that both share one HIP runtime)
+            import torch.distributed as dist
+
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+            dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+            self.pg = dist
+
+    def barrier(self):
+        if self.pg:
+            self.pg.barrier()
+
+    def reduce(self, value: float, op: str) -> float:
+        if not self.pg:
+            return value
+        import torch
+
+        t = torch.tensor([value], dtype=torch.float64)
+        self.pg.all_reduce(t, op=self.pg.ReduceOp.MAX if op == "max" else self.pg.ReduceOp.SUM)
+        return float(t.item())
+
+    def close(self):
+        if self.pg:
+            self.pg.destroy_process_group()
+
+
+def cpu_baseline(src, sl, tgt, tl, cm):
+    """The CPU restatement of the reference PCL-KdTree + Ceres path (the oracle), timed on this
+    host on the same pair: kNN + problem build on 1 thread (em_icp.hpp:57-156), residual /
+    Jacobian evaluation on 8 threads (em_icp.hpp:166)."""
+    import numpy as np
+
+    import oracle_lib as O
+
+    p = O.default_params(O.MODE_EM)
+    p.num_classes = N_CLASSES
+    p.use_kdtree = 1
+    threads = min(8, os.cpu_count() or 1)
+    p.num_threads = threads
+    t0 = time.perf_counter()
+    qt, st = O.align(p, src, sl, tgt, tl, cm, np.array([0, 0, 0, 1, 0, 0, 0.0]))
+    dt = time.perf_counter() - t0
+    return {
+        "value": st["total_corr"] / dt,
+        "unit": "correspondences/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"1 full align() of the same {len(src)}x{len(tgt)} pair (rank-0 pair): {st['outer_iters']} outer iterations, "
+                  f"{st['total_evals']} residual sweeps, {dt:.1f} s; kd-tree kNN + problem build on 1 thread, "
+                  f"residual/Jacobian sweeps on {threads} threads (host has {os.cpu_count()} cores)",
+        "ms_per_icp_iter": 1e3 * (dt - st["t_cov_s"]) / max(1, st["outer_iters"]),
+        "cov_ms": 1e3 * st["t_cov_s"],
+        "pose": [float(v) for v in qt],
+    }, qt
+
+
+def main():
+    args = parse_args()
+    dist = Dist()
+    import numpy as np
+
+    import synth
+
+    n = args.points
+    # weak scaling: every rank registers its own, differently seeded, pair
+    src, sl, tgt, tl, T_gt, cm = synth.lidar_pair(seed=2 + dist.rank, n_points=n)
+    ident = np.array([0, 0, 0, 1, 0, 0, 0.0])
+
+    if args.dry_run:
+        engine = None
+
+        def step():
+            time.sleep(0.01 * (1 + dist.rank))
+            return ident, dict(total_corr=3 * n * K_CORR, outer_iters=3, total_evals=30, nn_kernel_ms=0.0, nn_launches=0,
+                               t_cov_ms=0.0, total_lm_iters=0)
+    else:
+        sicp = importlib.import_module("semantic-icp_amd")
+        ndev = sicp.device_count()
+        if ndev < 1:
+            raise SystemExit("bench.py: no HIP device visible (there is no CPU fallback)")
+        p = sicp.default_params(sicp.MODE_EM)
+        p.num_classes = N_CLASSES
+        p.profile = 1  # SICP_PROFILE_NN: HIP events around the dominant kernel, on its own stream
+        engine = sicp.Engine(dist.local_rank % ndev, p)
+        engine.set_confusion(cm)
+        engine.set_source(src, sl)   # clouds resident in HBM before the timed region
+        engine.set_target(tgt, tl)
+
+        def step():
+            return engine.align(ident)
+
+    for _ in range(args.warmup):
+        step()
+    if engine:
+        engine.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    corr = outer = evals = nn_launches = lm_iters = 0
+    nn_ms = cov_ms = 0.0
+    qt = ident
+    for _ in range(args.steps):
+        qt, st = step()
+        corr += st["total_corr"]; outer += st["outer_iters"]; evals += st["total_evals"]
+        nn_ms += st["nn_kernel_ms"]; nn_launches += st["nn_launches"]; cov_ms += st["t_cov_ms"]
+        lm_iters += st["total_lm_iters"]
+    if engine:
+        engine.synchronize()
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed_max = dist.reduce(elapsed, "max")
+    corr_all = dist.reduce(float(corr), "sum")
+
+    out = None
+    if dist.rank == 0:
+        steps = max(1, args.steps)
+        ms_per_step = 1e3 * elapsed_max / steps
+        out = {
+            "metric": "correspondences/sec",
+            "value": corr_all / elapsed_max,
+            "unit": "correspondences/s",
+            "n_gpus": dist.world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32 (kNN) / f64 (residuals, Jacobians, solve)",
+            "data": "dry-run" if args.dry_run else "synthetic",
+            "config": {
+                "workload": f"EM-ICP align() on a synthetic KITTI-like scan pair, {n}x{n} points, K={K_CORR}, C={N_CLASSES} "
+                            "(metric point of BASELINE configs[1]); one independent pair per GPU",
+                "points": n, "K": K_CORR, "classes": N_CLASSES, "parallelism": f"pairs-sharded x{dist.world}",
+                "step": "one full align(): covariances of both clouds + all outer ICP iterations",
+            },
+            "ms_per_icp_iter": 1e3 * (elapsed - 1e-3 * cov_ms) / max(1, outer),
+            "cov_ms_per_align": cov_ms / steps,
+            "outer_iters_per_align": outer / steps,
+            "accumulate_passes_per_outer_iter": evals / max(1, outer),
+            "lm_iters_per_outer_iter": lm_iters / max(1, outer),
+        }
+        if nn_launches and not args.dry_run:
+            avg_ms = nn_ms / nn_launches
+            alg_bytes = 12 * n + 12 * n + 8 * K_CORR * n     # src+tgt xyz once, idx+dist^2 out
+            achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+            out["roofline"] = {
+                "kernel": "nn_partial_kernel<K=4,Q=2> (brute-force correspondence search, one launch per outer iteration)",
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "avg_launch_ms": avg_ms, "launches": nn_launches, "algorithmic_bytes_per_launch": alg_bytes,
+                "note": "brute force is FP32-VALU bound, not HBM bound (SURVEY.md 8d): see 'valu'",
+                "valu": {"pair_evals_per_launch": float(n) * n, "achieved_pair_evals_per_s": float(n) * n / (avg_ms * 1e-3),
+                         "peak_pair_evals_per_s": VALU_PAIR_PEAK, "frac": float(n) * n / (avg_ms * 1e-3) / VALU_PAIR_PEAK},
+            }
+        if not args.dry_run and not args.no_cpu_baseline:
+            base, oq = cpu_baseline(src, sl, tgt, tl, cm)
+            from scipy.spatial.transform import Rotation
+
+            import oracle_lib as O
+
+            D = np.linalg.inv(O.se3_matrix(oq)) @ O.se3_matrix(qt)
+            out["pose_delta_vs_cpu"] = {"rot_rad": float(np.linalg.norm(Rotation.from_matrix(D[:3, :3]).as_rotvec())),
+                                        "trans_m": float(np.linalg.norm(D[:3, 3]))}
+            base.pop("pose")
+            out["cpu_baseline"] = base
+    dist.barrier()
+    if engine:
+        engine.close()
+    dist.close()
+    if out is not None:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,198 @@
+/*
+ * sicp.h -- C ABI of the MI355X-native semantic-ICP registration engine.
+ *
+ * This is the drop-in boundary for the hot path of kxhit/semantic-icp: the body
+ * of align() in the reference's three header-only registration classes.  The
+ * reference has no FFI of its own (it is header-only C++ that the drivers
+ * instantiate directly), so every entry point below cites the reference
+ * member(s) it replaces; the C++ class shims in semantic-icp_amd/host/ keep the
+ * reference's class/method names on top of this ABI.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, opaque handle, int status
+ *     (0 = ok, negative = error; no exceptions cross the ABI; the library
+ *     never prints).
+ *   - The caller owns every input/output buffer (host memory unless a name
+ *     ends in _device); the handle owns all device memory.
+ *   - One handle = one HIP device + one stream.  Handles are independent and
+ *     may be driven from different host threads or processes (that is how
+ *     scan pairs shard across the 8 GPUs of a node); a single handle is not
+ *     thread-safe, like the reference classes.
+ *   - Pose exchange format: Sophus storage order qt[7] = [qx qy qz qw tx ty tz]
+ *     (reference: gicp_cost_function.h:64-70).  Tangent order [upsilon; omega].
+ *   - Clouds are SoA float32 xyz (+ uint32 labels): the layout the kernels read.
+ *     Labels are 1..C for SICP_MODE_EM (reference quirk: em_icp.hpp:301 indexes
+ *     label-1), arbitrary for SICP_MODE_SEMANTIC, ignored for SICP_MODE_GICP.
+ */
+#ifndef SICP_H_
+#define SICP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SICP_VERSION_MAJOR 0
+#define SICP_VERSION_MINOR 1
+
+/* ---- status codes ------------------------------------------------------- */
+enum {
+  SICP_OK = 0,
+  SICP_ERR_INVALID_ARGUMENT = -1,
+  SICP_ERR_NO_DEVICE = -2,       /* no HIP device / HIP runtime failure at create */
+  SICP_ERR_HIP = -3,             /* a HIP call failed; see sicp_last_error()       */
+  SICP_ERR_NOT_READY = -4,       /* clouds / confusion matrix missing for the mode */
+  SICP_ERR_TOO_FEW_POINTS = -5,  /* target has fewer than K points (reference: UB,
+                                    em_icp.hpp:62-65)                             */
+  SICP_ERR_BAD_LABEL = -6,       /* EM label outside 1..C (reference: UB)          */
+  SICP_ERR_OUT_OF_MEMORY = -7
+};
+
+/* ---- which reference class the handle behaves as ------------------------ */
+enum {
+  SICP_MODE_GICP = 0,     /* semanticicp::GICP<PointT>             gicp.h:15-132        */
+  SICP_MODE_EM = 1,       /* EmIterativeClosestPoint<N>            em_icp.h:17-122      */
+  SICP_MODE_SEMANTIC = 2  /* SemanticIterativeClosestPoint<P,S>    semantic_icp.h:15-83 */
+};
+
+enum { SICP_SOURCE = 0, SICP_TARGET = 1 };
+
+/* sicp_params.profile bits.  Each timed kernel adds one event synchronisation. */
+enum {
+  SICP_PROFILE_NN = 1,      /* correspondence search (nn_partial kernel)          */
+  SICP_PROFILE_COV = 2,     /* covariance self-kNN (nn_partial<20> kernel)        */
+  SICP_PROFILE_WEIGHT = 4,  /* EM weight kernel                                   */
+  SICP_PROFILE_ACC = 8      /* accumulate + finalize kernels, per LM evaluation   */
+};
+
+typedef struct sicp_context* sicp_handle;
+
+/* Tunables.  The reference hard-codes most of these as literals; defaults
+ * (sicp_default_params) reproduce them exactly. */
+typedef struct sicp_params {
+  int32_t mode;            /* SICP_MODE_*                                              */
+  int32_t knn;             /* correspondences per source point: 4 (em_icp.hpp:60) or 1  */
+  int32_t k_cov;           /* covariance neighbourhood (ctor arg k = 20, em_icp.h:42)   */
+  int32_t num_classes;     /* runtime C, replaces template parameter N (em_icp.h:16)    */
+  double epsilon;          /* ctor arg epsilon = 1e-3 (em_icp.h:43)                     */
+  double gate_sq;          /* 250, strict < (em_icp.hpp:65)                             */
+  double cauchy_a;         /* 3.0 (em_icp.hpp:111) / 1.5 (semantic_icp.hpp:96)          */
+  int32_t use_sqloss;      /* ComposedLoss(.., SQLoss): 1 EM/GICP, 0 Semantic            */
+  int32_t max_outer;       /* 50 (em_icp.hpp:180) / 35 (semantic_icp.hpp:152)            */
+  double outer_tol;        /* 1e-5 / 1e-3 on ||log(T_cur^-1 T_est)||^2                   */
+  int32_t min_class_pts;   /* 400, strict > (semantic_icp.hpp:51)                        */
+  int32_t max_lm_iterations;      /* 400 (em_icp.hpp:169)                                */
+  double gradient_tolerance;      /* 1e-11 (em_icp.hpp:163)                              */
+  double function_tolerance;      /* 1e-11 (em_icp.hpp:164)                              */
+  /* Ceres defaults the reference leaves untouched (Ceres 1.14..2.1 solver.h) */
+  double parameter_tolerance;     /* 1e-8  */
+  double initial_radius;          /* 1e4   */
+  double max_radius;              /* 1e16  */
+  double min_radius;              /* 1e-32 */
+  double min_relative_decrease;   /* 1e-3  */
+  double min_lm_diagonal;         /* 1e-6  */
+  double max_lm_diagonal;         /* 1e32  */
+  int32_t max_consecutive_invalid_steps; /* 5 */
+  int32_t jacobi_scaling;         /* 1 */
+  /* Reference quirks, reproduced by default (SURVEY.md 8a "Quirks") */
+  int32_t quirk_bool_probability; /* Q1: GICPCostFunction::Probability returns bool
+                                     (gicp_cost_function.h:75); 0 = use the double   */
+  int32_t quirk_float_products;   /* Q2: float32 products in the covariance moments
+                                     (em_icp.hpp:307-314); 0 = double products       */
+  /* engine knobs (no reference counterpart) */
+  int32_t nn_method;              /* 0 = LDS-tiled brute force (exact)                  */
+  int32_t profile;                /* SICP_PROFILE_* bit mask: bracket those kernels with
+                                     HIP events on the handle's stream (sicp_stats)     */
+} sicp_params;
+
+/* Per-align() counters; times in milliseconds.  *_kernel_ms are HIP-event
+ * times on the handle's stream and are only filled when params.profile = 1. */
+typedef struct sicp_stats {
+  int32_t outer_iters;      /* what getOuterIter() returns (em_icp.h:88-91)          */
+  int32_t total_lm_iters;
+  int32_t total_evals;      /* accumulate passes ("E" of SURVEY.md 8d), all outer    */
+  int32_t reserved0;
+  int64_t total_corr;       /* sum over outer passes of N_s*K candidate slots        */
+  int64_t total_active;     /* slots that passed the distance gate                   */
+  double final_cost;
+  double t_cov_ms, t_nn_ms, t_weight_ms, t_solve_ms, t_total_ms;  /* host wall clock */
+  double cov_kernel_ms;     /* nn_partial<k_cov> (self-kNN) launches                 */
+  double nn_kernel_ms;      /* nn_partial<K> (correspondence search) launches        */
+  double weight_kernel_ms;  /* EM weight kernel launches                             */
+  double acc_kernel_ms;     /* accumulate + finalize pairs                           */
+  int32_t cov_launches, nn_launches, weight_launches, acc_launches; /* timed launches */
+} sicp_stats;
+
+/* ---- lifetime ------------------------------------------------------------- */
+int sicp_device_count(int* count);
+/* replaces the three class constructors (em_icp.h:42-48, gicp.h:34-40,
+ * semantic_icp.h:35-39); mode and tunables follow via sicp_set_params */
+int sicp_create(int device_id, sicp_handle* out);
+int sicp_destroy(sicp_handle h);
+const char* sicp_strerror(int status);
+const char* sicp_last_error(sicp_handle h); /* detail of the last SICP_ERR_HIP */
+const char* sicp_version(void);
+
+/* ---- configuration --------------------------------------------------------- */
+int sicp_default_params(int mode, sicp_params* p);
+int sicp_set_params(sicp_handle h, const sicp_params* p);
+int sicp_get_params(sicp_handle h, sicp_params* p);
+
+/* setSourceCloud / setTargetCloud (em_icp.h:50-66, gicp.h:42-70) and
+ * setInputSource / setInputTarget (semantic_icp.h:41-49).  Copies the cloud to
+ * HBM (SoA).  label may be NULL for SICP_MODE_GICP.  In SICP_MODE_SEMANTIC the
+ * points are grouped by label in order of first appearance
+ * (pcl_2_semantic.h:24-39); all outputs stay in the caller's point order. */
+int sicp_set_cloud(sicp_handle h, int which, int32_t n, const float* x, const float* y,
+                   const float* z, const uint32_t* label);
+/* same, from buffers already resident on the handle's device */
+int sicp_set_cloud_device(sicp_handle h, int which, int32_t n, const float* x_device,
+                          const float* y_device, const float* z_device,
+                          const uint32_t* label_device);
+/* setConfusionMatrix (em_icp.h:68-71); cm is C*C row-major, cm[r*C+s] */
+int sicp_set_confusion(sicp_handle h, int32_t C, const double* cm_rowmajor);
+
+/* ---- the hot path ------------------------------------------------------------ */
+/* align(final, init) + getFinalTransFormation() + getOuterIter()
+ * (em_icp.hpp:25-200, gicp.hpp:29-175, semantic_icp.hpp:28-166).
+ * stats may be NULL. */
+int sicp_align(sicp_handle h, const double init_qt[7], double out_qt[7],
+               int32_t* outer_iters, sicp_stats* stats);
+
+/* the final_cloud output of align (em_icp.hpp:192-198): source transformed by
+ * float(matrix(qt)); ox/oy/oz are host buffers of n_source floats */
+int sicp_transform_source(sicp_handle h, const double qt[7], float* ox, float* oy, float* oz);
+
+/* getFusedLabels (em_icp.hpp:202-268): out_labels[n_source] */
+int sicp_fused_labels(sicp_handle h, const double qt[7], uint32_t* out_labels);
+
+/* ---- test / bench hooks: the individual stages -------------------------------- */
+/* ComputeCovariances (em_icp.hpp:270-343 = gicp.hpp:177-239 =
+ * semantic_point_cloud.hpp:25-84) for one cloud.  Any output may be NULL.
+ * cov9: n*9 row-major 3x3; normal3: n*3; hist: n*C uint8 neighbour counts
+ * (the reference's double histogram is count * (1/k) accumulated, em_icp.hpp:301);
+ * nn_idx: n*k_cov neighbour indices. */
+int sicp_covariances(sicp_handle h, int which, double* cov9, double* normal3, uint8_t* hist,
+                     int32_t* nn_idx);
+/* transform + nearestKSearch + gate (+ EM weight) at pose qt, i.e. the
+ * correspondence loop em_icp.hpp:46-108.  idx: n_source*K target indices
+ * (-1 = gated out), d2: n_source*K float32 squared distances, w: n_source*K
+ * weights (prob; 1 for non-EM).  Any output may be NULL; results stay on the
+ * device for sicp_accumulate. */
+int sicp_correspondences(sicp_handle h, const double qt[7], int32_t* idx, float* d2, double* w);
+/* one evaluation sweep of the inner solve at pose qt over the current
+ * correspondences: out28 = [H upper-triangular 21 | g 6 | cost], H = sum rho1 J J^T,
+ * g = sum rho1 r J, cost = 1/2 sum rho0 (what ceres::Evaluator produces from
+ * GICPCostFunction::Evaluate gicp_cost_function.h:27-73 through the losses). */
+int sicp_accumulate(sicp_handle h, const double qt[7], double out28[28]);
+/* the inner ceres::Solve (em_icp.hpp:162-177) on the current correspondences */
+int sicp_solve(sicp_handle h, const double init_qt[7], double out_qt[7], int32_t* lm_iters,
+               int32_t* evals, double* final_cost);
+
+int sicp_synchronize(sicp_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SICP_H_ */

@@ -1,0 +1,311 @@
+"""semantic-icp_amd -- MI355X-native semantic-ICP registration engine.
+
+This Python module is plumbing only: a ctypes view of the C ABI declared in
+include/sicp.h (implemented in csrc/ as hand-written gfx950 HIP kernels plus a
+C++ host driver).  Tests and bench.py call the engine through it.  The C++ class
+shims that keep the reference's API (SemanticIterativeClosestPoint,
+EmIterativeClosestPoint, GICP, SemanticPointCloud) live in host/.
+
+There is no CPU fallback: if libsicp.so cannot be built/loaded, or no HIP device
+is present, every call raises.
+
+The directory name contains a hyphen, so import it with
+    importlib.import_module("semantic-icp_amd")
+"""
+from __future__ import annotations
+
+import ctypes as C
+import importlib.util
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+
+MODE_GICP, MODE_EM, MODE_SEMANTIC = 0, 1, 2
+SOURCE, TARGET = 0, 1
+
+OK = 0
+ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_READY = -1, -2, -3, -4
+ERR_TOO_FEW_POINTS, ERR_BAD_LABEL, ERR_OUT_OF_MEMORY = -5, -6, -7
+
+
+class SicpParams(C.Structure):
+    _fields_ = [
+        ("mode", C.c_int32),
+        ("knn", C.c_int32),
+        ("k_cov", C.c_int32),
+        ("num_classes", C.c_int32),
+        ("epsilon", C.c_double),
+        ("gate_sq", C.c_double),
+        ("cauchy_a", C.c_double),
+        ("use_sqloss", C.c_int32),
+        ("max_outer", C.c_int32),
+        ("outer_tol", C.c_double),
+        ("min_class_pts", C.c_int32),
+        ("max_lm_iterations", C.c_int32),
+        ("gradient_tolerance", C.c_double),
+        ("function_tolerance", C.c_double),
+        ("parameter_tolerance", C.c_double),
+        ("initial_radius", C.c_double),
+        ("max_radius", C.c_double),
+        ("min_radius", C.c_double),
+        ("min_relative_decrease", C.c_double),
+        ("min_lm_diagonal", C.c_double),
+        ("max_lm_diagonal", C.c_double),
+        ("max_consecutive_invalid_steps", C.c_int32),
+        ("jacobi_scaling", C.c_int32),
+        ("quirk_bool_probability", C.c_int32),
+        ("quirk_float_products", C.c_int32),
+        ("nn_method", C.c_int32),
+        ("profile", C.c_int32),
+    ]
+
+
+class SicpStats(C.Structure):
+    _fields_ = [
+        ("outer_iters", C.c_int32),
+        ("total_lm_iters", C.c_int32),
+        ("total_evals", C.c_int32),
+        ("reserved0", C.c_int32),
+        ("total_corr", C.c_int64),
+        ("total_active", C.c_int64),
+        ("final_cost", C.c_double),
+        ("t_cov_ms", C.c_double),
+        ("t_nn_ms", C.c_double),
+        ("t_weight_ms", C.c_double),
+        ("t_solve_ms", C.c_double),
+        ("t_total_ms", C.c_double),
+        ("cov_kernel_ms", C.c_double),
+        ("nn_kernel_ms", C.c_double),
+        ("weight_kernel_ms", C.c_double),
+        ("acc_kernel_ms", C.c_double),
+        ("cov_launches", C.c_int32),
+        ("nn_launches", C.c_int32),
+        ("weight_launches", C.c_int32),
+        ("acc_launches", C.c_int32),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved0"}
+
+
+class SicpError(RuntimeError):
+    def __init__(self, status, where, detail=""):
+        self.status = status
+        msg = f"{where}: {_strerror(status)} ({status})"
+        if detail:
+            msg += f" -- {detail}"
+        super().__init__(msg)
+
+
+def _load_build_module():
+    spec = importlib.util.spec_from_file_location("_sicp_build", os.path.join(_PKG, "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile csrc/ for gfx950 into libsicp.so (in-tree)."""
+    return _load_build_module().build_lib(force=force, verbose=verbose)
+
+
+LIB_PATH = os.path.join(_PKG, "libsicp.so")
+_lib = None
+
+_dp = C.POINTER(C.c_double)
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int32)
+_up = C.POINTER(C.c_uint32)
+_bp = C.POINTER(C.c_uint8)
+
+
+def lib():
+    """The loaded C-ABI library.  Builds it when missing and hipcc is available;
+    raises if it can be neither found nor built (no silent fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        _lib = C.CDLL(LIB_PATH)
+        _lib.sicp_strerror.restype = C.c_char_p
+        _lib.sicp_last_error.restype = C.c_char_p
+        _lib.sicp_last_error.argtypes = [C.c_void_p]
+        _lib.sicp_version.restype = C.c_char_p
+        for name, args in {
+            "sicp_device_count": [C.POINTER(C.c_int)],
+            "sicp_create": [C.c_int, C.POINTER(C.c_void_p)],
+            "sicp_destroy": [C.c_void_p],
+            "sicp_default_params": [C.c_int, C.POINTER(SicpParams)],
+            "sicp_set_params": [C.c_void_p, C.POINTER(SicpParams)],
+            "sicp_get_params": [C.c_void_p, C.POINTER(SicpParams)],
+            "sicp_set_cloud": [C.c_void_p, C.c_int, C.c_int32, _fp, _fp, _fp, _up],
+            "sicp_set_cloud_device": [C.c_void_p, C.c_int, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+            "sicp_set_confusion": [C.c_void_p, C.c_int32, _dp],
+            "sicp_align": [C.c_void_p, _dp, _dp, _ip, C.POINTER(SicpStats)],
+            "sicp_transform_source": [C.c_void_p, _dp, _fp, _fp, _fp],
+            "sicp_fused_labels": [C.c_void_p, _dp, _up],
+            "sicp_covariances": [C.c_void_p, C.c_int, _dp, _dp, _bp, _ip],
+            "sicp_correspondences": [C.c_void_p, _dp, _ip, _fp, _dp],
+            "sicp_accumulate": [C.c_void_p, _dp, _dp],
+            "sicp_solve": [C.c_void_p, _dp, _dp, _ip, _ip, _dp],
+            "sicp_synchronize": [C.c_void_p],
+        }.items():
+            fn = getattr(_lib, name)
+            fn.argtypes = args
+            fn.restype = C.c_int
+    return _lib
+
+
+def _strerror(status: int) -> str:
+    return lib().sicp_strerror(status).decode()
+
+
+def version() -> str:
+    return lib().sicp_version().decode()
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    lib().sicp_device_count(C.byref(n))
+    return n.value
+
+
+def default_params(mode: int) -> SicpParams:
+    p = SicpParams()
+    st = lib().sicp_default_params(mode, C.byref(p))
+    if st != OK:
+        raise SicpError(st, "sicp_default_params")
+    return p
+
+
+def _ptr(a, t):
+    return None if a is None else a.ctypes.data_as(t)
+
+
+class Engine:
+    """One handle = one MI355X + one stream (include/sicp.h)."""
+
+    def __init__(self, device: int = 0, params: SicpParams | None = None):
+        self._h = C.c_void_p()
+        st = lib().sicp_create(device, C.byref(self._h))
+        if st != OK:
+            self._h = C.c_void_p()
+            raise SicpError(st, "sicp_create")
+        self.n = [0, 0]
+        if params is not None:
+            self.set_params(params)
+
+    def _check(self, st, where):
+        if st != OK:
+            detail = lib().sicp_last_error(self._h).decode() if st == ERR_HIP else ""
+            raise SicpError(st, where, detail)
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().sicp_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ---- configuration ----------------------------------------------------------
+    def set_params(self, p: SicpParams):
+        self._check(lib().sicp_set_params(self._h, C.byref(p)), "sicp_set_params")
+
+    def get_params(self) -> SicpParams:
+        p = SicpParams()
+        self._check(lib().sicp_get_params(self._h, C.byref(p)), "sicp_get_params")
+        return p
+
+    def set_cloud(self, which: int, xyz, labels=None):
+        xyz = np.asarray(xyz)
+        x, y, z = (np.ascontiguousarray(xyz[:, i], dtype=np.float32) for i in range(3))
+        lab = None if labels is None else np.ascontiguousarray(labels, dtype=np.uint32)
+        self._check(
+            lib().sicp_set_cloud(self._h, which, x.shape[0], _ptr(x, _fp), _ptr(y, _fp), _ptr(z, _fp), _ptr(lab, _up)),
+            "sicp_set_cloud",
+        )
+        self.n[which] = x.shape[0]
+
+    def set_source(self, xyz, labels=None):
+        self.set_cloud(SOURCE, xyz, labels)
+
+    def set_target(self, xyz, labels=None):
+        self.set_cloud(TARGET, xyz, labels)
+
+    def set_confusion(self, cm):
+        cm = np.ascontiguousarray(cm, dtype=np.float64)
+        assert cm.ndim == 2 and cm.shape[0] == cm.shape[1]
+        self._check(lib().sicp_set_confusion(self._h, cm.shape[0], _ptr(cm, _dp)), "sicp_set_confusion")
+
+    # ---- hot path -----------------------------------------------------------------
+    def align(self, init_qt=None, want_stats: bool = True):
+        init = np.array([0, 0, 0, 1, 0, 0, 0], dtype=np.float64) if init_qt is None else np.ascontiguousarray(init_qt, dtype=np.float64)
+        out = np.empty(7)
+        it = C.c_int32(0)
+        st = SicpStats()
+        self._check(
+            lib().sicp_align(self._h, _ptr(init, _dp), _ptr(out, _dp), C.byref(it), C.byref(st) if want_stats else None),
+            "sicp_align",
+        )
+        return out, (st.as_dict() if want_stats else {"outer_iters": it.value})
+
+    def transform_source(self, qt):
+        qt = np.ascontiguousarray(qt, dtype=np.float64)
+        n = self.n[SOURCE]
+        ox, oy, oz = (np.empty(n, dtype=np.float32) for _ in range(3))
+        self._check(lib().sicp_transform_source(self._h, _ptr(qt, _dp), _ptr(ox, _fp), _ptr(oy, _fp), _ptr(oz, _fp)), "sicp_transform_source")
+        return np.stack([ox, oy, oz], axis=1)
+
+    def fused_labels(self, qt):
+        qt = np.ascontiguousarray(qt, dtype=np.float64)
+        out = np.empty(self.n[SOURCE], dtype=np.uint32)
+        self._check(lib().sicp_fused_labels(self._h, _ptr(qt, _dp), _ptr(out, _up)), "sicp_fused_labels")
+        return out
+
+    # ---- stage hooks -----------------------------------------------------------------
+    def covariances(self, which: int, want_hist: bool = False, want_nn: bool = False):
+        n = self.n[which]
+        p = self.get_params()
+        cov = np.empty((n, 3, 3))
+        nrm = np.empty((n, 3))
+        hist = np.empty((n, p.num_classes), dtype=np.uint8) if want_hist else None
+        nn = np.empty((n, p.k_cov), dtype=np.int32) if want_nn else None
+        self._check(lib().sicp_covariances(self._h, which, _ptr(cov, _dp), _ptr(nrm, _dp), _ptr(hist, _bp), _ptr(nn, _ip)), "sicp_covariances")
+        return cov, nrm, hist, nn
+
+    def correspondences(self, qt):
+        qt = np.ascontiguousarray(qt, dtype=np.float64)
+        n, K = self.n[SOURCE], self.get_params().knn
+        idx = np.empty((n, K), dtype=np.int32)
+        d2 = np.empty((n, K), dtype=np.float32)
+        w = np.empty((n, K))
+        self._check(lib().sicp_correspondences(self._h, _ptr(qt, _dp), _ptr(idx, _ip), _ptr(d2, _fp), _ptr(w, _dp)), "sicp_correspondences")
+        return idx, d2, w
+
+    def accumulate(self, qt):
+        qt = np.ascontiguousarray(qt, dtype=np.float64)
+        out = np.empty(28)
+        self._check(lib().sicp_accumulate(self._h, _ptr(qt, _dp), _ptr(out, _dp)), "sicp_accumulate")
+        return out
+
+    def solve(self, init_qt):
+        init = np.ascontiguousarray(init_qt, dtype=np.float64)
+        out = np.empty(7)
+        it, ev, fc = C.c_int32(), C.c_int32(), C.c_double()
+        self._check(lib().sicp_solve(self._h, _ptr(init, _dp), _ptr(out, _dp), C.byref(it), C.byref(ev), C.byref(fc)), "sicp_solve")
+        return out, dict(lm_iters=it.value, evals=ev.value, cost=fc.value)
+
+    def synchronize(self):
+        self._check(lib().sicp_synchronize(self._h), "sicp_synchronize")

@@ -1,0 +1,96 @@
+// kernels.h -- argument blocks and launch wrappers of the gfx950 kernels (kernels.hip).
+#ifndef SICP_KERNELS_H_
+#define SICP_KERNELS_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sicp {
+
+struct Pose {
+  double R[9];  // row-major rotation (Eigen Quaternion::toRotationMatrix of the pose)
+  double t[3];
+};
+
+struct Mat4f {
+  float m[16];
+};
+
+struct LossArgs {
+  double cauchy_a;
+  int use_sqloss;
+};
+
+// one launch = queries [q_begin, q_begin+q_count) against targets [t_begin, t_begin+t_count)
+struct NNArgs {
+  const float *qx, *qy, *qz;
+  int q_begin, q_count;
+  int do_xform;   // 1: query = float(M * p) (pcl::transformPointCloud), 0: query = p
+  double M[12];   // rows 0..2 of the 4x4 pose matrix
+  const float *tx, *ty, *tz;
+  int t_begin, t_count;
+  int chunk_len;  // targets per grid.y slice
+  float* part_d;  // [n_chunks][q_count][K]
+  int* part_i;    // indices relative to t_begin
+};
+
+struct MergeArgs {
+  int q_begin, q_count, n_chunks, t_begin;
+  const float* part_d;
+  const int* part_i;
+  float gate_sq;  // +inf for the covariance self-query
+  int* out_i;     // [n][K] global target indices, -1 = none / gated out
+  float* out_d;   // [n][K] or nullptr
+};
+
+struct CovArgs {
+  int n, k, C;
+  const float *x, *y, *z;
+  const uint32_t* label;  // nullable
+  const int* nn;          // [n][k] global indices
+  int float_products;
+  double *nx, *ny, *nz;
+  uint8_t* hist;          // [n][C] or nullptr
+};
+
+struct WeightArgs {
+  int n_s, K, C;
+  const int* idx;
+  const float *sx, *sy, *sz, *tx, *ty, *tz;
+  const double *snx, *sny, *snz, *tnx, *tny, *tnz;
+  const uint8_t *s_hist, *t_hist;
+  const double* cm;    // C*C row-major
+  const double* hval;  // hval[c] = c additions of 1/k (em_icp.hpp:279,301)
+  Pose pose;
+  double one_m_eps;
+  int bool_probability;
+  double* w;
+};
+
+struct AccArgs {
+  int n_s, K;
+  const int* idx;
+  const double* w;  // nullable (weight 1)
+  const float *sx, *sy, *sz, *tx, *ty, *tz;
+  const double *snx, *sny, *snz, *tnx, *tny, *tnz;
+  Pose pose;
+  double one_m_eps;
+  LossArgs loss;
+  double* partials;  // [accumulate_blocks][28]
+};
+
+bool nn_k_supported(int K);
+int nn_queries_per_thread(int K);
+hipError_t launch_nn_partial(int K, const NNArgs& a, int n_chunks, hipStream_t st);
+hipError_t launch_nn_merge(int K, const MergeArgs& m, hipStream_t st);
+hipError_t launch_cov(const CovArgs& a, hipStream_t st);
+hipError_t launch_em_weight(const WeightArgs& a, hipStream_t st);
+hipError_t launch_fused_labels(const WeightArgs& a, uint32_t* out, hipStream_t st);
+int accumulate_blocks(int total);
+hipError_t launch_accumulate(const AccArgs& a, double* out28, hipStream_t st);
+hipError_t launch_count_active(const int* idx, int n, unsigned long long* out, hipStream_t st);
+hipError_t launch_transform_float(int n, const float* x, const float* y, const float* z, const Mat4f& M,
+                                  float* ox, float* oy, float* oz, hipStream_t st);
+
+}  // namespace sicp
+#endif

@@ -1,0 +1,573 @@
+// kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels for the semantic-ICP hot path.
+//
+// What each kernel replaces in the reference (paths relative to /root/reference):
+//   nn_partial / nn_merge : pcl::transformPointCloud + KdTreeFLANN::nearestKSearch + the
+//                           dist^2 < 250 gate            em_icp.hpp:46-65, gicp.hpp:54-70,
+//                                                        semantic_icp.hpp:53-69
+//   cov_kernel            : ComputeCovariances body      em_icp.hpp:298-340
+//   em_weight_kernel      : label posterior * Probability em_icp.hpp:77-89,108
+//   accumulate / finalize : GICPCostFunction::Evaluate + LocalParameterizationSE3 + losses +
+//                           Ceres' Corrector, summed to 28 doubles
+//                                                        gicp_cost_function.h:27-73
+//
+// Design notes (MI355X): SoA float32 clouds for coalesced reads; target tiles staged in LDS and
+// read back as wave-uniform (broadcast) ds_read_b128; top-K kept in statically indexed VGPRs;
+// the N_s x N_t search is split over a 2-D grid (query blocks x target chunks) so that >>256
+// workgroups are in flight, with a deterministic merge; no atomics anywhere, so every result is
+// run-to-run reproducible.  Nothing here is GEMM shaped: no MFMA.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+
+namespace sicp {
+
+// ------------------------------------------------------------------------------------------
+// helpers
+// ------------------------------------------------------------------------------------------
+
+// pcl::transformPointCloud<PointT,double>: (((m0*x + m1*y) + m2*z) + m3) in double, no
+// contraction, then one rounding to float.
+__device__ __forceinline__ float xform_row(const double* m, double x, double y, double z) {
+  double a = __dmul_rn(m[0], x);
+  a = __dadd_rn(a, __dmul_rn(m[1], y));
+  a = __dadd_rn(a, __dmul_rn(m[2], z));
+  a = __dadd_rn(a, m[3]);
+  return __double2float_rn(a);
+}
+
+// FLANN L2_Simple<float>: ((dx*dx) + dy*dy) + dz*dz, every product and sum rounded to float
+// (no FMA contraction, so that neighbour order matches the CPU kd-tree bit for bit).
+__device__ __forceinline__ float l2_simple(float ax, float ay, float az, float bx, float by, float bz) {
+  const float dx = __fsub_rn(ax, bx), dy = __fsub_rn(ay, by), dz = __fsub_rn(az, bz);
+  float r = __fmul_rn(dx, dx);
+  r = __fadd_rn(r, __fmul_rn(dy, dy));
+  r = __fadd_rn(r, __fmul_rn(dz, dz));
+  return r;
+}
+
+// Insert (d, i) into an ascending list held in registers.  Precondition: d < bd[K-1].
+// Strict comparisons keep the earlier (lower-index) entry first on ties.
+template <int K>
+__device__ __forceinline__ void topk_insert(float (&bd)[K], int (&bi)[K], float d, int i) {
+  bd[K - 1] = d;
+  bi[K - 1] = i;
+#pragma unroll
+  for (int j = K - 1; j > 0; --j) {
+    const bool sw = bd[j] < bd[j - 1];
+    const float dlo = sw ? bd[j] : bd[j - 1], dhi = sw ? bd[j - 1] : bd[j];
+    const int ilo = sw ? bi[j] : bi[j - 1], ihi = sw ? bi[j - 1] : bi[j];
+    bd[j - 1] = dlo; bd[j] = dhi;
+    bi[j - 1] = ilo; bi[j] = ihi;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// brute-force kNN, partial pass: grid = (query blocks, target chunks)
+// ------------------------------------------------------------------------------------------
+template <int K, int Q, int BS, int TILE>
+__global__ __launch_bounds__(BS) void nn_partial_kernel(NNArgs a) {
+  __shared__ float4 tile[TILE];
+  const int chunk = blockIdx.y;
+  const int c_lo = chunk * a.chunk_len;
+  const int c_hi = min(c_lo + a.chunk_len, a.t_count);
+
+  float px[Q], py[Q], pz[Q];
+  float bd[Q][K];
+  int bi[Q][K];
+#pragma unroll
+  for (int j = 0; j < Q; ++j) {
+    int q = blockIdx.x * (BS * Q) + j * BS + threadIdx.x;
+    q = min(q, a.q_count - 1);
+    const float x = a.qx[a.q_begin + q], y = a.qy[a.q_begin + q], z = a.qz[a.q_begin + q];
+    if (a.do_xform) {
+      const double dx = x, dy = y, dz = z;
+      px[j] = xform_row(a.M + 0, dx, dy, dz);
+      py[j] = xform_row(a.M + 4, dx, dy, dz);
+      pz[j] = xform_row(a.M + 8, dx, dy, dz);
+    } else {
+      px[j] = x; py[j] = y; pz[j] = z;
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) { bd[j][k] = INFINITY; bi[j][k] = -1; }
+  }
+
+  for (int t0 = c_lo; t0 < c_hi; t0 += TILE) {
+    const int n = min(TILE, c_hi - t0);
+    __syncthreads();
+    for (int p = threadIdx.x; p < n; p += BS) {
+      const int g = a.t_begin + t0 + p;
+      tile[p] = make_float4(a.tx[g], a.ty[g], a.tz[g], 0.f);
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int p = 0; p < n; ++p) {
+      const float4 t = tile[p];  // wave-uniform address: one broadcast ds_read_b128
+#pragma unroll
+      for (int j = 0; j < Q; ++j) {
+        const float d = l2_simple(px[j], py[j], pz[j], t.x, t.y, t.z);
+        if (d < bd[j][K - 1]) topk_insert<K>(bd[j], bi[j], d, t0 + p);
+      }
+    }
+  }
+
+#pragma unroll
+  for (int j = 0; j < Q; ++j) {
+    const int q = blockIdx.x * (BS * Q) + j * BS + threadIdx.x;
+    if (q < a.q_count) {
+      const size_t o = ((size_t)chunk * a.q_count + q) * K;
+#pragma unroll
+      for (int k = 0; k < K; ++k) { a.part_d[o + k] = bd[j][k]; a.part_i[o + k] = bi[j][k]; }
+    }
+  }
+}
+
+// merge the per-chunk lists (ascending chunk order == ascending index order, so strict <
+// keeps the lowest index on ties), apply the distance gate, emit global target indices
+template <int K>
+__global__ __launch_bounds__(256) void nn_merge_kernel(MergeArgs a) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= a.q_count) return;
+  float bd[K];
+  int bi[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) { bd[k] = INFINITY; bi[k] = -1; }
+  for (int c = 0; c < a.n_chunks; ++c) {
+    const size_t o = ((size_t)c * a.q_count + q) * K;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const float d = a.part_d[o + k];
+      const int i = a.part_i[o + k];
+      if (i >= 0 && d < bd[K - 1]) topk_insert<K>(bd, bi, d, i);
+    }
+  }
+  const size_t o = (size_t)(a.q_begin + q) * K;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const bool keep = bi[k] >= 0 && bd[k] < a.gate_sq;  // strict <, float compare (em_icp.hpp:65)
+    a.out_i[o + k] = keep ? bi[k] + a.t_begin : -1;
+    if (a.out_d) a.out_d[o + k] = bd[k];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// covariance / normal / label histogram from the k-neighbour lists   (em_icp.hpp:298-340)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void jacobi_rotate(double (&A)[3][3], double (&V)[3][3], int p, int q) {
+  const double apq = A[p][q];
+  if (apq == 0.0) return;
+  const double tau = (A[q][q] - A[p][p]) / (2.0 * apq);
+  const double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+  const double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double akp = A[k][p], akq = A[k][q];
+    A[k][p] = c * akp - s * akq;
+    A[k][q] = s * akp + c * akq;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double apk = A[p][k], aqk = A[q][k];
+    A[p][k] = c * apk - s * aqk;
+    A[q][k] = s * apk + c * aqk;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double vkp = V[k][p], vkq = V[k][q];
+    V[k][p] = c * vkp - s * vkq;
+    V[k][q] = s * vkp + c * vkq;
+  }
+}
+
+__global__ __launch_bounds__(256) void cov_kernel(CovArgs a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  double mean0 = 0, mean1 = 0, mean2 = 0;
+  double c00 = 0, c10 = 0, c11 = 0, c20 = 0, c21 = 0, c22 = 0;
+  const int* nn = a.nn + (size_t)i * a.k;
+  for (int j = 0; j < a.k; ++j) {
+    const int g = nn[j];
+    if (g < 0) continue;
+    const float x = a.x[g], y = a.y[g], z = a.z[g];
+    mean0 += (double)x; mean1 += (double)y; mean2 += (double)z;
+    if (a.float_products) {
+      // quirk Q2: pt.y*pt.x is a float32 product (em_icp.hpp:307-314)
+      c00 += (double)__fmul_rn(x, x);
+      c10 += (double)__fmul_rn(y, x);
+      c11 += (double)__fmul_rn(y, y);
+      c20 += (double)__fmul_rn(z, x);
+      c21 += (double)__fmul_rn(z, y);
+      c22 += (double)__fmul_rn(z, z);
+    } else {
+      const double dx = x, dy = y, dz = z;
+      c00 += dx * dx; c10 += dy * dx; c11 += dy * dy;
+      c20 += dz * dx; c21 += dz * dy; c22 += dz * dz;
+    }
+  }
+  // quirk Q3: divide by k whatever the neighbour count (em_icp.hpp:317,320)
+  const double kk = (double)a.k;
+  mean0 /= kk; mean1 /= kk; mean2 /= kk;
+  double A[3][3], V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  A[0][0] = __dsub_rn(c00 / kk, __dmul_rn(mean0, mean0));
+  A[1][0] = A[0][1] = __dsub_rn(c10 / kk, __dmul_rn(mean1, mean0));
+  A[1][1] = __dsub_rn(c11 / kk, __dmul_rn(mean1, mean1));
+  A[2][0] = A[0][2] = __dsub_rn(c20 / kk, __dmul_rn(mean2, mean0));
+  A[2][1] = A[1][2] = __dsub_rn(c21 / kk, __dmul_rn(mean2, mean1));
+  A[2][2] = __dsub_rn(c22 / kk, __dmul_rn(mean2, mean2));
+  // stand-in for Eigen::JacobiSVD(ComputeFullU) on a symmetric matrix: cyclic Jacobi;
+  // singular values = |eigenvalues|, the "normal" is the column of smallest |eigenvalue|
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    const double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+    const double dia = A[0][0] * A[0][0] + A[1][1] * A[1][1] + A[2][2] * A[2][2];
+    if (off <= 1e-300 || off <= 1e-34 * dia) break;
+    jacobi_rotate(A, V, 0, 1);
+    jacobi_rotate(A, V, 0, 2);
+    jacobi_rotate(A, V, 1, 2);
+  }
+  const double e0 = fabs(A[0][0]), e1 = fabs(A[1][1]), e2 = fabs(A[2][2]);
+  // last column after a stable descending sort by |eigenvalue| (ties keep the later column)
+  int col = 0;
+  double em = e0;
+  if (e1 <= em) { em = e1; col = 1; }
+  if (e2 <= em) { em = e2; col = 2; }
+  double nx = col == 0 ? V[0][0] : (col == 1 ? V[0][1] : V[0][2]);
+  double ny = col == 0 ? V[1][0] : (col == 1 ? V[1][1] : V[1][2]);
+  double nz = col == 0 ? V[2][0] : (col == 1 ? V[2][1] : V[2][2]);
+  a.nx[i] = nx; a.ny[i] = ny; a.nz[i] = nz;
+  if (a.hist) {
+    // label histogram as neighbour counts (em_icp.hpp:301: dist(label-1) += 1/k)
+    uint8_t* h = a.hist + (size_t)i * a.C;
+    for (int c = 0; c < a.C; ++c) {
+      int cnt = 0;
+      for (int j = 0; j < a.k; ++j) {
+        const int g = nn[j];
+        if (g >= 0) cnt += (a.label[g] == (uint32_t)(c + 1)) ? 1 : 0;
+      }
+      h[c] = (uint8_t)cnt;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// per-correspondence math (closed form of gicp_cost_function.h:31-70
+// chained with Sophus' Dx_this_mul_exp_x_at_0, for C = I - (1-eps) n n^T)
+// ------------------------------------------------------------------------------------------
+struct Corr {
+  double r;        // res^T A^-1 res  (the Ceres residual: squared Mahalanobis distance)
+  double J[6];     // d r / d delta, T*exp(delta), delta = [upsilon; omega]
+  double detA;
+};
+
+template <bool WANT_J>
+__device__ __forceinline__ void corr_eval(const Pose& P, double one_m_eps, double psx, double psy,
+                                          double psz, double nsx, double nsy, double nsz,
+                                          double ptx, double pty, double ptz, double ntx,
+                                          double nty, double ntz, Corr& o) {
+  const double* R = P.R;
+  const double mx = R[0] * nsx + R[1] * nsy + R[2] * nsz;
+  const double my = R[3] * nsx + R[4] * nsy + R[5] * nsz;
+  const double mz = R[6] * nsx + R[7] * nsy + R[8] * nsz;
+  // A = C_t + R C_s R^T = 2I - (1-eps)(n_t n_t^T + m m^T)
+  const double a00 = 2.0 - one_m_eps * (ntx * ntx + mx * mx);
+  const double a01 = -one_m_eps * (ntx * nty + mx * my);
+  const double a02 = -one_m_eps * (ntx * ntz + mx * mz);
+  const double a11 = 2.0 - one_m_eps * (nty * nty + my * my);
+  const double a12 = -one_m_eps * (nty * ntz + my * mz);
+  const double a22 = 2.0 - one_m_eps * (ntz * ntz + mz * mz);
+  const double rx = ptx - (R[0] * psx + R[1] * psy + R[2] * psz + P.t[0]);
+  const double ry = pty - (R[3] * psx + R[4] * psy + R[5] * psz + P.t[1]);
+  const double rz = ptz - (R[6] * psx + R[7] * psy + R[8] * psz + P.t[2]);
+  // Eigen Matrix3d::inverse(): cofactors / determinant
+  const double k00 = a11 * a22 - a12 * a12;
+  const double k01 = a02 * a12 - a01 * a22;
+  const double k02 = a01 * a12 - a02 * a11;
+  const double k11 = a00 * a22 - a02 * a02;
+  const double k12 = a01 * a02 - a00 * a12;
+  const double k22 = a00 * a11 - a01 * a01;
+  const double det = a00 * k00 + a01 * k01 + a02 * k02;
+  const double inv = 1.0 / det;
+  const double ax = inv * (k00 * rx + k01 * ry + k02 * rz);
+  const double ay = inv * (k01 * rx + k11 * ry + k12 * rz);
+  const double az = inv * (k02 * rx + k12 * ry + k22 * rz);
+  o.r = rx * ax + ry * ay + rz * az;
+  o.detA = det;
+  if (WANT_J) {
+    const double bx = R[0] * ax + R[3] * ay + R[6] * az;  // b = R^T a
+    const double by = R[1] * ax + R[4] * ay + R[7] * az;
+    const double bz = R[2] * ax + R[5] * ay + R[8] * az;
+    const double nb = one_m_eps * (nsx * bx + nsy * by + nsz * bz);
+    const double cx = psx + bx - nb * nsx;  // c = p_s + C_s b
+    const double cy = psy + by - nb * nsy;
+    const double cz = psz + bz - nb * nsz;
+    o.J[0] = -2.0 * bx; o.J[1] = -2.0 * by; o.J[2] = -2.0 * bz;
+    o.J[3] = 2.0 * (by * cz - bz * cy);
+    o.J[4] = 2.0 * (bz * cx - bx * cz);
+    o.J[5] = 2.0 * (bx * cy - by * cx);
+  }
+}
+
+// rho0 / rho1 of the reference's loss stacks at s = r^2 (em_icp.hpp:109-117,
+// gicp.hpp:98-104, semantic_icp.hpp:96; Ceres CauchyLoss/ScaledLoss/ComposedLoss, sqloss.h).
+// rho2 < 0 for all of them, so Ceres' Corrector scales residual and Jacobian by sqrt(rho1).
+__device__ __forceinline__ void loss_eval(const LossArgs& L, double s, double w, double& rho0, double& rho1) {
+  const double b = L.cauchy_a * L.cauchy_a, c = 1.0 / b;
+  if (L.use_sqloss) {
+    const double v = s + 2.220446049250313e-16;  // std::numeric_limits<double>::epsilon()
+    const double g0 = sqrt(v), g1 = 1.0 / (2.0 * g0);
+    const double sum = 1.0 + g0 * c, invs = 1.0 / sum;
+    double f0 = b * log(sum);
+    double f1 = fmax(2.2250738585072014e-308, invs);
+    f0 *= w; f1 *= w;  // ScaledLoss (w == 1 outside EM)
+    rho0 = f0;
+    rho1 = f1 * g1;
+  } else {
+    const double sum = 1.0 + s * c, invs = 1.0 / sum;
+    rho0 = b * log(sum);
+    rho1 = fmax(2.2250738585072014e-308, invs);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// EM weight: label posterior from the confusion matrix x the (bool) geometric gate
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void em_weight_kernel(WeightArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double cm_lds[];  // C*C confusion matrix
+  for (int e = threadIdx.x; e < a.C * a.C; e += blockDim.x) cm_lds[e] = a.cm[e];
+  __syncthreads();
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= a.n_s * a.K) return;
+  const int i = e / a.K;
+  const int j = a.idx[e];
+  if (j < 0) { a.w[e] = 0.0; return; }
+  const uint8_t* hs = a.s_hist + (size_t)i * a.C;
+  const uint8_t* ht = a.t_hist + (size_t)j * a.C;
+  // em_icp.hpp:84-89
+  double prob = 0.0;
+  for (int s = 0; s < a.C; ++s) {
+    double temp = 0.0, temp2 = 0.0;
+    for (int r = 0; r < a.C; ++r) {
+      const double cm = cm_lds[r * a.C + s];
+      temp += a.hval[ht[r]] * cm;
+      temp2 += a.hval[hs[r]] * cm;
+    }
+    temp *= temp2;
+    prob += temp;
+  }
+  // em_icp.hpp:108 -> gicp_cost_function.h:75-87
+  Corr c;
+  corr_eval<false>(a.pose, a.one_m_eps, a.sx[i], a.sy[i], a.sz[i], a.snx[i], a.sny[i], a.snz[i],
+                   a.tx[j], a.ty[j], a.tz[j], a.tnx[j], a.tny[j], a.tnz[j], c);
+  const double two_pi = 6.283185307179586;
+  const double probability = pow(two_pi * two_pi * two_pi * c.detA, -0.5) * exp(-0.5 * c.r);
+  if (a.bool_probability) {
+    prob *= (probability != 0.0) ? 1.0 : 0.0;  // quirk Q1: double -> bool (NaN -> true)
+  } else {
+    prob *= probability;
+  }
+  a.w[e] = prob;
+}
+
+// ------------------------------------------------------------------------------------------
+// accumulate: 28 doubles = [H upper 21 | g 6 | cost] over all correspondence slots
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+template <int BS>
+__global__ __launch_bounds__(BS) void accumulate_kernel(AccArgs a) {
+  __shared__ double red[BS / 64][28];
+  double acc[28];
+#pragma unroll
+  for (int k = 0; k < 28; ++k) acc[k] = 0.0;
+  const int total = a.n_s * a.K;
+  for (int e = blockIdx.x * BS + threadIdx.x; e < total; e += gridDim.x * BS) {
+    const int j = a.idx[e];
+    if (j < 0) continue;
+    const int i = e / a.K;
+    Corr c;
+    corr_eval<true>(a.pose, a.one_m_eps, a.sx[i], a.sy[i], a.sz[i], a.snx[i], a.sny[i], a.snz[i],
+                    a.tx[j], a.ty[j], a.tz[j], a.tnx[j], a.tny[j], a.tnz[j], c);
+    const double w = a.w ? a.w[e] : 1.0;
+    double rho0, rho1;
+    loss_eval(a.loss, c.r * c.r, w, rho0, rho1);
+    int o = 0;
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
+      const double jp = rho1 * c.J[p];
+#pragma unroll
+      for (int q = p; q < 6; ++q) acc[o++] += jp * c.J[q];
+      acc[21 + p] += jp * c.r;
+    }
+    acc[27] += 0.5 * rho0;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 28; ++k) {
+    const double s = wave_sum(acc[k]);
+    if (lane == 0) red[wave][k] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 28) {
+    double s = 0.0;
+#pragma unroll
+    for (int wv = 0; wv < BS / 64; ++wv) s += red[wv][threadIdx.x];
+    a.partials[(size_t)blockIdx.x * 28 + threadIdx.x] = s;
+  }
+}
+
+// sum the per-block partials in a fixed order: one wave per output (16 waves, 28 outputs)
+__global__ __launch_bounds__(1024) void finalize_kernel(const double* partials, int n_blocks, double* out28) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int k = wave; k < 28; k += 16) {
+    double s = 0.0;
+    for (int b = lane; b < n_blocks; b += 64) s += partials[(size_t)b * 28 + k];
+    s = wave_sum(s);
+    if (lane == 0) out28[k] = s;
+  }
+}
+
+// final_cloud = float(matrix) * source, the float overload of pcl::transformPointCloud
+// (em_icp.hpp:192-198): float matrix, float arithmetic, row by row
+__global__ void transform_float_kernel(int n, const float* x, const float* y, const float* z, Mat4f M,
+                                       float* ox, float* oy, float* oz) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float px = x[i], py = y[i], pz = z[i];
+  const float* m = M.m;
+  ox[i] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(m[0], px), __fmul_rn(m[1], py)), __fmul_rn(m[2], pz)), m[3]);
+  oy[i] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(m[4], px), __fmul_rn(m[5], py)), __fmul_rn(m[6], pz)), m[7]);
+  oz[i] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(m[8], px), __fmul_rn(m[9], py)), __fmul_rn(m[10], pz)), m[11]);
+}
+
+// fused label = arg max_s sum_c prob_c * (t_c . CM[:,s]) (s_i . CM[:,s])   (em_icp.hpp:224-266)
+__global__ __launch_bounds__(256) void fused_label_kernel(WeightArgs a, uint32_t* out_labels) {
+  extern __shared__ __attribute__((aligned(16))) double cm_lds[];
+  for (int e = threadIdx.x; e < a.C * a.C; e += blockDim.x) cm_lds[e] = a.cm[e];
+  __syncthreads();
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n_s) return;
+  const uint8_t* hs = a.s_hist + (size_t)i * a.C;
+  double max_prob = 0.0;
+  int max_s = 0;
+  for (int s = 0; s < a.C; ++s) {
+    double temp2 = 0.0;
+    for (int r = 0; r < a.C; ++r) temp2 += a.hval[hs[r]] * cm_lds[r * a.C + s];
+    double sprob = 0.0;
+    for (int c = 0; c < a.K; ++c) {
+      const int j = a.idx[(size_t)i * a.K + c];
+      if (j < 0) continue;
+      const uint8_t* ht = a.t_hist + (size_t)j * a.C;
+      double temp = 0.0;
+      for (int r = 0; r < a.C; ++r) temp += a.hval[ht[r]] * cm_lds[r * a.C + s];
+      Corr cr;
+      corr_eval<false>(a.pose, a.one_m_eps, a.sx[i], a.sy[i], a.sz[i], a.snx[i], a.sny[i], a.snz[i],
+                       a.tx[j], a.ty[j], a.tz[j], a.tnx[j], a.tny[j], a.tnz[j], cr);
+      const double two_pi = 6.283185307179586;
+      const double probability = pow(two_pi * two_pi * two_pi * cr.detA, -0.5) * exp(-0.5 * cr.r);
+      const double prob = a.bool_probability ? ((probability != 0.0) ? 1.0 : 0.0) : probability;
+      temp *= temp2;
+      sprob += temp * prob;
+    }
+    if (sprob > max_prob) { max_s = s; max_prob = sprob; }  // first max wins (em_icp.hpp:259)
+  }
+  out_labels[i] = (uint32_t)(max_s + 1);
+}
+
+// statistics: number of live correspondence slots (integer atomics: order independent)
+__global__ void count_active_kernel(const int* idx, int n, unsigned long long* out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = e < n && idx[e] >= 0;
+  const unsigned long long m = __ballot(live);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(out, (unsigned long long)__popcll(m));
+}
+
+// ------------------------------------------------------------------------------------------
+// launch wrappers
+// ------------------------------------------------------------------------------------------
+static constexpr int NN_BS = 256;
+static constexpr int NN_TILE = 1024;
+
+int nn_queries_per_thread(int K) { return K == 1 ? 4 : (K <= 4 ? 2 : 1); }
+
+template <int K, int Q>
+static hipError_t launch_nn_partial(const NNArgs& a, int n_chunks, hipStream_t st) {
+  dim3 grid((a.q_count + NN_BS * Q - 1) / (NN_BS * Q), n_chunks);
+  hipLaunchKernelGGL((nn_partial_kernel<K, Q, NN_BS, NN_TILE>), grid, dim3(NN_BS), 0, st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_nn_partial(int K, const NNArgs& a, int n_chunks, hipStream_t st) {
+  switch (K) {
+    case 1: return launch_nn_partial<1, 4>(a, n_chunks, st);
+    case 4: return launch_nn_partial<4, 2>(a, n_chunks, st);
+    case 20: return launch_nn_partial<20, 1>(a, n_chunks, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t launch_nn_merge(int K, const MergeArgs& m, hipStream_t st) {
+  dim3 grid((m.q_count + 255) / 256);
+  switch (K) {
+    case 1: hipLaunchKernelGGL((nn_merge_kernel<1>), grid, dim3(256), 0, st, m); break;
+    case 4: hipLaunchKernelGGL((nn_merge_kernel<4>), grid, dim3(256), 0, st, m); break;
+    case 20: hipLaunchKernelGGL((nn_merge_kernel<20>), grid, dim3(256), 0, st, m); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+bool nn_k_supported(int K) { return K == 1 || K == 4 || K == 20; }
+
+hipError_t launch_cov(const CovArgs& a, hipStream_t st) {
+  if (a.n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(cov_kernel, dim3((a.n + 255) / 256), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_em_weight(const WeightArgs& a, hipStream_t st) {
+  const int total = a.n_s * a.K;
+  if (total <= 0) return hipSuccess;
+  hipLaunchKernelGGL(em_weight_kernel, dim3((total + 255) / 256), dim3(256), sizeof(double) * a.C * a.C, st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_fused_labels(const WeightArgs& a, uint32_t* out, hipStream_t st) {
+  if (a.n_s <= 0) return hipSuccess;
+  hipLaunchKernelGGL(fused_label_kernel, dim3((a.n_s + 255) / 256), dim3(256), sizeof(double) * a.C * a.C, st, a, out);
+  return hipGetLastError();
+}
+
+int accumulate_blocks(int total) {
+  const int bs = 256;
+  int nb = (total + bs - 1) / bs;
+  if (nb > 1024) nb = 1024;
+  if (nb < 1) nb = 1;
+  return nb;
+}
+
+hipError_t launch_accumulate(const AccArgs& a, double* out28, hipStream_t st) {
+  const int nb = accumulate_blocks(a.n_s * a.K);
+  hipLaunchKernelGGL((accumulate_kernel<256>), dim3(nb), dim3(256), 0, st, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(1024), 0, st, a.partials, nb, out28);
+  return hipGetLastError();
+}
+
+hipError_t launch_count_active(const int* idx, int n, unsigned long long* out, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(count_active_kernel, dim3((n + 255) / 256), dim3(256), 0, st, idx, n, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_transform_float(int n, const float* x, const float* y, const float* z, const Mat4f& M,
+                                  float* ox, float* oy, float* oz, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(transform_float_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, x, y, z, M, ox, oy, oz);
+  return hipGetLastError();
+}
+
+}  // namespace sicp

@@ -1,0 +1,157 @@
+// se3.hpp -- host-side SE(3) for the engine (product code; the reference uses Sophus::SE3d,
+// which is not vendored and not installed here, so its published formulas are restated).
+//
+// Storage: qt[7] = [qx qy qz qw tx ty tz] (Sophus order, gicp_cost_function.h:64-70).
+// Tangent: [upsilon(3); omega(3)], updates are T * exp(delta)
+// (local_parameterization_se3.h:17-25).
+#ifndef SICP_SE3_HPP_
+#define SICP_SE3_HPP_
+
+#include <cmath>
+#include <cstring>
+
+namespace sicp {
+namespace se3 {
+
+constexpr double kEps = 1e-10;  // Sophus::Constants<double>::epsilon()
+constexpr double kPi = 3.14159265358979323846;
+
+// Eigen Quaternion::toRotationMatrix (no normalisation), row-major
+inline void rotation(const double* qt, double* R) {
+  const double x = qt[0], y = qt[1], z = qt[2], w = qt[3];
+  const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+  const double twx = tx * w, twy = ty * w, twz = tz * w;
+  const double txx = tx * x, txy = ty * x, txz = tz * x;
+  const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  R[0] = 1 - (tyy + tzz); R[1] = txy - twz;       R[2] = txz + twy;
+  R[3] = txy + twz;       R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
+}
+
+inline void matvec3(const double* A, const double* v, double* o) {
+  const double a = A[0] * v[0] + A[1] * v[1] + A[2] * v[2];
+  const double b = A[3] * v[0] + A[4] * v[1] + A[5] * v[2];
+  const double c = A[6] * v[0] + A[7] * v[1] + A[8] * v[2];
+  o[0] = a; o[1] = b; o[2] = c;
+}
+
+// rows 0..2 of the 4x4 matrix, row-major 3x4 (what pcl::transformPointCloud consumes)
+inline void matrix34(const double* qt, double* M) {
+  double R[9];
+  rotation(qt, R);
+  for (int i = 0; i < 3; ++i) {
+    M[4 * i + 0] = R[3 * i + 0]; M[4 * i + 1] = R[3 * i + 1]; M[4 * i + 2] = R[3 * i + 2];
+    M[4 * i + 3] = qt[4 + i];
+  }
+}
+
+// Sophus SE3::exp
+inline void exp(const double* a, double* qt) {
+  const double* w = a + 3;
+  const double theta_sq = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  const double theta = std::sqrt(theta_sq);
+  double imag, real;
+  if (theta < kEps) {
+    const double t4 = theta_sq * theta_sq;
+    imag = 0.5 - theta_sq / 48.0 + t4 / 3840.0;
+    real = 1.0 - theta_sq / 8.0 + t4 / 384.0;
+  } else {
+    imag = std::sin(0.5 * theta) / theta;
+    real = std::cos(0.5 * theta);
+  }
+  qt[0] = imag * w[0]; qt[1] = imag * w[1]; qt[2] = imag * w[2]; qt[3] = real;
+  // V = I + (1-cos)/th^2 * W + (th - sin)/th^3 * W^2 ; small angle: V = R
+  double V[9];
+  if (theta < kEps) {
+    rotation(qt, V);
+  } else {
+    const double c1 = (1 - std::cos(theta)) / theta_sq, c2 = (theta - std::sin(theta)) / (theta_sq * theta);
+    const double W[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+    double W2[9];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j)
+        W2[3 * i + j] = W[3 * i] * W[j] + W[3 * i + 1] * W[3 + j] + W[3 * i + 2] * W[6 + j];
+    for (int i = 0; i < 9; ++i) V[i] = c1 * W[i] + c2 * W2[i];
+    V[0] += 1; V[4] += 1; V[8] += 1;
+  }
+  matvec3(V, a, qt + 4);
+}
+
+// Sophus SE3::log
+inline void log(const double* qt, double* a) {
+  const double sqn = qt[0] * qt[0] + qt[1] * qt[1] + qt[2] * qt[2];
+  const double n = std::sqrt(sqn), qw = qt[3];
+  double f;
+  if (n < kEps) {
+    f = 2.0 / qw - (2.0 / 3.0) * sqn / (qw * qw * qw);
+  } else if (std::fabs(qw) < kEps) {
+    f = (qw > 0 ? kPi : -kPi) / n;
+  } else {
+    f = 2.0 * std::atan(n / qw) / n;
+  }
+  const double theta = f * n;
+  const double w[3] = {f * qt[0], f * qt[1], f * qt[2]};
+  double c;
+  if (std::fabs(theta) < kEps) {
+    c = 1.0 / 12.0;
+  } else {
+    const double h = 0.5 * theta;
+    c = (1.0 - theta * std::cos(h) / (2.0 * std::sin(h))) / (theta * theta);
+  }
+  const double W[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+  double Vi[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      const double w2 = W[3 * i] * W[j] + W[3 * i + 1] * W[3 + j] + W[3 * i + 2] * W[6 + j];
+      Vi[3 * i + j] = -0.5 * W[3 * i + j] + c * w2 + (i == j ? 1.0 : 0.0);
+    }
+  matvec3(Vi, qt + 4, a);
+  a[3] = w[0]; a[4] = w[1]; a[5] = w[2];
+}
+
+// group product (Sophus: quaternion product + first-order renormalisation)
+inline void mul(const double* a, const double* b, double* out) {
+  const double ax = a[0], ay = a[1], az = a[2], aw = a[3];
+  const double bx = b[0], by = b[1], bz = b[2], bw = b[3];
+  double q[4];
+  q[3] = aw * bw - ax * bx - ay * by - az * bz;
+  q[0] = aw * bx + ax * bw + ay * bz - az * by;
+  q[1] = aw * by + ay * bw + az * bx - ax * bz;
+  q[2] = aw * bz + az * bw + ax * by - ay * bx;
+  const double sq = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  if (sq != 1.0) {
+    const double s = 2.0 / (1.0 + sq);
+    q[0] *= s; q[1] *= s; q[2] *= s; q[3] *= s;
+  }
+  double R[9], t[3];
+  rotation(a, R);
+  matvec3(R, b + 4, t);
+  const double o[7] = {q[0], q[1], q[2], q[3], a[4] + t[0], a[5] + t[1], a[6] + t[2]};
+  std::memcpy(out, o, sizeof o);
+}
+
+inline void inverse(const double* a, double* out) {
+  const double c[7] = {-a[0], -a[1], -a[2], a[3], 0, 0, 0};
+  double R[9], t[3];
+  rotation(c, R);
+  matvec3(R, a + 4, t);
+  const double o[7] = {c[0], c[1], c[2], c[3], -t[0], -t[1], -t[2]};
+  std::memcpy(out, o, sizeof o);
+}
+
+// LocalParameterizationSE3::Plus
+inline void plus(const double* qt, const double* delta, double* out) {
+  double e[7];
+  exp(delta, e);
+  mul(qt, e, out);
+}
+
+inline double norm7(const double* a) {
+  double s = 0;
+  for (int i = 0; i < 7; ++i) s += a[i] * a[i];
+  return std::sqrt(s);
+}
+
+}  // namespace se3
+}  // namespace sicp
+#endif

@@ -1,0 +1,856 @@
+// sicp_api.cpp -- implementation of the C ABI in include/sicp.h on top of the gfx950 kernels.
+//
+// Host side of the hot path: cloud upload (SoA), stage drivers, the outer ICP loops of the three
+// reference classes (em_icp.hpp:25-200, gicp.hpp:29-175, semantic_icp.hpp:28-166), the 6-DoF LM
+// driver (lm.hpp) and SE(3) (se3.hpp).  There is no CPU fallback: every stage runs on the GPU
+// and every entry point fails with SICP_ERR_NO_DEVICE / SICP_ERR_HIP if it cannot.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+#include "lm.hpp"
+#include "se3.hpp"
+#include "sicp.h"
+
+namespace {
+
+using sicp::se3::matrix34;
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t cap = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  hipError_t reserve(size_t n) {
+    if (n <= cap) return hipSuccess;
+    release();
+    size_t want = n + n / 8 + 64;
+    hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
+    if (e != hipSuccess) { p = nullptr; return e; }
+    cap = want;
+    return hipSuccess;
+  }
+};
+
+struct Cloud {
+  int n = 0;
+  bool is_set = false, has_label = false;
+  std::vector<float> hx, hy, hz;  // caller order
+  std::vector<uint32_t> hl;
+  // device layout: caller order (GICP / EM) or grouped by label in first-seen order (SEMANTIC)
+  int layout = -1;        // -1 none, 0 flat, 1 grouped
+  std::vector<int> perm;  // device index -> caller index; empty = identity
+  std::vector<uint32_t> seg_label;
+  std::vector<int> seg_off;  // n_seg + 1
+  DevBuf<float> x, y, z;
+  DevBuf<uint32_t> label;
+  DevBuf<double> nx, ny, nz;
+  DevBuf<uint8_t> hist;
+  DevBuf<int> nn;
+  bool feat_valid = false;
+  int feat_k = 0, feat_C = 0, feat_float_products = 0;
+  bool feat_hist = false;
+  int n_seg() const { return (int)seg_label.size(); }
+  int caller_index(int d) const { return perm.empty() ? d : perm[d]; }
+};
+
+double now_ms() {
+  using namespace std::chrono;
+  return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+struct sicp_context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  sicp_params params;
+  Cloud cloud[2];
+  int C = 0;
+  std::vector<double> cm;
+  DevBuf<double> d_cm, d_hval;
+  int hval_k = 0;
+  // correspondences of the last search
+  DevBuf<int> idx;
+  DevBuf<float> d2;
+  DevBuf<double> w;
+  int corr_n = 0, corr_K = 0;
+  bool corr_valid = false, corr_weighted = false;
+  DevBuf<float> part_d;
+  DevBuf<int> part_i;
+  DevBuf<double> partials, out28;
+  DevBuf<long long> d_count;
+  double* h_out28 = nullptr;      // pinned, 28 doubles
+  long long* h_count = nullptr;   // pinned
+  DevBuf<float> tmpx, tmpy, tmpz;
+  DevBuf<uint32_t> tmpl;
+  std::string last_error;
+  sicp_stats st;
+};
+
+namespace {
+
+#define HIPCHECK(expr)                                                                         \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess) {                                                                    \
+      h->last_error = std::string(#expr) + ": " + hipGetErrorString(_e);                       \
+      return SICP_ERR_HIP;                                                                     \
+    }                                                                                          \
+  } while (0)
+
+#define SICPCHECK(expr)          \
+  do {                           \
+    int _s = (expr);             \
+    if (_s != SICP_OK) return _s; \
+  } while (0)
+
+struct KernelTimer {
+  // brackets a group of launches with events when params.profile is on
+  sicp_context* h;
+  bool on;
+  KernelTimer(sicp_context* ctx, int bit) : h(ctx), on((ctx->params.profile & bit) != 0) {
+    if (on) (void)hipEventRecord(h->ev0, h->stream);
+  }
+  // returns elapsed ms (synchronises the stream up to here); 0 when profiling is off
+  double stop() {
+    if (!on) return 0.0;
+    float ms = 0.f;
+    if (hipEventRecord(h->ev1, h->stream) != hipSuccess) return 0.0;
+    if (hipEventSynchronize(h->ev1) != hipSuccess) return 0.0;
+    if (hipEventElapsedTime(&ms, h->ev0, h->ev1) != hipSuccess) return 0.0;
+    return (double)ms;
+  }
+};
+
+int set_device(sicp_context* h) {
+  HIPCHECK(hipSetDevice(h->device));
+  return SICP_OK;
+}
+
+// ---- cloud layout -----------------------------------------------------------------------------
+int prepare_cloud(sicp_context* h, Cloud& c) {
+  const int want = h->params.mode == SICP_MODE_SEMANTIC ? 1 : 0;
+  if (!c.is_set) return SICP_ERR_NOT_READY;
+  if (want == 1 && !c.has_label) return SICP_ERR_NOT_READY;
+  if (c.layout == want) return SICP_OK;
+  const int n = c.n;
+  c.perm.clear();
+  c.seg_label.clear();
+  c.seg_off.clear();
+  std::vector<float> gx, gy, gz;
+  std::vector<uint32_t> gl;
+  const float *px = c.hx.data(), *py = c.hy.data(), *pz = c.hz.data();
+  const uint32_t* pl = c.has_label ? c.hl.data() : nullptr;
+  if (want == 0) {
+    c.seg_label.push_back(0);
+    c.seg_off = {0, n};
+  } else {
+    // pcl_2_semantic.h:24-39: one sub-cloud per label, labels in order of first appearance,
+    // points in cloud order inside each label
+    std::vector<int> which(n), cnt;
+    for (int i = 0; i < n; ++i) {
+      int s = -1;
+      for (size_t k = 0; k < c.seg_label.size(); ++k)
+        if (c.seg_label[k] == c.hl[i]) { s = (int)k; break; }
+      if (s < 0) { s = (int)c.seg_label.size(); c.seg_label.push_back(c.hl[i]); cnt.push_back(0); }
+      which[i] = s;
+      cnt[s]++;
+    }
+    c.seg_off.assign(c.seg_label.size() + 1, 0);
+    for (size_t k = 0; k < c.seg_label.size(); ++k) c.seg_off[k + 1] = c.seg_off[k] + cnt[k];
+    std::vector<int> fill(c.seg_off.begin(), c.seg_off.end() - 1);
+    c.perm.resize(n);
+    for (int i = 0; i < n; ++i) c.perm[fill[which[i]]++] = i;
+    gx.resize(n); gy.resize(n); gz.resize(n); gl.resize(n);
+    for (int d = 0; d < n; ++d) {
+      const int i = c.perm[d];
+      gx[d] = c.hx[i]; gy[d] = c.hy[i]; gz[d] = c.hz[i]; gl[d] = c.hl[i];
+    }
+    px = gx.data(); py = gy.data(); pz = gz.data(); pl = gl.data();
+  }
+  const size_t m = (size_t)(n > 0 ? n : 1);
+  HIPCHECK(c.x.reserve(m)); HIPCHECK(c.y.reserve(m)); HIPCHECK(c.z.reserve(m));
+  HIPCHECK(c.label.reserve(m));
+  if (n > 0) {
+    HIPCHECK(hipMemcpyAsync(c.x.p, px, sizeof(float) * n, hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(hipMemcpyAsync(c.y.p, py, sizeof(float) * n, hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(hipMemcpyAsync(c.z.p, pz, sizeof(float) * n, hipMemcpyHostToDevice, h->stream));
+    if (pl) HIPCHECK(hipMemcpyAsync(c.label.p, pl, sizeof(uint32_t) * n, hipMemcpyHostToDevice, h->stream));
+  }
+  HIPCHECK(hipStreamSynchronize(h->stream));  // staging vectors go out of scope
+  c.layout = want;
+  c.feat_valid = false;
+  h->corr_valid = false;
+  return SICP_OK;
+}
+
+// ---- brute-force kNN driver -------------------------------------------------------------------
+int run_nn(sicp_context* h, int K, const float* qx, const float* qy, const float* qz, int q_begin,
+           int q_count, const double* M34, const float* tx, const float* ty, const float* tz,
+           int t_begin, int t_count, float gate_sq, int* out_i, float* out_d, int timer_bit) {
+  if (q_count <= 0) return SICP_OK;
+  const int Q = sicp::nn_queries_per_thread(K);
+  const int qblocks = (q_count + 256 * Q - 1) / (256 * Q);
+  // >= ~8 workgroups per CU so the search fills the chip, but never chunks below one LDS tile
+  int chunks = (2048 + qblocks - 1) / qblocks;
+  const int max_chunks = (t_count + 1023) / 1024;
+  if (chunks > max_chunks) chunks = max_chunks;
+  if (chunks < 1) chunks = 1;
+  int chunk_len = (t_count + chunks - 1) / chunks;
+  chunk_len = ((chunk_len + 1023) / 1024) * 1024;
+  if (chunk_len < 1024) chunk_len = 1024;
+  chunks = t_count > 0 ? (t_count + chunk_len - 1) / chunk_len : 1;
+  const size_t need = (size_t)chunks * q_count * K;
+  HIPCHECK(h->part_d.reserve(need));
+  HIPCHECK(h->part_i.reserve(need));
+  sicp::NNArgs a;
+  a.qx = qx; a.qy = qy; a.qz = qz;
+  a.q_begin = q_begin; a.q_count = q_count;
+  a.do_xform = M34 ? 1 : 0;
+  for (int i = 0; i < 12; ++i) a.M[i] = M34 ? M34[i] : 0.0;
+  a.tx = tx; a.ty = ty; a.tz = tz;
+  a.t_begin = t_begin; a.t_count = t_count;
+  a.chunk_len = chunk_len;
+  a.part_d = h->part_d.p; a.part_i = h->part_i.p;
+  sicp::MergeArgs m;
+  m.q_begin = q_begin; m.q_count = q_count; m.n_chunks = chunks; m.t_begin = t_begin;
+  m.part_d = h->part_d.p; m.part_i = h->part_i.p;
+  m.gate_sq = gate_sq;
+  m.out_i = out_i; m.out_d = out_d;
+  {
+    KernelTimer kt(h, timer_bit);
+    HIPCHECK(sicp::launch_nn_partial(K, a, chunks, h->stream));
+    const double ms = kt.stop();
+    if (timer_bit == SICP_PROFILE_NN) { h->st.nn_kernel_ms += ms; h->st.nn_launches += 1; }
+    else { h->st.cov_kernel_ms += ms; h->st.cov_launches += 1; }
+  }
+  HIPCHECK(sicp::launch_nn_merge(K, m, h->stream));
+  return SICP_OK;
+}
+
+// ---- per-point normals (+ label histograms) ----------------------------------------------------
+int ensure_hval(sicp_context* h, int k) {
+  if (h->hval_k == k && h->d_hval.p) return SICP_OK;
+  std::vector<double> hv(k + 1);
+  const double increment = 1.0 / (double)k;  // em_icp.hpp:279
+  double acc = 0.0;
+  for (int c = 0; c <= k; ++c) { hv[c] = acc; acc += increment; }  // em_icp.hpp:301, repeated +=
+  HIPCHECK(h->d_hval.reserve(k + 1));
+  HIPCHECK(hipMemcpyAsync(h->d_hval.p, hv.data(), sizeof(double) * (k + 1), hipMemcpyHostToDevice, h->stream));
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  h->hval_k = k;
+  return SICP_OK;
+}
+
+int compute_features(sicp_context* h, Cloud& c, bool with_hist) {
+  const sicp_params& P = h->params;
+  const int k = P.k_cov, n = c.n;
+  const size_t m = (size_t)(n > 0 ? n : 1);
+  HIPCHECK(c.nx.reserve(m)); HIPCHECK(c.ny.reserve(m)); HIPCHECK(c.nz.reserve(m));
+  HIPCHECK(c.nn.reserve(m * k));
+  if (with_hist) HIPCHECK(c.hist.reserve(m * P.num_classes));
+  for (int s = 0; s < c.n_seg(); ++s) {
+    const int o = c.seg_off[s], cnt = c.seg_off[s + 1] - o;
+    SICPCHECK(run_nn(h, k, c.x.p, c.y.p, c.z.p, o, cnt, nullptr, c.x.p, c.y.p, c.z.p, o, cnt,
+                     std::numeric_limits<float>::infinity(), c.nn.p, nullptr, SICP_PROFILE_COV));
+  }
+  sicp::CovArgs a;
+  a.n = n; a.k = k; a.C = with_hist ? P.num_classes : 0;
+  a.x = c.x.p; a.y = c.y.p; a.z = c.z.p;
+  a.label = c.has_label ? c.label.p : nullptr;
+  a.nn = c.nn.p;
+  a.float_products = P.quirk_float_products;
+  a.nx = c.nx.p; a.ny = c.ny.p; a.nz = c.nz.p;
+  a.hist = with_hist ? c.hist.p : nullptr;
+  HIPCHECK(sicp::launch_cov(a, h->stream));
+  c.feat_valid = true;
+  c.feat_k = k; c.feat_C = with_hist ? P.num_classes : 0;
+  c.feat_float_products = P.quirk_float_products;
+  c.feat_hist = with_hist;
+  return SICP_OK;
+}
+
+bool features_current(const sicp_context* h, const Cloud& c, bool with_hist) {
+  return c.feat_valid && c.feat_k == h->params.k_cov && c.feat_float_products == h->params.quirk_float_products &&
+         (!with_hist || (c.feat_hist && c.feat_C == h->params.num_classes));
+}
+
+int check_ready(sicp_context* h, bool need_cm) {
+  const sicp_params& P = h->params;
+  if (!h->cloud[0].is_set || !h->cloud[1].is_set) return SICP_ERR_NOT_READY;
+  if (!sicp::nn_k_supported(P.knn) || !sicp::nn_k_supported(P.k_cov)) return SICP_ERR_INVALID_ARGUMENT;
+  if (P.mode != SICP_MODE_GICP && (!h->cloud[0].has_label || !h->cloud[1].has_label)) return SICP_ERR_NOT_READY;
+  if (P.mode == SICP_MODE_EM || need_cm) {
+    if (P.num_classes < 1 || P.num_classes > 255 || h->C != P.num_classes) return SICP_ERR_NOT_READY;
+    for (int wch = 0; wch < 2; ++wch)
+      for (uint32_t l : h->cloud[wch].hl)
+        if (l < 1 || l > (uint32_t)P.num_classes) return SICP_ERR_BAD_LABEL;  // em_icp.hpp:301 indexes label-1
+  }
+  if (P.mode != SICP_MODE_SEMANTIC && h->cloud[1].n < P.knn) return SICP_ERR_TOO_FEW_POINTS;
+  return SICP_OK;
+}
+
+void fill_pose(const double* qt, sicp::Pose& p) {
+  sicp::se3::rotation(qt, p.R);
+  p.t[0] = qt[4]; p.t[1] = qt[5]; p.t[2] = qt[6];
+}
+
+int segment_of(const Cloud& c, uint32_t label) {
+  for (int k = 0; k < c.n_seg(); ++k)
+    if (c.seg_label[k] == label) return k;
+  return -1;
+}
+
+// transform + kNN + gate (+ EM weight) at pose qt: the loop em_icp.hpp:46-108
+int run_correspondences(sicp_context* h, const double* qt, int K, bool weights) {
+  const sicp_params& P = h->params;
+  Cloud &S = h->cloud[0], &T = h->cloud[1];
+  const size_t slots = (size_t)(S.n > 0 ? S.n : 1) * K;
+  HIPCHECK(h->idx.reserve(slots));
+  HIPCHECK(h->d2.reserve(slots));
+  HIPCHECK(h->w.reserve(slots));
+  double M[12];
+  matrix34(qt, M);
+  const bool sem = P.mode == SICP_MODE_SEMANTIC;
+  if (sem) {  // label segments that are skipped keep (idx, d2) = (-1, +inf)
+    HIPCHECK(hipMemsetAsync(h->idx.p, 0xFF, sizeof(int) * slots, h->stream));
+    HIPCHECK(hipMemsetD32Async((hipDeviceptr_t)h->d2.p, 0x7f800000, slots, h->stream));
+  }
+  {
+    const double t0 = now_ms();
+    for (int s = 0; s < S.n_seg(); ++s) {
+      const int so = S.seg_off[s], sn = S.seg_off[s + 1] - so;
+      int ts = 0;
+      if (sem) {
+        ts = segment_of(T, S.seg_label[s]);
+        if (ts < 0) continue;                    // semantic_icp.hpp:50
+        if (!(sn > P.min_class_pts)) continue;   // semantic_icp.hpp:51
+      }
+      const int to = T.seg_off[ts], tn = T.seg_off[ts + 1] - to;
+      SICPCHECK(run_nn(h, K, S.x.p, S.y.p, S.z.p, so, sn, M, T.x.p, T.y.p, T.z.p, to, tn,
+                       (float)P.gate_sq, h->idx.p, h->d2.p, SICP_PROFILE_NN));
+      h->st.total_corr += (int64_t)sn * K;
+    }
+    h->st.t_nn_ms += now_ms() - t0;
+  }
+  h->corr_weighted = false;
+  if (weights && P.mode == SICP_MODE_EM) {
+    KernelTimer kt(h, SICP_PROFILE_WEIGHT);
+    const double t0 = now_ms();
+    SICPCHECK(ensure_hval(h, P.k_cov));
+    sicp::WeightArgs a;
+    a.n_s = S.n; a.K = K; a.C = P.num_classes;
+    a.idx = h->idx.p;
+    a.sx = S.x.p; a.sy = S.y.p; a.sz = S.z.p; a.tx = T.x.p; a.ty = T.y.p; a.tz = T.z.p;
+    a.snx = S.nx.p; a.sny = S.ny.p; a.snz = S.nz.p; a.tnx = T.nx.p; a.tny = T.ny.p; a.tnz = T.nz.p;
+    a.s_hist = S.hist.p; a.t_hist = T.hist.p;
+    a.cm = h->d_cm.p; a.hval = h->d_hval.p;
+    fill_pose(qt, a.pose);
+    a.one_m_eps = 1.0 - P.epsilon;
+    a.bool_probability = P.quirk_bool_probability;
+    a.w = h->w.p;
+    HIPCHECK(sicp::launch_em_weight(a, h->stream));
+    h->st.weight_launches += 1;
+    h->st.weight_kernel_ms += kt.stop();
+    h->st.t_weight_ms += now_ms() - t0;
+    h->corr_weighted = true;
+  }
+  h->corr_n = S.n;
+  h->corr_K = K;
+  h->corr_valid = true;
+  return SICP_OK;
+}
+
+int eval28(sicp_context* h, const double* qt, double* out28) {
+  const sicp_params& P = h->params;
+  Cloud &S = h->cloud[0], &T = h->cloud[1];
+  const int nb = sicp::accumulate_blocks(h->corr_n * h->corr_K);
+  HIPCHECK(h->partials.reserve((size_t)nb * 28));
+  HIPCHECK(h->out28.reserve(28));
+  sicp::AccArgs a;
+  a.n_s = h->corr_n; a.K = h->corr_K;
+  a.idx = h->idx.p;
+  a.w = h->corr_weighted ? h->w.p : nullptr;
+  a.sx = S.x.p; a.sy = S.y.p; a.sz = S.z.p; a.tx = T.x.p; a.ty = T.y.p; a.tz = T.z.p;
+  a.snx = S.nx.p; a.sny = S.ny.p; a.snz = S.nz.p; a.tnx = T.nx.p; a.tny = T.ny.p; a.tnz = T.nz.p;
+  fill_pose(qt, a.pose);
+  a.one_m_eps = 1.0 - P.epsilon;
+  a.loss.cauchy_a = P.cauchy_a;
+  a.loss.use_sqloss = P.use_sqloss;
+  a.partials = h->partials.p;
+  KernelTimer kt(h, SICP_PROFILE_ACC);
+  HIPCHECK(sicp::launch_accumulate(a, h->out28.p, h->stream));
+  h->st.acc_launches += 1;
+  h->st.acc_kernel_ms += kt.stop();
+  HIPCHECK(hipMemcpyAsync(h->h_out28, h->out28.p, sizeof(double) * 28, hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  std::memcpy(out28, h->h_out28, sizeof(double) * 28);
+  h->st.total_evals++;
+  return SICP_OK;
+}
+
+sicp::LmOptions lm_options(const sicp_params& P) {
+  sicp::LmOptions o;
+  o.max_iterations = P.max_lm_iterations;
+  o.gradient_tolerance = P.gradient_tolerance;
+  o.function_tolerance = P.function_tolerance;
+  o.parameter_tolerance = P.parameter_tolerance;
+  o.initial_radius = P.initial_radius;
+  o.max_radius = P.max_radius;
+  o.min_radius = P.min_radius;
+  o.min_relative_decrease = P.min_relative_decrease;
+  o.min_lm_diagonal = P.min_lm_diagonal;
+  o.max_lm_diagonal = P.max_lm_diagonal;
+  o.max_consecutive_invalid_steps = P.max_consecutive_invalid_steps;
+  o.jacobi_scaling = P.jacobi_scaling != 0;
+  return o;
+}
+
+int run_solve(sicp_context* h, const double* init_qt, double* out_qt, sicp::LmResult* res) {
+  int hip_status = SICP_OK;
+  auto eval = [&](const double* qt, double* o) {
+    hip_status = eval28(h, qt, o);
+    return hip_status;
+  };
+  *res = sicp::lm_solve(lm_options(h->params), eval, init_qt, out_qt);
+  return hip_status;
+}
+
+// statistics only: add the number of live slots of the current search to the device counter
+int count_active(sicp_context* h) {
+  HIPCHECK(sicp::launch_count_active(h->idx.p, h->corr_n * h->corr_K, (unsigned long long*)h->d_count.p, h->stream));
+  return SICP_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+const char* sicp_version(void) { return "semantic-icp_amd 0.1 (gfx950)"; }
+
+const char* sicp_strerror(int s) {
+  switch (s) {
+    case SICP_OK: return "ok";
+    case SICP_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case SICP_ERR_NO_DEVICE: return "no usable HIP device";
+    case SICP_ERR_HIP: return "HIP runtime error (see sicp_last_error)";
+    case SICP_ERR_NOT_READY: return "clouds / labels / confusion matrix not set for this mode";
+    case SICP_ERR_TOO_FEW_POINTS: return "target cloud has fewer points than correspondences requested";
+    case SICP_ERR_BAD_LABEL: return "EM label outside 1..C";
+    case SICP_ERR_OUT_OF_MEMORY: return "out of memory";
+    default: return "unknown status";
+  }
+}
+
+const char* sicp_last_error(sicp_handle h) { return h ? h->last_error.c_str() : ""; }
+
+int sicp_device_count(int* count) {
+  if (!count) return SICP_ERR_INVALID_ARGUMENT;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { *count = 0; return SICP_ERR_NO_DEVICE; }
+  *count = n;
+  return SICP_OK;
+}
+
+int sicp_default_params(int mode, sicp_params* p) {
+  if (!p || mode < SICP_MODE_GICP || mode > SICP_MODE_SEMANTIC) return SICP_ERR_INVALID_ARGUMENT;
+  std::memset(p, 0, sizeof *p);
+  p->mode = mode;
+  p->k_cov = 20;          // em_icp.h:42, gicp.h:34, semantic_point_cloud.h:31
+  p->epsilon = 0.001;     // em_icp.h:43
+  p->gate_sq = 250.0;     // em_icp.hpp:65, gicp.hpp:70, semantic_icp.hpp:69
+  p->min_class_pts = 400; // semantic_icp.hpp:51
+  p->max_lm_iterations = 400;         // em_icp.hpp:169
+  p->gradient_tolerance = 0.1 * 1e-10; // 0.1 * Sophus::Constants<double>::epsilon(), em_icp.hpp:163
+  p->function_tolerance = 0.1 * 1e-10; // em_icp.hpp:164
+  p->parameter_tolerance = 1e-8;
+  p->initial_radius = 1e4;
+  p->max_radius = 1e16;
+  p->min_radius = 1e-32;
+  p->min_relative_decrease = 1e-3;
+  p->min_lm_diagonal = 1e-6;
+  p->max_lm_diagonal = 1e32;
+  p->max_consecutive_invalid_steps = 5;
+  p->jacobi_scaling = 1;
+  p->quirk_bool_probability = 1;
+  p->quirk_float_products = 1;
+  if (mode == SICP_MODE_EM) {
+    p->knn = 4; p->cauchy_a = 3.0; p->use_sqloss = 1;  // em_icp.hpp:60,111,115
+    p->outer_tol = 1e-5; p->max_outer = 50;            // em_icp.hpp:180
+  } else if (mode == SICP_MODE_GICP) {
+    p->knn = 1; p->cauchy_a = 3.0; p->use_sqloss = 1;  // gicp.hpp:69,100,102
+    p->outer_tol = 1e-5; p->max_outer = 50;            // gicp.hpp:154
+  } else {
+    p->knn = 1; p->cauchy_a = 1.5; p->use_sqloss = 0;  // semantic_icp.hpp:68,96
+    p->outer_tol = 0.001; p->max_outer = 35;           // semantic_icp.hpp:152
+  }
+  return SICP_OK;
+}
+
+int sicp_create(int device_id, sicp_handle* out) {
+  if (!out) return SICP_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return SICP_ERR_NO_DEVICE;
+  if (device_id < 0 || device_id >= n) return SICP_ERR_INVALID_ARGUMENT;
+  sicp_context* h = new (std::nothrow) sicp_context();
+  if (!h) return SICP_ERR_OUT_OF_MEMORY;
+  h->device = device_id;
+  sicp_default_params(SICP_MODE_GICP, &h->params);
+  std::memset(&h->st, 0, sizeof h->st);
+  bool ok = hipSetDevice(device_id) == hipSuccess &&
+            hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreate(&h->ev0) == hipSuccess && hipEventCreate(&h->ev1) == hipSuccess &&
+            hipHostMalloc((void**)&h->h_out28, sizeof(double) * 28, hipHostMallocDefault) == hipSuccess &&
+            hipHostMalloc((void**)&h->h_count, sizeof(long long), hipHostMallocDefault) == hipSuccess;
+  if (!ok) {
+    sicp_destroy(h);
+    return SICP_ERR_NO_DEVICE;
+  }
+  *out = h;
+  return SICP_OK;
+}
+
+int sicp_destroy(sicp_handle h) {
+  if (!h) return SICP_OK;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->h_out28) (void)hipHostFree(h->h_out28);
+  if (h->h_count) (void)hipHostFree(h->h_count);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return SICP_OK;
+}
+
+int sicp_set_params(sicp_handle h, const sicp_params* p) {
+  if (!h || !p) return SICP_ERR_INVALID_ARGUMENT;
+  if (p->mode < SICP_MODE_GICP || p->mode > SICP_MODE_SEMANTIC) return SICP_ERR_INVALID_ARGUMENT;
+  if (!sicp::nn_k_supported(p->knn) || !sicp::nn_k_supported(p->k_cov)) return SICP_ERR_INVALID_ARGUMENT;
+  if (!(p->epsilon > 0) || !(p->cauchy_a > 0) || p->nn_method != 0) return SICP_ERR_INVALID_ARGUMENT;
+  h->params = *p;
+  h->corr_valid = false;
+  return SICP_OK;
+}
+
+int sicp_get_params(sicp_handle h, sicp_params* p) {
+  if (!h || !p) return SICP_ERR_INVALID_ARGUMENT;
+  *p = h->params;
+  return SICP_OK;
+}
+
+int sicp_set_cloud(sicp_handle h, int which, int32_t n, const float* x, const float* y, const float* z,
+                   const uint32_t* label) {
+  if (!h || (which != SICP_SOURCE && which != SICP_TARGET) || n < 0) return SICP_ERR_INVALID_ARGUMENT;
+  if (n > 0 && (!x || !y || !z)) return SICP_ERR_INVALID_ARGUMENT;
+  SICPCHECK(set_device(h));
+  Cloud& c = h->cloud[which];
+  c.n = n;
+  c.hx.assign(x, x + n); c.hy.assign(y, y + n); c.hz.assign(z, z + n);
+  c.has_label = label != nullptr;
+  if (label) c.hl.assign(label, label + n); else c.hl.clear();
+  c.is_set = true;
+  c.layout = -1;
+  c.feat_valid = false;
+  h->corr_valid = false;
+  // upload now for the current mode, so that align() starts with the cloud resident in HBM;
+  // a later mode change re-lays it out lazily
+  if (h->params.mode != SICP_MODE_SEMANTIC || c.has_label) return prepare_cloud(h, c);
+  return SICP_OK;
+}
+
+int sicp_set_cloud_device(sicp_handle h, int which, int32_t n, const float* xd, const float* yd, const float* zd,
+                          const uint32_t* ld) {
+  if (!h || n < 0 || (n > 0 && (!xd || !yd || !zd))) return SICP_ERR_INVALID_ARGUMENT;
+  SICPCHECK(set_device(h));
+  // the host keeps a copy of every cloud (regrouping for SICP_MODE_SEMANTIC and the final
+  // un-permutation need it), so a device-resident input is mirrored once
+  std::vector<float> x(n), y(n), z(n);
+  std::vector<uint32_t> l(ld ? n : 0);
+  if (n > 0) {
+    HIPCHECK(hipMemcpy(x.data(), xd, sizeof(float) * n, hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(y.data(), yd, sizeof(float) * n, hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(z.data(), zd, sizeof(float) * n, hipMemcpyDeviceToHost));
+    if (ld) HIPCHECK(hipMemcpy(l.data(), ld, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
+  }
+  return sicp_set_cloud(h, which, n, x.data(), y.data(), z.data(), ld ? l.data() : nullptr);
+}
+
+int sicp_set_confusion(sicp_handle h, int32_t C, const double* cm) {
+  if (!h || C < 1 || C > 255 || !cm) return SICP_ERR_INVALID_ARGUMENT;
+  SICPCHECK(set_device(h));
+  h->C = C;
+  h->cm.assign(cm, cm + (size_t)C * C);
+  HIPCHECK(h->d_cm.reserve((size_t)C * C));
+  HIPCHECK(hipMemcpyAsync(h->d_cm.p, h->cm.data(), sizeof(double) * C * C, hipMemcpyHostToDevice, h->stream));
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  return SICP_OK;
+}
+
+int sicp_align(sicp_handle h, const double init_qt[7], double out_qt[7], int32_t* outer_iters, sicp_stats* stats) {
+  if (!h || !init_qt || !out_qt) return SICP_ERR_INVALID_ARGUMENT;
+  SICPCHECK(set_device(h));
+  SICPCHECK(check_ready(h, false));
+  const sicp_params& P = h->params;
+  const bool em = P.mode == SICP_MODE_EM, sem = P.mode == SICP_MODE_SEMANTIC;
+  std::memset(&h->st, 0, sizeof h->st);
+  const double t_begin = now_ms();
+  Cloud &S = h->cloud[0], &T = h->cloud[1];
+  HIPCHECK(h->d_count.reserve(1));
+  if (stats) HIPCHECK(hipMemsetAsync(h->d_count.p, 0, sizeof(long long), h->stream));
+  SICPCHECK(prepare_cloud(h, S));
+  SICPCHECK(prepare_cloud(h, T));
+  {
+    // em_icp.hpp:28-29 / gicp.hpp:33-34 recompute the covariances on every align(); for
+    // SemanticICP they belong to cloud construction (semantic_point_cloud.hpp:25-84)
+    const double t0 = now_ms();
+    if (!sem || !features_current(h, S, false)) SICPCHECK(compute_features(h, S, em));
+    if (!sem || !features_current(h, T, false)) SICPCHECK(compute_features(h, T, em));
+    if (P.profile) HIPCHECK(hipStreamSynchronize(h->stream));
+    h->st.t_cov_ms = now_ms() - t0;
+  }
+  double cur[7], est[7];
+  std::memcpy(cur, init_qt, sizeof cur);
+  bool converged = false;
+  int outer = 0, count = 0;
+  while (!converged) {
+    std::memcpy(est, cur, sizeof est);
+    if (sem) count++;  // semantic_icp.hpp:47
+    SICPCHECK(run_correspondences(h, cur, P.knn, true));
+    {
+      const double t0 = now_ms();
+      sicp::LmResult r;
+      SICPCHECK(run_solve(h, est, est, &r));
+      h->st.total_lm_iters += r.iterations;
+      h->st.final_cost = r.cost;
+      h->st.t_solve_ms += now_ms() - t0;
+    }
+    if (stats) SICPCHECK(count_active(h));
+    // em_icp.hpp:179-187 / gicp.hpp:153-161 / semantic_icp.hpp:151-158
+    double inv[7], rel[7], lg[6];
+    sicp::se3::inverse(cur, inv);
+    sicp::se3::mul(inv, est, rel);
+    sicp::se3::log(rel, lg);
+    double mse = 0;
+    for (int i = 0; i < 6; ++i) mse += lg[i] * lg[i];
+    if (sem) {
+      if (mse < P.outer_tol || count > P.max_outer) converged = true;
+      std::memcpy(cur, est, sizeof cur);
+    } else {
+      if (mse < P.outer_tol || outer > P.max_outer) converged = true;
+      std::memcpy(cur, est, sizeof cur);
+      outer++;
+    }
+  }
+  std::memcpy(out_qt, cur, sizeof cur);
+  if (stats) {
+    HIPCHECK(hipMemcpyAsync(h->h_count, h->d_count.p, sizeof(long long), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    h->st.total_active = *h->h_count;
+  }
+  h->st.outer_iters = sem ? count : outer;
+  h->st.t_total_ms = now_ms() - t_begin;
+  if (outer_iters) *outer_iters = h->st.outer_iters;
+  if (stats) *stats = h->st;
+  return SICP_OK;
+}
+
+int sicp_transform_source(sicp_handle h, const double qt[7], float* ox, float* oy, float* oz) {
+  if (!h || !qt || !ox || !oy || !oz) return SICP_ERR_INVALID_ARGUMENT;
+  SICPCHECK(set_device(h));
+  Cloud& S = h->cloud[0];
+  SICPCHECK(prepare_cloud(h, S));
+  const int n = S.n;
+  const size_t m = (size_t)(n > 0 ? n : 1);
+  HIPCHECK(h->tmpx.reserve(m)); HIPCHECK(h->tmpy.reserve(m)); HIPCHECK(h->tmpz.reserve(m));
+  double M[12];
+  matrix34(qt, M);
+  sicp::Mat4f Mf;
+  for (int i = 0; i < 12; ++i) Mf.m[i] = (float)M[i];  // (trans.matrix()).cast<float>(), em_icp.hpp:193
+  Mf.m[12] = Mf.m[13] = Mf.m[14] = 0.f; Mf.m[15] = 1.f;
+  HIPCHECK(sicp::launch_transform_float(n, S.x.p, S.y.p, S.z.p, Mf, h->tmpx.p, h->tmpy.p, h->tmpz.p, h->stream));
+  std::vector<float> bx(n), by(n), bz(n);
+  if (n > 0) {
+    HIPCHECK(hipMemcpyAsync(bx.data(), h->tmpx.p, sizeof(float) * n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipMemcpyAsync(by.data(), h->tmpy.p, sizeof(float) * n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipMemcpyAsync(bz.data(), h->tmpz.p, sizeof(float) * n, hipMemcpyDeviceToHost, h->stream));
+  }
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  for (int d = 0; d < n; ++d) {
+    const int i = S.caller_index(d);
+    ox[i] = bx[d]; oy[i] = by[d]; oz[i] = bz[d];
+  }
+  return SICP_OK;
+}
+
+int sicp_covariances(sicp_handle h, int which, double* cov9, double* normal3, uint8_t* hist, int32_t* nn_idx) {
+  if (!h || (which != SICP_SOURCE && which != SICP_TARGET)) return SICP_ERR_INVALID_ARGUMENT;
+  SICPCHECK(set_device(h));
+  const sicp_params& P = h->params;
+  if (!sicp::nn_k_supported(P.k_cov)) return SICP_ERR_INVALID_ARGUMENT;
+  Cloud& c = h->cloud[which];
+  SICPCHECK(prepare_cloud(h, c));
+  const bool with_hist = P.mode == SICP_MODE_EM && c.has_label && P.num_classes >= 1;
+  if (hist && !with_hist) return SICP_ERR_NOT_READY;
+  if (with_hist)
+    for (uint32_t l : c.hl)
+      if (l < 1 || l > (uint32_t)P.num_classes) return SICP_ERR_BAD_LABEL;
+  SICPCHECK(compute_features(h, c, with_hist));
+  const int n = c.n, k = P.k_cov;
+  std::vector<double> nx(n), ny(n), nz(n);
+  if (n > 0) {
+    HIPCHECK(hipMemcpyAsync(nx.data(), c.nx.p, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipMemcpyAsync(ny.data(), c.ny.p, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipMemcpyAsync(nz.data(), c.nz.p, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+  }
+  std::vector<uint8_t> hh;
+  std::vector<int> nn;
+  if (hist && n > 0) {
+    hh.resize((size_t)n * P.num_classes);
+    HIPCHECK(hipMemcpyAsync(hh.data(), c.hist.p, hh.size(), hipMemcpyDeviceToHost, h->stream));
+  }
+  if (nn_idx && n > 0) {
+    nn.resize((size_t)n * k);
+    HIPCHECK(hipMemcpyAsync(nn.data(), c.nn.p, sizeof(int) * nn.size(), hipMemcpyDeviceToHost, h->stream));
+  }
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  const double ome = 1.0 - P.epsilon;
+  for (int d = 0; d < n; ++d) {
+    const int i = c.caller_index(d);
+    const double v[3] = {nx[d], ny[d], nz[d]};
+    if (normal3) { normal3[3 * (size_t)i] = v[0]; normal3[3 * (size_t)i + 1] = v[1]; normal3[3 * (size_t)i + 2] = v[2]; }
+    if (cov9)  // the covariance the kernels use: C = I - (1-eps) n n^T  (== em_icp.hpp:331-338)
+      for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) cov9[9 * (size_t)i + 3 * a + b] = (a == b ? 1.0 : 0.0) - ome * v[a] * v[b];
+    if (hist) std::memcpy(hist + (size_t)i * P.num_classes, hh.data() + (size_t)d * P.num_classes, P.num_classes);
+    if (nn_idx)
+      for (int j = 0; j < k; ++j) {
+        const int g = nn[(size_t)d * k + j];
+        nn_idx[(size_t)i * k + j] = g < 0 ? -1 : c.caller_index(g);
+      }
+  }
+  return SICP_OK;
+}
+
+int sicp_correspondences(sicp_handle h, const double qt[7], int32_t* idx, float* d2, double* w) {
+  if (!h || !qt) return SICP_ERR_INVALID_ARGUMENT;
+  SICPCHECK(set_device(h));
+  SICPCHECK(check_ready(h, false));
+  const sicp_params& P = h->params;
+  const bool em = P.mode == SICP_MODE_EM;
+  Cloud &S = h->cloud[0], &T = h->cloud[1];
+  SICPCHECK(prepare_cloud(h, S));
+  SICPCHECK(prepare_cloud(h, T));
+  if (!features_current(h, S, em)) SICPCHECK(compute_features(h, S, em));
+  if (!features_current(h, T, em)) SICPCHECK(compute_features(h, T, em));
+  SICPCHECK(run_correspondences(h, qt, P.knn, true));
+  const int n = S.n, K = P.knn;
+  const size_t slots = (size_t)n * K;
+  std::vector<int> hi(slots);
+  std::vector<float> hd(slots);
+  std::vector<double> hw(slots);
+  if (slots) {
+    HIPCHECK(hipMemcpyAsync(hi.data(), h->idx.p, sizeof(int) * slots, hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipMemcpyAsync(hd.data(), h->d2.p, sizeof(float) * slots, hipMemcpyDeviceToHost, h->stream));
+    if (h->corr_weighted) HIPCHECK(hipMemcpyAsync(hw.data(), h->w.p, sizeof(double) * slots, hipMemcpyDeviceToHost, h->stream));
+  }
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  for (int d = 0; d < n; ++d) {
+    const int i = S.caller_index(d);
+    for (int c = 0; c < K; ++c) {
+      const size_t e = (size_t)d * K + c, o = (size_t)i * K + c;
+      const int j = hi[e];
+      if (idx) idx[o] = j < 0 ? -1 : T.caller_index(j);
+      if (d2) d2[o] = hd[e];
+      if (w) w[o] = j < 0 ? 0.0 : (h->corr_weighted ? hw[e] : 1.0);
+    }
+  }
+  return SICP_OK;
+}
+
+int sicp_accumulate(sicp_handle h, const double qt[7], double out28[28]) {
+  if (!h || !qt || !out28) return SICP_ERR_INVALID_ARGUMENT;
+  if (!h->corr_valid) return SICP_ERR_NOT_READY;
+  SICPCHECK(set_device(h));
+  return eval28(h, qt, out28);
+}
+
+int sicp_solve(sicp_handle h, const double init_qt[7], double out_qt[7], int32_t* lm_iters, int32_t* evals,
+               double* final_cost) {
+  if (!h || !init_qt || !out_qt) return SICP_ERR_INVALID_ARGUMENT;
+  if (!h->corr_valid) return SICP_ERR_NOT_READY;
+  SICPCHECK(set_device(h));
+  sicp::LmResult r;
+  SICPCHECK(run_solve(h, init_qt, out_qt, &r));
+  if (lm_iters) *lm_iters = r.iterations;
+  if (evals) *evals = r.evaluations;
+  if (final_cost) *final_cost = r.cost;
+  return SICP_OK;
+}
+
+int sicp_fused_labels(sicp_handle h, const double qt[7], uint32_t* out_labels) {
+  if (!h || !qt || !out_labels) return SICP_ERR_INVALID_ARGUMENT;
+  SICPCHECK(set_device(h));
+  if (h->params.mode != SICP_MODE_EM) return SICP_ERR_INVALID_ARGUMENT;
+  SICPCHECK(check_ready(h, true));
+  const sicp_params& P = h->params;
+  Cloud &S = h->cloud[0], &T = h->cloud[1];
+  if (T.n < 4) return SICP_ERR_TOO_FEW_POINTS;
+  SICPCHECK(prepare_cloud(h, S));
+  SICPCHECK(prepare_cloud(h, T));
+  // getFusedLabels reuses what align() left behind (em_icp.hpp:230-241)
+  if (!features_current(h, S, true)) SICPCHECK(compute_features(h, S, true));
+  if (!features_current(h, T, true)) SICPCHECK(compute_features(h, T, true));
+  SICPCHECK(run_correspondences(h, qt, 4, false));  // K = 4 is a literal here (em_icp.hpp:221)
+  h->corr_valid = false;                            // K may differ from params.knn
+  SICPCHECK(ensure_hval(h, P.k_cov));
+  sicp::WeightArgs a;
+  a.n_s = S.n; a.K = 4; a.C = P.num_classes;
+  a.idx = h->idx.p;
+  a.sx = S.x.p; a.sy = S.y.p; a.sz = S.z.p; a.tx = T.x.p; a.ty = T.y.p; a.tz = T.z.p;
+  a.snx = S.nx.p; a.sny = S.ny.p; a.snz = S.nz.p; a.tnx = T.nx.p; a.tny = T.ny.p; a.tnz = T.nz.p;
+  a.s_hist = S.hist.p; a.t_hist = T.hist.p;
+  a.cm = h->d_cm.p; a.hval = h->d_hval.p;
+  fill_pose(qt, a.pose);
+  a.one_m_eps = 1.0 - P.epsilon;
+  a.bool_probability = P.quirk_bool_probability;
+  a.w = nullptr;
+  HIPCHECK(h->tmpl.reserve((size_t)(S.n > 0 ? S.n : 1)));
+  HIPCHECK(sicp::launch_fused_labels(a, h->tmpl.p, h->stream));
+  std::vector<uint32_t> tmp(S.n);
+  if (S.n > 0) HIPCHECK(hipMemcpyAsync(tmp.data(), h->tmpl.p, sizeof(uint32_t) * S.n, hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  for (int d = 0; d < S.n; ++d) out_labels[S.caller_index(d)] = tmp[d];
+  return SICP_OK;
+}
+
+int sicp_synchronize(sicp_handle h) {
+  if (!h) return SICP_ERR_INVALID_ARGUMENT;
+  SICPCHECK(set_device(h));
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  return SICP_OK;
+}
+
+}  // extern "C"

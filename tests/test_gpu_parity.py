@@ -1,0 +1,363 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on
+the same seeded inputs, against the committed goldens, and -- at the BASELINE metric size --
+through size-independent properties.
+
+Bars: bit-exact for index / integer work (kNN indices, float32 squared distances, label
+histograms, fused labels); documented floating-point tolerances elsewhere; final pose within the
+north-star tolerance (1e-4 rad / 1e-3 m) of the oracle -- in practice ~1e-9.
+"""
+import importlib
+import os
+
+import numpy as np
+import pytest
+from scipy.spatial.transform import Rotation
+
+import oracle_lib as O
+import synth
+from np_ref import mat_to_qt
+
+pytestmark = pytest.mark.gpu
+
+sicp = importlib.import_module("semantic-icp_amd")
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+IDENT = np.array([0, 0, 0, 1, 0, 0, 0.0])
+
+# north star: final pose within 1e-4 rad / 1e-3 m of the reference solve
+ROT_TOL, TRANS_TOL = 1e-4, 1e-3
+
+
+def pose_delta(qa, qb):
+    D = np.linalg.inv(O.se3_matrix(qa)) @ O.se3_matrix(qb)
+    return np.linalg.norm(Rotation.from_matrix(D[:3, :3]).as_rotvec()), np.linalg.norm(D[:3, 3])
+
+
+def pose_err_to_matrix(q, T):
+    D = np.linalg.inv(T) @ O.se3_matrix(q)
+    return np.linalg.norm(Rotation.from_matrix(D[:3, :3]).as_rotvec()), np.linalg.norm(D[:3, 3])
+
+
+def make_engine(mode, C=0, cm=None, **kw):
+    p = sicp.default_params(mode)
+    p.num_classes = C
+    for k, v in kw.items():
+        setattr(p, k, v)
+    e = sicp.Engine(0, p)
+    if cm is not None:
+        e.set_confusion(cm)
+    return e, p
+
+
+def oracle_params(mode, C=0, **kw):
+    p = O.default_params(mode)
+    p.num_classes = C
+    p.use_kdtree = 1
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+@pytest.fixture(scope="module")
+def pair1():
+    return synth.config1_pair(seed=1, n_per_label=700)
+
+
+@pytest.fixture(scope="module")
+def lidar20k():
+    return synth.lidar_pair(seed=2, n_points=20000)
+
+
+# ------------------------------------------------------------------------------------------------
+# correspondence search: bit-exact
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode,K", [(sicp.MODE_GICP, 1), (sicp.MODE_EM, 4)])
+def test_knn_bit_exact_vs_oracle(lidar20k, mode, K):
+    src, sl, tgt, tl, T_gt, cm = lidar20k
+    e, p = make_engine(mode, 11, cm, gate_sq=1e30)
+    e.set_source(src, sl)
+    e.set_target(tgt, tl)
+    qt = mat_to_qt(synth.pose_matrix(1.3, (0.1, 0.2, 1.0), (0.4, -0.2, 0.05)))
+    idx, d2, _ = e.correspondences(qt)
+    q = O.transform_points(O.se3_matrix(qt), src)
+    oi, od = O.knn(q, tgt, K, kdtree=True)
+    assert np.array_equal(idx, oi)
+    assert np.array_equal(d2, od)
+    assert (np.diff(d2, axis=1) >= 0).all()  # ascending, like FLANN's result set
+
+
+def test_knn_ties_ragged_sizes_and_gate():
+    g = np.load(os.path.join(G, "knn.npz"))
+    q, t = g["q"], g["t"]  # contains exact duplicate targets: lowest index must win
+    e, p = make_engine(sicp.MODE_EM, 3, synth.confusion_matrix(3), gate_sq=4.0)
+    lab_q = np.ones(len(q), dtype=np.uint32)
+    lab_t = np.ones(len(t), dtype=np.uint32)
+    e.set_source(q, lab_q)
+    e.set_target(t, lab_t)
+    idx, d2, _ = e.correspondences(IDENT)
+    want_i, want_d = g["idx4"].copy(), g["d2_4"]
+    want_i[~(want_d < np.float32(4.0))] = -1  # strict <
+    assert np.array_equal(idx, want_i) and np.array_equal(d2, want_d)
+    # GICP K=1, targets fewer than one LDS tile, queries not a multiple of the block
+    e2, _ = make_engine(sicp.MODE_GICP)
+    e2.set_source(q[:257])
+    e2.set_target(t[:37])
+    idx, d2, _ = e2.correspondences(IDENT)
+    oi, od = O.knn(q[:257], t[:37], 1)
+    oi[~(od < np.float32(250.0))] = -1
+    assert np.array_equal(idx, oi) and np.array_equal(d2, od)
+
+
+def test_too_few_targets_and_bad_labels_are_errors():
+    e, p = make_engine(sicp.MODE_EM, 3, synth.confusion_matrix(3))
+    pts = np.random.default_rng(0).normal(size=(50, 3)).astype(np.float32)
+    e.set_source(pts, np.ones(50, dtype=np.uint32))
+    e.set_target(pts[:3], np.ones(3, dtype=np.uint32))  # K = 4 > 3 (reference: UB, em_icp.hpp:62-65)
+    with pytest.raises(sicp.SicpError) as err:
+        e.align()
+    assert err.value.status == sicp.ERR_TOO_FEW_POINTS
+    e.set_target(pts, np.zeros(50, dtype=np.uint32))  # label 0 (reference: dist(-1), UB)
+    with pytest.raises(sicp.SicpError) as err:
+        e.align()
+    assert err.value.status == sicp.ERR_BAD_LABEL
+    e3, _ = make_engine(sicp.MODE_EM, 3)  # no confusion matrix
+    e3.set_source(pts, np.ones(50, dtype=np.uint32))
+    e3.set_target(pts, np.ones(50, dtype=np.uint32))
+    with pytest.raises(sicp.SicpError) as err:
+        e3.align()
+    assert err.value.status == sicp.ERR_NOT_READY
+
+
+# ------------------------------------------------------------------------------------------------
+# covariances / normals / histograms
+# ------------------------------------------------------------------------------------------------
+def test_covariances_vs_oracle_and_golden(lidar20k):
+    g = np.load(os.path.join(G, "cov.npz"))
+    e, p = make_engine(sicp.MODE_EM, int(g["C"]), synth.confusion_matrix(int(g["C"])))
+    e.set_source(g["p"], g["labels"])
+    cov, nrm, hist, nn = e.covariances(sicp.SOURCE, want_hist=True, want_nn=True)
+    assert np.array_equal(nn, g["nn"])                       # k = 20 self-kNN: bit exact
+    assert np.array_equal(hist.astype(np.float64) / 20.0, g["hist"]) or np.allclose(hist / 20.0, g["hist"], atol=1e-15)
+    assert np.array_equal(hist, np.rint(g["hist"] * 20).astype(np.uint8))
+    ok = g["gaps"] > 1e-6
+    dots = np.abs(np.einsum("ni,ni->n", nrm, g["normals"]))
+    assert (1 - dots[ok]).max() < 1e-12
+    assert np.allclose(cov[ok], g["cov"][ok], atol=1e-9, rtol=0)
+    # bigger, LiDAR-like cloud against the oracle (float-product quirk matters at 40 m range)
+    src, sl, *_ = lidar20k
+    e2, _ = make_engine(sicp.MODE_EM, 11, synth.confusion_matrix(11))
+    e2.set_source(src, sl)
+    cov, nrm, hist, nn = e2.covariances(sicp.SOURCE, want_hist=True, want_nn=True)
+    ocov, onrm, ohist = O.covariances(src, sl, 20, 1e-3, 11, kdtree=True)
+    onn, _ = O.knn(src, src, 20, kdtree=True)
+    assert np.array_equal(nn, onn)
+    assert np.array_equal(hist, np.rint(ohist * 20).astype(np.uint8))
+    # normals agree wherever the PCA direction is well conditioned
+    dots = np.abs(np.einsum("ni,ni->n", nrm, onrm))
+    assert np.mean(1 - dots < 1e-9) > 0.999
+    assert np.median(np.abs(cov - ocov).reshape(len(src), -1).max(axis=1)) < 1e-12
+
+
+def test_small_class_divides_by_k_quirk():
+    # quirk Q3: fewer than k points -> still divided by k (em_icp.hpp:317,320)
+    rng = np.random.default_rng(3)
+    pts = rng.normal(size=(12, 3)).astype(np.float32)
+    e, _ = make_engine(sicp.MODE_GICP)
+    e.set_source(pts)
+    cov, nrm, _, nn = e.covariances(sicp.SOURCE, want_nn=True)
+    ocov, onrm, _ = O.covariances(pts, None, 20, 1e-3)
+    assert (nn[:, 12:] == -1).all() and (np.sort(nn[:, :12], axis=1) == np.arange(12)).all()
+    assert (1 - np.abs(np.einsum("ni,ni->n", nrm, onrm))).max() < 1e-10
+
+
+# ------------------------------------------------------------------------------------------------
+# weights + accumulation
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", [sicp.MODE_GICP, sicp.MODE_EM, sicp.MODE_SEMANTIC])
+def test_weights_and_accumulate_vs_oracle(pair1, mode):
+    src, sl, tgt, tl, T_gt = pair1
+    C = 4
+    cm = synth.confusion_matrix(C)
+    e, p = make_engine(mode, C, cm)
+    e.set_source(src, sl)
+    e.set_target(tgt, tl)
+    qt = mat_to_qt(synth.pose_matrix(1.0, (0, 1, 0), (0.05, 0.0, -0.02)))
+    idx, d2, w = e.correspondences(qt)
+    op = oracle_params(mode, C)
+    if mode == sicp.MODE_SEMANTIC:
+        # per-label covariances and per-label search, in the caller's point order
+        scov = np.zeros((len(src), 3, 3)); tcov = np.zeros((len(tgt), 3, 3))
+        want = np.full((len(src), 1), -1, dtype=np.int32)
+        q = O.transform_points(O.se3_matrix(qt), src)
+        for l in np.unique(sl):
+            si, ti = np.nonzero(sl == l)[0], np.nonzero(tl == l)[0]
+            scov[si] = O.covariances(src[si], None, 20, 1e-3)[0]
+            tcov[ti] = O.covariances(tgt[ti], None, 20, 1e-3)[0]
+            oi, od = O.knn(q[si], tgt[ti], 1)
+            want[si, 0] = np.where(od[:, 0] < np.float32(250), ti[oi[:, 0]], -1)
+        assert np.array_equal(idx, want)
+        ow = (idx >= 0).astype(np.float64)
+    else:
+        scov, _, sh = O.covariances(src, sl if mode == sicp.MODE_EM else None, 20, 1e-3, C)
+        tcov, _, th = O.covariances(tgt, tl if mode == sicp.MODE_EM else None, 20, 1e-3, C)
+        ow = np.zeros(idx.shape)
+        for i in range(len(src)):
+            for c in range(idx.shape[1]):
+                j = idx[i, c]
+                if j < 0:
+                    continue
+                if mode == sicp.MODE_EM:
+                    b, _ = O.gicp_probability(qt, src[i].astype(np.float64), tgt[j].astype(np.float64), scov[i], tcov[j])
+                    ow[i, c] = O.em_prob(cm, th[j], sh[i]) * float(b)
+                else:
+                    ow[i, c] = 1.0
+    assert np.allclose(w, ow, rtol=1e-12, atol=0)
+    got = e.accumulate(qt)
+    ref = O.accumulate(op, qt, src, scov, tgt, tcov, idx, ow)
+    scale = np.abs(ref[:21]).max()
+    # closed-form Jacobian + normals vs the literal chain rule on full covariance matrices:
+    # float64 throughout, different operation order
+    assert np.allclose(got[:21], ref[:21], rtol=0, atol=1e-9 * scale)
+    assert np.allclose(got[21:27], ref[21:27], rtol=0, atol=1e-9 * np.abs(ref[21:27]).max() + 1e-9 * scale)
+    assert np.isclose(got[27], ref[27], rtol=1e-11)
+    # run-to-run reproducible (no atomics in the reduction)
+    assert np.array_equal(got, e.accumulate(qt))
+    # inner solve from the same correspondences
+    est, info = e.solve(qt)
+    oest, oinfo = O.solve(op, src, scov, tgt, tcov, idx, ow, qt)
+    rot, tr = pose_delta(est, oest)
+    assert rot < 1e-7 and tr < 1e-7
+    assert np.isclose(info["cost"], oinfo["cost"], rtol=1e-9)
+
+
+# ------------------------------------------------------------------------------------------------
+# full align(): the three reference classes
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode,key", [(sicp.MODE_GICP, "gicp"), (sicp.MODE_EM, "em"), (sicp.MODE_SEMANTIC, "sem")])
+def test_align_vs_oracle_and_golden(mode, key):
+    g = np.load(os.path.join(G, "align.npz"))
+    C = 4
+    e, p = make_engine(mode, C, g["cm"])
+    e.set_source(g["src"], g["sl"])
+    e.set_target(g["tgt"], g["tl"])
+    qt, st = e.align(IDENT)
+    oq, ost = O.align(oracle_params(mode, C), g["src"], g["sl"], g["tgt"], g["tl"], g["cm"], IDENT)
+    rot, tr = pose_delta(qt, oq)
+    assert rot < ROT_TOL and tr < TRANS_TOL
+    assert rot < 1e-7 and tr < 1e-7, (rot, tr)  # what is actually achieved
+    assert st["outer_iters"] == ost["outer_iters"] == int(g[f"{key}_outer"])
+    assert st["total_active"] == ost["total_active"] and st["total_corr"] == ost["total_corr"]
+    rot, tr = pose_err_to_matrix(qt, g[f"{key}_T"])  # independent scipy solve
+    assert rot < 1e-6 and tr < 1e-6
+    # a12: final cloud = float(matrix) * source
+    out = e.transform_source(qt)
+    M = O.se3_matrix(qt).astype(np.float32)
+    want = (g["src"] @ M[:3, :3].T + M[:3, 3]).astype(np.float32)
+    assert np.allclose(out, want, atol=2e-6)
+
+
+def test_align_config1_all_modes(pair1):
+    src, sl, tgt, tl, T_gt = pair1
+    for mode in (sicp.MODE_SEMANTIC, sicp.MODE_GICP, sicp.MODE_EM):
+        e, p = make_engine(mode, 4, synth.confusion_matrix(4))
+        e.set_source(src, sl)
+        e.set_target(tgt, tl)
+        qt, st = e.align()
+        oq, ost = O.align(oracle_params(mode, 4), src, sl, tgt, tl, synth.confusion_matrix(4), IDENT)
+        rot, tr = pose_delta(qt, oq)
+        assert rot < 1e-7 and tr < 1e-7 and st["outer_iters"] == ost["outer_iters"]
+        rot, tr = pose_err_to_matrix(qt, T_gt)
+        assert rot < 3e-3 and tr < 2e-2
+
+
+def test_semantic_skips_small_and_missing_classes():
+    src, sl, tgt, tl, T_gt = synth.config1_pair(seed=5, n_per_label=450)
+    # class 7: only in the source; class 9: in both but <= 400 source points
+    rng = np.random.default_rng(1)
+    extra_s = rng.uniform(0, 5, (500, 3)).astype(np.float32)
+    small = rng.uniform(0, 5, (300, 3)).astype(np.float32)
+    src2 = np.concatenate([src, extra_s, small]); sl2 = np.concatenate([sl, np.full(500, 7), np.full(300, 9)]).astype(np.uint32)
+    tgt2 = np.concatenate([tgt, small + 0.5]); tl2 = np.concatenate([tl, np.full(300, 9)]).astype(np.uint32)
+    e, p = make_engine(sicp.MODE_SEMANTIC)
+    e.set_source(src2, sl2)
+    e.set_target(tgt2, tl2)
+    idx, d2, w = e.correspondences(IDENT)
+    assert (idx[sl2 == 7] == -1).all() and (idx[sl2 == 9] == -1).all() and (idx[sl2 <= 4] >= 0).all()
+    qt, st = e.align()
+    oq, ost = O.align(oracle_params(sicp.MODE_SEMANTIC), src2, sl2, tgt2, tl2, None, IDENT)
+    rot, tr = pose_delta(qt, oq)
+    assert rot < 1e-7 and tr < 1e-7 and st["outer_iters"] == ost["outer_iters"]
+
+
+def test_em_lidar20k_vs_oracle_and_fused_labels(lidar20k):
+    src, sl, tgt, tl, T_gt, cm = lidar20k
+    e, p = make_engine(sicp.MODE_EM, 11, cm)
+    e.set_source(src, sl)
+    e.set_target(tgt, tl)
+    qt, st = e.align()
+    oq, ost = O.align(oracle_params(sicp.MODE_EM, 11), src, sl, tgt, tl, cm, IDENT)
+    rot, tr = pose_delta(qt, oq)
+    assert rot < ROT_TOL and tr < TRANS_TOL
+    assert st["outer_iters"] == ost["outer_iters"]
+    rot, tr = pose_err_to_matrix(qt, T_gt)
+    assert rot < 5e-3 and tr < 5e-2
+    lab = e.fused_labels(qt)
+    olab = O.fused_labels(oracle_params(sicp.MODE_EM, 11), src, sl, tgt, tl, cm, qt)
+    assert np.mean(lab == olab) > 0.9999  # arg-max of float64 sums: ties may flip on rounding
+
+
+def test_quirk_flags_change_results(pair1):
+    src, sl, tgt, tl, T_gt = pair1
+    far = src + np.float32(35.0)  # float32 products only matter away from the origin
+    e, _ = make_engine(sicp.MODE_GICP)
+    e.set_source(far)
+    _, n1, _, _ = e.covariances(sicp.SOURCE)
+    e2, _ = make_engine(sicp.MODE_GICP, quirk_float_products=0)
+    e2.set_source(far)
+    _, n2, _, _ = e2.covariances(sicp.SOURCE)
+    d = 1 - np.abs(np.einsum("ni,ni->n", n1, n2))
+    assert d.max() > 1e-8  # Q2 visibly perturbs the normals ...
+    _, on, _ = O.covariances(far, None, 20, 1e-3)
+    assert np.mean(1 - np.abs(np.einsum("ni,ni->n", n1, on)) < 1e-9) > 0.999  # ... and the default matches the reference
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE metric size (100K x 100K): size-independent properties
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def lidar100k():
+    return synth.lidar_pair(seed=2, n_points=100_000)
+
+
+def test_metric_size_properties(lidar100k):
+    src, sl, tgt, tl, T_gt, cm = lidar100k
+    e, p = make_engine(sicp.MODE_EM, 11, cm)
+    e.set_source(src, sl)
+    e.set_target(tgt, tl)
+    # kNN: sorted, gated, self-consistent distances; spot-check rows against the oracle kd-tree
+    qt0 = mat_to_qt(synth.pose_matrix(0.5, (0, 0, 1), (0.2, 0.1, 0.0)))
+    idx, d2, w = e.correspondences(qt0)
+    assert idx.shape == (100_000, 4) and (np.diff(d2, axis=1) >= 0).all()
+    assert ((idx >= 0) == (d2 < np.float32(250))).all()
+    q = O.transform_points(O.se3_matrix(qt0), src)
+    rows = np.random.default_rng(0).choice(100_000, 2000, replace=False)
+    oi, od = O.knn(q[rows], tgt, 4, kdtree=True)
+    oi[~(od < np.float32(250))] = -1
+    assert np.array_equal(idx[rows], oi) and np.array_equal(d2[rows], od)
+    dd = q[:, None, :] - tgt[np.maximum(idx, 0)]
+    rec = (dd[..., 0] * dd[..., 0] + dd[..., 1] * dd[..., 1]) + dd[..., 2] * dd[..., 2]
+    assert np.array_equal(rec[idx >= 0], d2[idx >= 0])
+    assert (w >= 0).all() and (w[idx < 0] == 0).all() and w.max() <= 1.0 + 1e-12
+    # H symmetric positive definite, deterministic
+    a1, a2 = e.accumulate(qt0), e.accumulate(qt0)
+    assert np.array_equal(a1, a2)
+    H = np.zeros((6, 6)); H[np.triu_indices(6)] = a1[:21]; H = H + H.T - np.diag(np.diag(H))
+    assert np.linalg.eigvalsh(H).min() > 0
+    # planted transform recovery, idempotence, determinism
+    qt, st = e.align()
+    rot, tr = pose_err_to_matrix(qt, T_gt)
+    assert rot < 2e-3 and tr < 2e-2, (rot, tr)
+    qt_b, st_b = e.align()
+    assert np.array_equal(qt, qt_b) and st["total_evals"] == st_b["total_evals"]
+    qt2, st2 = e.align(qt)
+    rot, tr = pose_delta(qt, qt2)
+    assert st2["outer_iters"] == 1 and rot < 3.2e-3 and tr < 3.2e-3  # inside the outer stop radius sqrt(1e-5)
