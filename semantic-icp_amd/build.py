@@ -28,7 +28,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [
-        hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
+        hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
         "-I", os.path.join(ROOT, "include"), "-I", CSRC,
         *[os.path.join(CSRC, s) for s in SOURCES],
         "-o", LIB, "-Wl,-rpath,/opt/rocm/lib",

@@ -25,10 +25,15 @@ namespace sicp {
 // ------------------------------------------------------------------------------------------
 // helpers
 // ------------------------------------------------------------------------------------------
+// NOTE: this file is compiled with -ffp-contract=off (build.py).  HIP's __fmul_rn/__fadd_rn are
+// plain operators that hipcc's default -ffp-contract=fast would fuse into FMAs; the float32
+// distance, the double transform and the float32 moment products must round exactly like the
+// reference's x86 code (separate multiply and add), or neighbour order flips on near-ties.
 
 // pcl::transformPointCloud<PointT,double>: (((m0*x + m1*y) + m2*z) + m3) in double, no
 // contraction, then one rounding to float.
 __device__ __forceinline__ float xform_row(const double* m, double x, double y, double z) {
+#pragma clang fp contract(off)
   double a = __dmul_rn(m[0], x);
   a = __dadd_rn(a, __dmul_rn(m[1], y));
   a = __dadd_rn(a, __dmul_rn(m[2], z));
@@ -39,6 +44,7 @@ __device__ __forceinline__ float xform_row(const double* m, double x, double y, 
 // FLANN L2_Simple<float>: ((dx*dx) + dy*dy) + dz*dz, every product and sum rounded to float
 // (no FMA contraction, so that neighbour order matches the CPU kd-tree bit for bit).
 __device__ __forceinline__ float l2_simple(float ax, float ay, float az, float bx, float by, float bz) {
+#pragma clang fp contract(off)
   const float dx = __fsub_rn(ax, bx), dy = __fsub_rn(ay, by), dz = __fsub_rn(az, bz);
   float r = __fmul_rn(dx, dx);
   r = __fadd_rn(r, __fmul_rn(dy, dy));

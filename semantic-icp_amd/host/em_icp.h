@@ -1,0 +1,101 @@
+// em_icp.h -- semanticicp::EmIterativeClosestPoint<N> with the reference's public surface
+// (reference: semantic_icp/em_icp.h:17-122, impl/em_icp.hpp).  align() / getFusedLabels() run on
+// the MI355X engine; the class count N stays a template parameter here (the C ABI takes it at
+// run time).
+#ifndef SEMANTIC_ICP_EM_ICP_H_
+#define SEMANTIC_ICP_EM_ICP_H_
+#include <cstddef>
+#include <memory>
+#include <vector>
+
+#include "sicp_engine.hpp"
+
+namespace semanticicp {
+
+template <size_t N>
+class EmIterativeClosestPoint {
+ public:
+  typedef pcl::PointXYZL PointT;
+  typedef typename pcl::PointCloud<PointT> PointCloud;
+  typedef typename PointCloud::Ptr PointCloudPtr;
+  typedef std::vector<Eigen::Matrix3d, Eigen::aligned_allocator<Eigen::Matrix3d>> MatricesVector;
+  typedef std::shared_ptr<MatricesVector> MatricesVectorPtr;
+  typedef typename pcl::KdTreeFLANN<PointT> KdTree;
+  typedef typename KdTree::Ptr KdTreePtr;
+  typedef Eigen::Matrix<double, 6, 1> Vector6d;
+
+  EmIterativeClosestPoint(int k = 20, double epsilon = 0.001) : kCorrespondences_(k), kEpsilon_(epsilon), outer_iter(0), cm_set_(false) {}
+
+  // reference: em_icp.h:50-66 (the reference builds its kd-tree here; the engine uploads the
+  // cloud to HBM here)
+  inline void setSourceCloud(const PointCloudPtr& cloud) { source_cloud_ = cloud; upload(SICP_SOURCE, cloud); }
+  inline void setTargetCloud(const PointCloudPtr& cloud) { target_cloud_ = cloud; upload(SICP_TARGET, cloud); }
+
+  // reference: em_icp.h:68-71
+  inline void setConfusionMatrix(const Eigen::Matrix<double, (int)N, (int)N>& in) {
+    double cm[N * N];
+    for (size_t r = 0; r < N; ++r)
+      for (size_t c = 0; c < N; ++c) cm[r * N + c] = in((int)r, (int)c);
+    sicp_handle h = engine_.get();
+    detail::check(sicp_set_confusion(h, (int32_t)N, cm), h, "sicp_set_confusion");
+    cm_set_ = true;
+  }
+
+  // reference: impl/em_icp.hpp:25-200 (finalCloud may be nullptr, :194)
+  void align(PointCloudPtr finalCloud, const Sophus::SE3d& initTransform) {
+    sicp_handle h = engine_.get();
+    configure(h);
+    double out[7];
+    int32_t iters = 0;
+    detail::check(sicp_align(h, initTransform.data(), out, &iters, nullptr), h, "sicp_align");
+    final_transformation_ = detail::to_se3(out);
+    outer_iter = iters;
+    if (finalCloud != nullptr) {
+      Eigen::Matrix4f mat = (final_transformation_.matrix()).template cast<float>();
+      pcl::transformPointCloud(*source_cloud_, *finalCloud, mat);
+    }
+  }
+
+  // reference: impl/em_icp.hpp:202-268 (appends one point per source point)
+  void getFusedLabels(PointCloudPtr labeledCloud, const Sophus::SE3d& transformation) {
+    sicp_handle h = engine_.get();
+    configure(h);
+    std::vector<uint32_t> lab(source_cloud_->size());
+    detail::check(sicp_fused_labels(h, transformation.data(), lab.data()), h, "sicp_fused_labels");
+    for (size_t i = 0; i < source_cloud_->size(); ++i) {
+      PointT p = source_cloud_->points[i];
+      p.label = lab[i];
+      labeledCloud->push_back(p);
+    }
+  }
+
+  Sophus::SE3d getFinalTransFormation() { return final_transformation_; }
+  int getOuterIter() { return outer_iter; }
+
+ protected:
+  void configure(sicp_handle h) {
+    sicp_params p;
+    detail::check(sicp_default_params(SICP_MODE_EM, &p), h, "sicp_default_params");
+    p.k_cov = kCorrespondences_;
+    p.epsilon = kEpsilon_;
+    p.num_classes = (int32_t)N;
+    detail::check(sicp_set_params(h, &p), h, "sicp_set_params");
+  }
+  void upload(int which, const PointCloudPtr& cloud) {
+    sicp_handle h = engine_.get();
+    configure(h);
+    detail::FlatCloud f = detail::flatten(*cloud);
+    detail::check(sicp_set_cloud(h, which, f.size(), f.x.data(), f.y.data(), f.z.data(), f.label.data()), h, "sicp_set_cloud");
+  }
+
+  int kCorrespondences_;
+  double kEpsilon_;
+  int outer_iter;
+  bool cm_set_;
+  Sophus::SE3d final_transformation_;
+  PointCloudPtr source_cloud_, target_cloud_;
+  detail::Engine engine_;
+};
+
+}  // namespace semanticicp
+#endif  // SEMANTIC_ICP_EM_ICP_H_

@@ -1,0 +1,112 @@
+// gicp.h -- semanticicp::GICP<PointT> with the reference's public surface
+// (reference: semantic_icp/gicp.h:15-132, impl/gicp.hpp).  align() runs on the MI355X engine.
+#ifndef GICP_H_
+#define GICP_H_
+#include <memory>
+#include <vector>
+
+#include "semantic_point_cloud.h"
+#include "sicp_engine.hpp"
+
+namespace semanticicp {
+
+template <typename PointT>
+class GICP {
+ public:
+  typedef pcl::PointCloud<PointT> PointCloud;
+  typedef typename PointCloud::Ptr PointCloudPtr;
+  typedef std::vector<Eigen::Matrix3d, Eigen::aligned_allocator<Eigen::Matrix3d>> MatricesVector;
+  typedef std::vector<Eigen::Matrix<double, 6, 6>, Eigen::aligned_allocator<Eigen::Matrix<double, 6, 6>>> CovarianceVector;
+  typedef std::shared_ptr<MatricesVector> MatricesVectorPtr;
+  typedef std::shared_ptr<const MatricesVector> MatricesVectorConstPtr;
+  typedef pcl::KdTreeFLANN<PointT> KdTree;
+  typedef typename KdTree::Ptr KdTreePtr;
+  typedef Eigen::Matrix<double, 6, 1> Vector6d;
+
+  GICP(int k = 20, double epsilon = 0.001) : kCorrespondences_(k), epsilon_(epsilon), outer_iter(0) {}
+
+  // reference: gicp.h:42-70.  The kd-tree / covariance arguments of the 3-argument overloads are
+  // accepted and handed back by the getters, but align() recomputes the covariances from the
+  // cloud, as the reference does (impl/gicp.hpp:33-34).  (exec/kitti_eval.cc:213 passes the tree
+  // of a *different* scan there -- SURVEY.md quirk Q7 -- which this engine therefore ignores.)
+  inline void setSourceCloud(const PointCloudPtr& cloud) {
+    sourceCloud_ = cloud;
+    sourceKdTree_ = KdTreePtr(new KdTree());
+    sourceKdTree_->setInputCloud(sourceCloud_);
+    sourceCovariances_ = MatricesVectorPtr(new MatricesVector());
+  }
+  inline void setSourceCloud(const PointCloudPtr& cloud, const KdTreePtr& tree, const MatricesVectorPtr& covs) {
+    sourceCloud_ = cloud; sourceKdTree_ = tree; sourceCovariances_ = covs;
+  }
+  inline void setTargetCloud(const PointCloudPtr& cloud) {
+    targetCloud_ = cloud;
+    targetKdTree_ = KdTreePtr(new KdTree());
+    targetKdTree_->setInputCloud(targetCloud_);
+    targetCovariances_ = MatricesVectorPtr(new MatricesVector());
+  }
+  inline void setTargetCloud(const PointCloudPtr& cloud, const KdTreePtr& tree, const MatricesVectorPtr& covs) {
+    targetCloud_ = cloud; targetKdTree_ = tree; targetCovariances_ = covs;
+  }
+  inline KdTreePtr getSourceKdTree() { return sourceKdTree_; }
+  inline MatricesVectorPtr getSourceCovariances() { return sourceCovariances_; }
+  inline KdTreePtr getTargetKdTree() { return targetKdTree_; }
+  inline MatricesVectorPtr getTargetCovariances() { return targetCovariances_; }
+
+  void align(PointCloudPtr finalCloud) {  // reference: impl/gicp.hpp:21-27
+    Sophus::SE3d init;
+    align(finalCloud, init);
+  }
+
+  void align(PointCloudPtr finalCloud, Sophus::SE3d& initTransform) {  // reference: impl/gicp.hpp:29-175
+    sicp_handle h = engine_.get();
+    sicp_params p;
+    detail::check(sicp_default_params(SICP_MODE_GICP, &p), h, "sicp_default_params");
+    p.k_cov = kCorrespondences_;
+    p.epsilon = epsilon_;
+    detail::check(sicp_set_params(h, &p), h, "sicp_set_params");
+    detail::FlatCloud s = detail::flatten(*sourceCloud_), t = detail::flatten(*targetCloud_);
+    detail::check(sicp_set_cloud(h, SICP_SOURCE, s.size(), s.x.data(), s.y.data(), s.z.data(), nullptr), h, "sicp_set_cloud");
+    detail::check(sicp_set_cloud(h, SICP_TARGET, t.size(), t.x.data(), t.y.data(), t.z.data(), nullptr), h, "sicp_set_cloud");
+    double out[7];
+    int32_t iters = 0;
+    detail::check(sicp_align(h, initTransform.data(), out, &iters, nullptr), h, "sicp_align");
+    finalTransformation_ = detail::to_se3(out);
+    outer_iter = iters;
+    fill_covariances(h, SICP_SOURCE, s.size(), sourceCovariances_);
+    fill_covariances(h, SICP_TARGET, t.size(), targetCovariances_);
+    if (finalCloud != nullptr) {  // impl/gicp.hpp:166-172
+      Eigen::Matrix4f mat = (finalTransformation_.matrix()).template cast<float>();
+      pcl::transformPointCloud(*sourceCloud_, *finalCloud, mat);
+    }
+  }
+
+  Sophus::SE3d getFinalTransFormation() { return finalTransformation_; }
+  int getOuterIter() { return outer_iter; }
+
+ protected:
+  void fill_covariances(sicp_handle h, int which, int n, MatricesVectorPtr& out) {
+    if (!out) out = MatricesVectorPtr(new MatricesVector());
+    out->resize(n);
+    if (n == 0) return;
+    std::vector<double> c9((size_t)n * 9);
+    detail::check(sicp_covariances(h, which, c9.data(), nullptr, nullptr, nullptr), h, "sicp_covariances");
+    for (int i = 0; i < n; ++i)
+      for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) (*out)[i](a, b) = c9[(size_t)i * 9 + 3 * a + b];
+  }
+
+  int kCorrespondences_;
+  double epsilon_;
+  int outer_iter;
+  Sophus::SE3d finalTransformation_;
+  PointCloudPtr sourceCloud_;
+  KdTreePtr sourceKdTree_;
+  MatricesVectorPtr sourceCovariances_;
+  PointCloudPtr targetCloud_;
+  KdTreePtr targetKdTree_;
+  MatricesVectorPtr targetCovariances_;
+  detail::Engine engine_;
+};
+
+}  // namespace semanticicp
+#endif  // GICP_H_

@@ -1,0 +1,82 @@
+// sicp_engine.hpp -- RAII holder of one C-ABI handle (include/sicp.h) for the class shims.
+#ifndef SICP_HOST_ENGINE_HPP_
+#define SICP_HOST_ENGINE_HPP_
+#include <cstdlib>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "sicp.h"
+
+#if defined(SICP_HAVE_REAL_DEPS)
+#include <Eigen/Core>
+#include <pcl/kdtree/kdtree_flann.h>
+#include <pcl/point_cloud.h>
+#include <pcl/point_types.h>
+#include <sophus/se3.hpp>
+#else
+#include "compat/eigen_lite.h"
+#include "compat/pcl_lite.h"
+#include "compat/sophus_lite.h"
+#endif
+
+namespace semanticicp {
+namespace detail {
+
+// The reference's methods return void and never throw; a registration that cannot run on the
+// GPU must not look like a success, so failures surface as std::runtime_error.
+inline void check(int status, sicp_handle h, const char* where) {
+  if (status == SICP_OK) return;
+  std::string msg = std::string(where) + ": " + sicp_strerror(status);
+  if (status == SICP_ERR_HIP && h) msg += std::string(" -- ") + sicp_last_error(h);
+  throw std::runtime_error(msg);
+}
+
+class Engine {
+ public:
+  Engine() = default;
+  Engine(const Engine&) = delete;
+  Engine& operator=(const Engine&) = delete;
+  ~Engine() { if (h_) sicp_destroy(h_); }
+  sicp_handle get() {
+    if (!h_) {
+      const char* dev = std::getenv("SICP_DEVICE");  // one process / thread per GPU picks its device here
+      check(sicp_create(dev ? std::atoi(dev) : 0, &h_), nullptr, "sicp_create");
+    }
+    return h_;
+  }
+ private:
+  sicp_handle h_ = nullptr;
+};
+
+struct FlatCloud {
+  std::vector<float> x, y, z;
+  std::vector<uint32_t> label;
+  void push(float px, float py, float pz, uint32_t l) { x.push_back(px); y.push_back(py); z.push_back(pz); label.push_back(l); }
+  int size() const { return (int)x.size(); }
+};
+
+inline uint32_t label_of(const pcl::PointXYZ&) { return 0; }
+inline uint32_t label_of(const pcl::PointXYZL& p) { return p.label; }
+
+template <typename PointT>
+FlatCloud flatten(const pcl::PointCloud<PointT>& c) {
+  FlatCloud f;
+  f.x.reserve(c.size()); f.y.reserve(c.size()); f.z.reserve(c.size()); f.label.reserve(c.size());
+  for (const auto& p : c.points) f.push(p.x, p.y, p.z, label_of(p));
+  return f;
+}
+
+inline Sophus::SE3d to_se3(const double* qt) {
+#if defined(SICP_HAVE_REAL_DEPS)
+  Sophus::SE3d s;
+  for (int i = 0; i < 7; ++i) s.data()[i] = qt[i];
+  return s;
+#else
+  return Sophus::SE3d::fromData(qt);
+#endif
+}
+
+}  // namespace detail
+}  // namespace semanticicp
+#endif

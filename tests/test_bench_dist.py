@@ -1,0 +1,35 @@
+"""CPU test of the N > 1 path of bench.py: two gloo ranks, pairs sharded (one per rank), no
+data-path collective; rank 0 reports the aggregate over the max-over-ranks time."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run(cmd):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout  # exactly ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_world_size_2_gloo_dry_run():
+    one = run([sys.executable, "bench.py", "--dry-run", "--steps", "2", "--warmup", "1", "--points", "20000"])
+    two = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", "29541", "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1",
+               "--dry-run", "--points", "20000"])
+    for out, n in ((one, 1), (two, 2)):
+        assert out["n_gpus"] == n and out["steps"] == 2 and out["warmup"] == 1
+        assert out["scaling"] == "weak" and out["higher_is_better"] is True and out["data"] == "dry-run"
+        assert out["metric"] == "correspondences/sec" and out["unit"] == "correspondences/s"
+        assert out["vs_baseline"] is None and "workload" in out["config"]
+    # dry-run step of rank r sleeps 10*(1+r) ms and reports 3 outer iterations of 20000*4 slots:
+    # the aggregate counts both ranks' correspondences over the slower rank's time
+    corr_per_rank = 2 * 3 * 20000 * 4
+    assert abs(one["value"] * one["ms_per_step"] * 2e-3 - corr_per_rank) < 1e-6 * corr_per_rank
+    assert abs(two["value"] * two["ms_per_step"] * 2e-3 - 2 * corr_per_rank) < 1e-6 * corr_per_rank
+    assert two["ms_per_step"] > 1.5 * one["ms_per_step"]  # max over ranks, rank 1 is slower
