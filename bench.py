@@ -43,6 +43,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--points", type=int, default=N_POINTS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--nn-method", type=int, default=None, help="0 brute force, 1 box tree (default: library default)")
     ap.add_argument("--dry-run", action="store_true", help="exercise the multi-process plumbing without a GPU")
     return ap.parse_args()
 
@@ -139,6 +140,9 @@ def main():
         p = sicp.default_params(sicp.MODE_EM)
         p.num_classes = N_CLASSES
         p.profile = 1  # SICP_PROFILE_NN: HIP events around the dominant kernel, on its own stream
+        if args.nn_method is not None:
+            p.nn_method = args.nn_method
+        nn_method = p.nn_method
         engine = sicp.Engine(dist.local_rank % ndev, p)
         engine.set_confusion(cm)
         engine.set_source(src, sl)   # clouds resident in HBM before the timed region
@@ -202,7 +206,8 @@ def main():
             alg_bytes = 12 * n + 12 * n + 8 * K_CORR * n     # src+tgt xyz once, idx+dist^2 out
             achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
             out["roofline"] = {
-                "kernel": "nn_partial_kernel<K=4,Q=2> (brute-force correspondence search, one launch per outer iteration)",
+                "kernel": ("bvh_knn_kernel<K=4> (exact box-tree correspondence search, one launch per outer iteration)" if nn_method == 1 else
+                           "nn_partial_kernel<K=4,Q=2> (brute-force correspondence search, one launch per outer iteration)"),
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None,
                 "avg_launch_ms": avg_ms, "launches": nn_launches, "algorithmic_bytes_per_launch": alg_bytes,

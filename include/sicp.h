@@ -101,7 +101,8 @@ typedef struct sicp_params {
   int32_t quirk_float_products;   /* Q2: float32 products in the covariance moments
                                      (em_icp.hpp:307-314); 0 = double products       */
   /* engine knobs (no reference counterpart) */
-  int32_t nn_method;              /* 0 = LDS-tiled brute force (exact)                  */
+  int32_t nn_method;              /* 0 = LDS-tiled brute force, 1 = Morton box-tree walk;
+                                     both exact, bit-identical results                  */
   int32_t profile;                /* SICP_PROFILE_* bit mask: bracket those kernels with
                                      HIP events on the handle's stream (sicp_stats)     */
 } sicp_params;

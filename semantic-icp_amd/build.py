@@ -11,7 +11,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libsicp.so")
 SOURCES = ["kernels.hip", "sicp_api.cpp"]
-HEADERS = ["kernels.h", "lm.hpp", "se3.hpp"]
+HEADERS = ["kernels.h", "lm.hpp", "se3.hpp", "bvh.hpp"]
 ARCH = "gfx950"
 
 

@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "bvh.hpp"
+
 namespace sicp {
 
 struct Pose {
@@ -21,26 +23,54 @@ struct LossArgs {
   int use_sqloss;
 };
 
-// one launch = queries [q_begin, q_begin+q_count) against targets [t_begin, t_begin+t_count)
+// brute force: queries [q_begin, q_begin+q_count) (SoA, device order) against the packed points
+// pts4[t_begin .. t_begin+t_count) = (x, y, z, caller index bits)
 struct NNArgs {
   const float *qx, *qy, *qz;
   int q_begin, q_count;
   int do_xform;   // 1: query = float(M * p) (pcl::transformPointCloud), 0: query = p
   double M[12];   // rows 0..2 of the 4x4 pose matrix
-  const float *tx, *ty, *tz;
+  const float4* pts4;
   int t_begin, t_count;
-  int chunk_len;  // targets per grid.y slice
-  float* part_d;  // [n_chunks][q_count][K]
-  int* part_i;    // indices relative to t_begin
+  int chunk_len;              // targets per grid.y slice
+  unsigned long long* part;   // [n_chunks][q_count][K] keys
 };
 
 struct MergeArgs {
-  int q_begin, q_count, n_chunks, t_begin;
-  const float* part_d;
-  const int* part_i;
-  float gate_sq;  // +inf for the covariance self-query
-  int* out_i;     // [n][K] global target indices, -1 = none / gated out
-  float* out_d;   // [n][K] or nullptr
+  int q_begin, q_count, n_chunks;
+  const unsigned long long* part;
+  const int* inv;   // caller index -> device index of the target cloud
+  float gate_sq;    // +inf for the covariance self-query
+  int* out_i;       // [n][K] device indices of the target cloud, -1 = none / gated out
+  float* out_d;     // [n][K] or nullptr
+};
+
+// one tree = one cloud segment (bvh.hpp)
+struct TreeArgs {
+  const float4* pts4;     // packed points of the whole cloud, every segment padded to kLeaf
+  const float4* box_lo;   // boxes of all segments
+  const float4* box_hi;
+  const int* lut;         // seed tables of all segments
+  TreeLevels lv;
+  int n;                  // points in this segment
+  int pt_begin;           // first packed point of the segment
+  int node_begin;         // first box of the segment
+  int lut_begin;
+  float lo[3];
+  float scale;
+};
+
+struct KnnArgs {
+  const float *qx, *qy, *qz;
+  int q_begin, q_count;
+  int do_xform;
+  double M[12];
+  TreeArgs tree;
+  int self;        // queries are the tree's own points (covariance neighbourhoods)
+  float gate_sq;
+  const int* inv;
+  int* out_i;
+  float* out_d;
 };
 
 struct CovArgs {
@@ -83,6 +113,7 @@ bool nn_k_supported(int K);
 int nn_queries_per_thread(int K);
 hipError_t launch_nn_partial(int K, const NNArgs& a, int n_chunks, hipStream_t st);
 hipError_t launch_nn_merge(int K, const MergeArgs& m, hipStream_t st);
+hipError_t launch_bvh_knn(int K, const KnnArgs& a, hipStream_t st);
 hipError_t launch_cov(const CovArgs& a, hipStream_t st);
 hipError_t launch_em_weight(const WeightArgs& a, hipStream_t st);
 hipError_t launch_fused_labels(const WeightArgs& a, uint32_t* out, hipStream_t st);

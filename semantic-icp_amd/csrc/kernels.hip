@@ -10,11 +10,13 @@
 //                           Ceres' Corrector, summed to 28 doubles
 //                                                        gicp_cost_function.h:27-73
 //
-// Design notes (MI355X): SoA float32 clouds for coalesced reads; target tiles staged in LDS and
-// read back as wave-uniform (broadcast) ds_read_b128; top-K kept in statically indexed VGPRs;
-// the N_s x N_t search is split over a 2-D grid (query blocks x target chunks) so that >>256
-// workgroups are in flight, with a deterministic merge; no atomics anywhere, so every result is
-// run-to-run reproducible.  Nothing here is GEMM shaped: no MFMA.
+// Design notes (MI355X): clouds live in HBM in Morton order (SoA float32 + a packed float4
+// x,y,z,caller-index copy for the search kernels).  Two exact kNN engines produce identical
+// results: an LDS-tiled brute force (target tiles broadcast from LDS, 2-D grid of query blocks x
+// target chunks, deterministic merge) and a stackless walk of a 4-ary box tree over the Morton
+// order.  Top-K lists are 64-bit (distance, caller index) keys in statically indexed VGPRs.
+// No floating-point atomics anywhere, so every result is run-to-run reproducible.  Nothing here
+// is GEMM shaped: no MFMA.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -52,19 +54,67 @@ __device__ __forceinline__ float l2_simple(float ax, float ay, float az, float b
   return r;
 }
 
-// Insert (d, i) into an ascending list held in registers.  Precondition: d < bd[K-1].
-// Strict comparisons keep the earlier (lower-index) entry first on ties.
+// ---- (distance, caller index) keys -----------------------------------------------------------
+// A neighbour is the 64-bit key  float_bits(d2) << 32 | caller_index.  d2 >= +0, so the float
+// bit pattern orders like the value and one unsigned compare is the lexicographic order
+// "smaller distance first, lower caller index on exact ties" (the tie rule this build defines;
+// FLANN leaves tie order unspecified) --
+// independent of the order in which candidates are visited (device order is Morton order).
+typedef unsigned long long u64;
+static constexpr u64 KEY_EMPTY = ~0ull;  // high word = NaN pattern: above every real distance
+
+__device__ __forceinline__ u64 make_key(float d, unsigned orig) { return ((u64)__float_as_uint(d) << 32) | orig; }
+__device__ __forceinline__ float key_dist(u64 k) { return __uint_as_float((unsigned)(k >> 32)); }
+
+// Insert into an ascending key list held in registers.  Precondition: key < bk[K-1].
 template <int K>
-__device__ __forceinline__ void topk_insert(float (&bd)[K], int (&bi)[K], float d, int i) {
-  bd[K - 1] = d;
-  bi[K - 1] = i;
+__device__ __forceinline__ void key_insert(u64 (&bk)[K], u64 key) {
+  bk[K - 1] = key;
 #pragma unroll
   for (int j = K - 1; j > 0; --j) {
-    const bool sw = bd[j] < bd[j - 1];
-    const float dlo = sw ? bd[j] : bd[j - 1], dhi = sw ? bd[j - 1] : bd[j];
-    const int ilo = sw ? bi[j] : bi[j - 1], ihi = sw ? bi[j - 1] : bi[j];
-    bd[j - 1] = dlo; bd[j] = dhi;
-    bi[j - 1] = ilo; bi[j] = ihi;
+    const bool sw = bk[j] < bk[j - 1];
+    const u64 lo = sw ? bk[j] : bk[j - 1], hi = sw ? bk[j - 1] : bk[j];
+    bk[j - 1] = lo;
+    bk[j] = hi;
+  }
+}
+
+// candidate test shared by both search kernels; wd caches key_dist(bk[K-1]) (NaN while the list
+// is not full, and `!(d > NaN)` is true)
+template <int K>
+__device__ __forceinline__ void consider(u64 (&bk)[K], float& wd, float d, unsigned orig) {
+  if (!(d > wd)) {
+    const u64 key = make_key(d, orig);
+    if (key < bk[K - 1]) {
+      key_insert<K>(bk, key);
+      wd = key_dist(bk[K - 1]);
+    }
+  }
+}
+
+__device__ __forceinline__ void load_query(const float* qx, const float* qy, const float* qz, int g, int do_xform,
+                                           const double* M, float& px, float& py, float& pz) {
+  const float x = qx[g], y = qy[g], z = qz[g];
+  if (do_xform) {
+    const double dx = x, dy = y, dz = z;
+    px = xform_row(M + 0, dx, dy, dz);
+    py = xform_row(M + 4, dx, dy, dz);
+    pz = xform_row(M + 8, dx, dy, dz);
+  } else {
+    px = x; py = y; pz = z;
+  }
+}
+
+// results -> device indices (caller index -> device index through inv[]), gate, distances
+template <int K>
+__device__ __forceinline__ void emit(const u64 (&bk)[K], const int* inv, float gate_sq, int* out_i, float* out_d, size_t o) {
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const unsigned orig = (unsigned)bk[k];
+    const float d = bk[k] == KEY_EMPTY ? INFINITY : key_dist(bk[k]);
+    const bool keep = orig != 0xffffffffu && d < gate_sq;  // strict <, float compare (em_icp.hpp:65)
+    out_i[o + k] = keep ? inv[orig] : -1;
+    if (out_d) out_d[o + k] = d;
   }
 }
 
@@ -78,42 +128,28 @@ __global__ __launch_bounds__(BS) void nn_partial_kernel(NNArgs a) {
   const int c_lo = chunk * a.chunk_len;
   const int c_hi = min(c_lo + a.chunk_len, a.t_count);
 
-  float px[Q], py[Q], pz[Q];
-  float bd[Q][K];
-  int bi[Q][K];
+  float px[Q], py[Q], pz[Q], wd[Q];
+  u64 bk[Q][K];
 #pragma unroll
   for (int j = 0; j < Q; ++j) {
     int q = blockIdx.x * (BS * Q) + j * BS + threadIdx.x;
     q = min(q, a.q_count - 1);
-    const float x = a.qx[a.q_begin + q], y = a.qy[a.q_begin + q], z = a.qz[a.q_begin + q];
-    if (a.do_xform) {
-      const double dx = x, dy = y, dz = z;
-      px[j] = xform_row(a.M + 0, dx, dy, dz);
-      py[j] = xform_row(a.M + 4, dx, dy, dz);
-      pz[j] = xform_row(a.M + 8, dx, dy, dz);
-    } else {
-      px[j] = x; py[j] = y; pz[j] = z;
-    }
+    load_query(a.qx, a.qy, a.qz, a.q_begin + q, a.do_xform, a.M, px[j], py[j], pz[j]);
 #pragma unroll
-    for (int k = 0; k < K; ++k) { bd[j][k] = INFINITY; bi[j][k] = -1; }
+    for (int k = 0; k < K; ++k) bk[j][k] = KEY_EMPTY;
+    wd[j] = key_dist(KEY_EMPTY);
   }
 
   for (int t0 = c_lo; t0 < c_hi; t0 += TILE) {
     const int n = min(TILE, c_hi - t0);
     __syncthreads();
-    for (int p = threadIdx.x; p < n; p += BS) {
-      const int g = a.t_begin + t0 + p;
-      tile[p] = make_float4(a.tx[g], a.ty[g], a.tz[g], 0.f);
-    }
+    for (int p = threadIdx.x; p < n; p += BS) tile[p] = a.pts4[a.t_begin + t0 + p];
     __syncthreads();
 #pragma unroll 4
     for (int p = 0; p < n; ++p) {
-      const float4 t = tile[p];  // wave-uniform address: one broadcast ds_read_b128
+      const float4 t = tile[p];  // wave-uniform address: one broadcast LDS read
 #pragma unroll
-      for (int j = 0; j < Q; ++j) {
-        const float d = l2_simple(px[j], py[j], pz[j], t.x, t.y, t.z);
-        if (d < bd[j][K - 1]) topk_insert<K>(bd[j], bi[j], d, t0 + p);
-      }
+      for (int j = 0; j < Q; ++j) consider<K>(bk[j], wd[j], l2_simple(px[j], py[j], pz[j], t.x, t.y, t.z), __float_as_uint(t.w));
     }
   }
 
@@ -123,37 +159,117 @@ __global__ __launch_bounds__(BS) void nn_partial_kernel(NNArgs a) {
     if (q < a.q_count) {
       const size_t o = ((size_t)chunk * a.q_count + q) * K;
 #pragma unroll
-      for (int k = 0; k < K; ++k) { a.part_d[o + k] = bd[j][k]; a.part_i[o + k] = bi[j][k]; }
+      for (int k = 0; k < K; ++k) a.part[o + k] = bk[j][k];
     }
   }
 }
 
-// merge the per-chunk lists (ascending chunk order == ascending index order, so strict <
-// keeps the lowest index on ties), apply the distance gate, emit global target indices
+// merge the per-chunk key lists, apply the distance gate, emit device indices
 template <int K>
 __global__ __launch_bounds__(256) void nn_merge_kernel(MergeArgs a) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= a.q_count) return;
-  float bd[K];
-  int bi[K];
+  u64 bk[K];
 #pragma unroll
-  for (int k = 0; k < K; ++k) { bd[k] = INFINITY; bi[k] = -1; }
+  for (int k = 0; k < K; ++k) bk[k] = KEY_EMPTY;
   for (int c = 0; c < a.n_chunks; ++c) {
     const size_t o = ((size_t)c * a.q_count + q) * K;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      const float d = a.part_d[o + k];
-      const int i = a.part_i[o + k];
-      if (i >= 0 && d < bd[K - 1]) topk_insert<K>(bd, bi, d, i);
+      const u64 key = a.part[o + k];
+      if (key < bk[K - 1]) key_insert<K>(bk, key);
     }
   }
-  const size_t o = (size_t)(a.q_begin + q) * K;
+  emit<K>(bk, a.inv, a.gate_sq, a.out_i, a.out_d, (size_t)(a.q_begin + q) * K);
+}
+
+// ------------------------------------------------------------------------------------------
+// exact kNN through the Morton-ordered 4-ary box tree (bvh.hpp): one query per lane, seed leaf
+// for a first bound, then a stackless fixed-order depth-first walk pruned by the float32 box
+// distance.  Result sets are order independent (keys), so the output equals brute force bit for
+// bit.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned spread5(unsigned v) {
+  v &= 31u;
+  v = (v | (v << 8)) & 0x100fu;
+  v = (v | (v << 4)) & 0x10c3u;
+  v = (v | (v << 2)) & 0x1249u;
+  return v;
+}
+
+__device__ __forceinline__ unsigned quant5(float p, float lo, float scale) {
+  const float v = (p - lo) * scale;
+  unsigned q = !(v > 0.f) ? 0u : (v >= 2097151.f ? 2097151u : (unsigned)v);
+  return q >> 16;
+}
+
+template <int K>
+__device__ __forceinline__ void scan_leaf(const float4* __restrict__ pts, float px, float py, float pz, u64 (&bk)[K], float& wd) {
+  float4 t[kLeaf];
 #pragma unroll
-  for (int k = 0; k < K; ++k) {
-    const bool keep = bi[k] >= 0 && bd[k] < a.gate_sq;  // strict <, float compare (em_icp.hpp:65)
-    a.out_i[o + k] = keep ? bi[k] + a.t_begin : -1;
-    if (a.out_d) a.out_d[o + k] = bd[k];
+  for (int p = 0; p < kLeaf; ++p) t[p] = pts[p];  // padded with (+inf, +inf, +inf, -1): no bounds test
+#pragma unroll
+  for (int p = 0; p < kLeaf; ++p) consider<K>(bk, wd, l2_simple(px, py, pz, t[p].x, t[p].y, t[p].z), __float_as_uint(t[p].w));
+}
+
+template <int K>
+__global__ __launch_bounds__(64) void bvh_knn_kernel(KnnArgs a) {
+  __shared__ int s_off[kMaxLevels], s_cnt[kMaxLevels];
+  if (threadIdx.x < kMaxLevels) { s_off[threadIdx.x] = a.tree.lv.off[threadIdx.x]; s_cnt[threadIdx.x] = a.tree.lv.cnt[threadIdx.x]; }
+  __syncthreads();
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= a.q_count) return;
+  float px, py, pz;
+  load_query(a.qx, a.qy, a.qz, a.q_begin + q, a.do_xform, a.M, px, py, pz);
+  u64 bk[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) bk[k] = KEY_EMPTY;
+  float wd = key_dist(KEY_EMPTY);
+  const float4* __restrict__ pts = a.tree.pts4 + a.tree.pt_begin;
+  const float4* __restrict__ blo = a.tree.box_lo + a.tree.node_begin;
+  const float4* __restrict__ bhi = a.tree.box_hi + a.tree.node_begin;
+
+  int seed;
+  if (a.self) {
+    seed = q / kLeaf;
+  } else {
+    const unsigned prefix = spread5(quant5(px, a.tree.lo[0], a.tree.scale)) | (spread5(quant5(py, a.tree.lo[1], a.tree.scale)) << 1) |
+                            (spread5(quant5(pz, a.tree.lo[2], a.tree.scale)) << 2);
+    seed = a.tree.lut[a.tree.lut_begin + prefix];
   }
+  scan_leaf<K>(pts + (size_t)seed * kLeaf, px, py, pz, bk, wd);
+
+  const int top = a.tree.lv.n_levels - 1;
+  int k = top, j = 0;
+  for (;;) {
+    if (!(k == 0 && j == seed)) {
+      const int node = s_off[k] + j;
+      const float4 lo = blo[node], hi = bhi[node];
+      const float ex = fmaxf(fmaxf(lo.x - px, px - hi.x), 0.f);
+      const float ey = fmaxf(fmaxf(lo.y - py, py - hi.y), 0.f);
+      const float ez = fmaxf(fmaxf(lo.z - pz, pz - hi.z), 0.f);
+      const float lb = (ex * ex + ey * ey) + ez * ez;  // lower bound of l2_simple over the box (monotone rounding)
+      if (!(lb > wd)) {  // lb == wd may still hide an equal distance with a lower caller index
+        if (k == 0) {
+          scan_leaf<K>(pts + (size_t)j * kLeaf, px, py, pz, bk, wd);
+        } else {
+          --k;
+          j *= kFan;
+          continue;
+        }
+      }
+    }
+    bool done = false;
+    for (;;) {  // next node in depth-first order
+      ++j;
+      if ((j & (kFan - 1)) != 0 && j < s_cnt[k]) break;
+      if (k == top) { done = true; break; }
+      j = (j - 1) / kFan;
+      ++k;
+    }
+    if (done) break;
+  }
+  emit<K>(bk, a.inv, a.gate_sq, a.out_i, a.out_d, (size_t)(a.q_begin + q) * K);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -520,6 +636,18 @@ hipError_t launch_nn_merge(int K, const MergeArgs& m, hipStream_t st) {
     case 1: hipLaunchKernelGGL((nn_merge_kernel<1>), grid, dim3(256), 0, st, m); break;
     case 4: hipLaunchKernelGGL((nn_merge_kernel<4>), grid, dim3(256), 0, st, m); break;
     case 20: hipLaunchKernelGGL((nn_merge_kernel<20>), grid, dim3(256), 0, st, m); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_bvh_knn(int K, const KnnArgs& a, hipStream_t st) {
+  if (a.q_count <= 0) return hipSuccess;
+  dim3 grid((a.q_count + 63) / 64);
+  switch (K) {
+    case 1: hipLaunchKernelGGL((bvh_knn_kernel<1>), grid, dim3(64), 0, st, a); break;
+    case 4: hipLaunchKernelGGL((bvh_knn_kernel<4>), grid, dim3(64), 0, st, a); break;
+    case 20: hipLaunchKernelGGL((bvh_knn_kernel<20>), grid, dim3(64), 0, st, a); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

@@ -53,13 +53,23 @@ struct Cloud {
   bool is_set = false, has_label = false;
   std::vector<float> hx, hy, hz;  // caller order
   std::vector<uint32_t> hl;
-  // device layout: caller order (GICP / EM) or grouped by label in first-seen order (SEMANTIC)
+  // device layout: one segment (GICP / EM) or one segment per label in first-seen order
+  // (SEMANTIC); inside a segment the points are in Morton order
   int layout = -1;        // -1 none, 0 flat, 1 grouped
-  std::vector<int> perm;  // device index -> caller index; empty = identity
+  std::vector<int> perm;  // device index -> caller index
   std::vector<uint32_t> seg_label;
   std::vector<int> seg_off;  // n_seg + 1
   DevBuf<float> x, y, z;
   DevBuf<uint32_t> label;
+  // search structure (bvh.hpp): packed points (x, y, z, caller index), boxes, seed tables
+  struct SegTree {
+    sicp::TreeLevels lv;
+    int n, pt_begin, node_begin, lut_begin;
+    float lo[3], scale;
+  };
+  std::vector<SegTree> trees;
+  DevBuf<float4> pts4, box_lo, box_hi;
+  DevBuf<int> lut, inv;  // inv: caller index -> device index
   DevBuf<double> nx, ny, nz;
   DevBuf<uint8_t> hist;
   DevBuf<int> nn;
@@ -67,7 +77,7 @@ struct Cloud {
   int feat_k = 0, feat_C = 0, feat_float_products = 0;
   bool feat_hist = false;
   int n_seg() const { return (int)seg_label.size(); }
-  int caller_index(int d) const { return perm.empty() ? d : perm[d]; }
+  int caller_index(int d) const { return perm[d]; }
 };
 
 double now_ms() {
@@ -93,8 +103,7 @@ struct sicp_context {
   DevBuf<double> w;
   int corr_n = 0, corr_K = 0;
   bool corr_valid = false, corr_weighted = false;
-  DevBuf<float> part_d;
-  DevBuf<int> part_i;
+  DevBuf<unsigned long long> part;
   DevBuf<double> partials, out28;
   DevBuf<long long> d_count;
   double* h_out28 = nullptr;      // pinned, 28 doubles
@@ -152,49 +161,88 @@ int prepare_cloud(sicp_context* h, Cloud& c) {
   if (want == 1 && !c.has_label) return SICP_ERR_NOT_READY;
   if (c.layout == want) return SICP_OK;
   const int n = c.n;
-  c.perm.clear();
   c.seg_label.clear();
   c.seg_off.clear();
-  std::vector<float> gx, gy, gz;
-  std::vector<uint32_t> gl;
-  const float *px = c.hx.data(), *py = c.hy.data(), *pz = c.hz.data();
-  const uint32_t* pl = c.has_label ? c.hl.data() : nullptr;
+  std::vector<std::vector<int>> seg_ids;
   if (want == 0) {
     c.seg_label.push_back(0);
-    c.seg_off = {0, n};
+    seg_ids.emplace_back(n);
+    for (int i = 0; i < n; ++i) seg_ids[0][i] = i;
   } else {
-    // pcl_2_semantic.h:24-39: one sub-cloud per label, labels in order of first appearance,
-    // points in cloud order inside each label
-    std::vector<int> which(n), cnt;
+    // pcl_2_semantic.h:24-39: one sub-cloud per label, labels in order of first appearance
     for (int i = 0; i < n; ++i) {
-      int s = -1;
+      int sidx = -1;
       for (size_t k = 0; k < c.seg_label.size(); ++k)
-        if (c.seg_label[k] == c.hl[i]) { s = (int)k; break; }
-      if (s < 0) { s = (int)c.seg_label.size(); c.seg_label.push_back(c.hl[i]); cnt.push_back(0); }
-      which[i] = s;
-      cnt[s]++;
+        if (c.seg_label[k] == c.hl[i]) { sidx = (int)k; break; }
+      if (sidx < 0) { sidx = (int)c.seg_label.size(); c.seg_label.push_back(c.hl[i]); seg_ids.emplace_back(); }
+      seg_ids[sidx].push_back(i);
     }
-    c.seg_off.assign(c.seg_label.size() + 1, 0);
-    for (size_t k = 0; k < c.seg_label.size(); ++k) c.seg_off[k + 1] = c.seg_off[k] + cnt[k];
-    std::vector<int> fill(c.seg_off.begin(), c.seg_off.end() - 1);
-    c.perm.resize(n);
-    for (int i = 0; i < n; ++i) c.perm[fill[which[i]]++] = i;
-    gx.resize(n); gy.resize(n); gz.resize(n); gl.resize(n);
-    for (int d = 0; d < n; ++d) {
-      const int i = c.perm[d];
-      gx[d] = c.hx[i]; gy[d] = c.hy[i]; gz[d] = c.hz[i]; gl[d] = c.hl[i];
+  }
+  // Morton order + box tree per segment (the role of setInputCloud's kd-tree build, em_icp.h:50-66)
+  const int n_seg = (int)seg_ids.size();
+  c.seg_off.assign(n_seg + 1, 0);
+  c.trees.assign(n_seg, Cloud::SegTree());
+  c.perm.resize(n);
+  std::vector<float4> pts4, blo, bhi;
+  std::vector<int> lut;
+  const float inf = std::numeric_limits<float>::infinity();
+  float4 pad;
+  pad.x = pad.y = pad.z = inf;
+  { const unsigned m1 = 0xffffffffu; std::memcpy(&pad.w, &m1, 4); }
+  for (int sg = 0; sg < n_seg; ++sg) {
+    sicp::HostTree t;
+    sicp::build_segment_tree(c.hx.data(), c.hy.data(), c.hz.data(), seg_ids[sg], t);
+    const int cnt = (int)seg_ids[sg].size(), o = c.seg_off[sg];
+    c.seg_off[sg + 1] = o + cnt;
+    Cloud::SegTree& st = c.trees[sg];
+    st.lv = t.lv; st.n = cnt;
+    st.pt_begin = (int)pts4.size(); st.node_begin = (int)blo.size(); st.lut_begin = (int)lut.size();
+    st.lo[0] = t.lo[0]; st.lo[1] = t.lo[1]; st.lo[2] = t.lo[2]; st.scale = t.scale;
+    for (int e = 0; e < cnt; ++e) {
+      const int i = seg_ids[sg][e];
+      c.perm[o + e] = i;
+      float4 v;
+      v.x = c.hx[i]; v.y = c.hy[i]; v.z = c.hz[i];
+      const unsigned ui = (unsigned)i;
+      std::memcpy(&v.w, &ui, 4);
+      pts4.push_back(v);
     }
-    px = gx.data(); py = gy.data(); pz = gz.data(); pl = gl.data();
+    const int padded = std::max(1, (cnt + sicp::kLeaf - 1) / sicp::kLeaf) * sicp::kLeaf;
+    for (int e = cnt; e < padded; ++e) pts4.push_back(pad);
+    for (int k = 0; k < t.total_nodes(); ++k) {
+      float4 l, u;
+      l.x = t.box_lo[4 * k]; l.y = t.box_lo[4 * k + 1]; l.z = t.box_lo[4 * k + 2]; l.w = 0;
+      u.x = t.box_hi[4 * k]; u.y = t.box_hi[4 * k + 1]; u.z = t.box_hi[4 * k + 2]; u.w = 0;
+      blo.push_back(l); bhi.push_back(u);
+    }
+    lut.insert(lut.end(), t.lut.begin(), t.lut.end());
+  }
+  std::vector<float> gx(n), gy(n), gz(n);
+  std::vector<uint32_t> gl(c.has_label ? n : 0);
+  std::vector<int> inv(n);
+  for (int d = 0; d < n; ++d) {
+    const int i = c.perm[d];
+    gx[d] = c.hx[i]; gy[d] = c.hy[i]; gz[d] = c.hz[i];
+    if (c.has_label) gl[d] = c.hl[i];
+    inv[i] = d;
   }
   const size_t m = (size_t)(n > 0 ? n : 1);
   HIPCHECK(c.x.reserve(m)); HIPCHECK(c.y.reserve(m)); HIPCHECK(c.z.reserve(m));
-  HIPCHECK(c.label.reserve(m));
-  if (n > 0) {
-    HIPCHECK(hipMemcpyAsync(c.x.p, px, sizeof(float) * n, hipMemcpyHostToDevice, h->stream));
-    HIPCHECK(hipMemcpyAsync(c.y.p, py, sizeof(float) * n, hipMemcpyHostToDevice, h->stream));
-    HIPCHECK(hipMemcpyAsync(c.z.p, pz, sizeof(float) * n, hipMemcpyHostToDevice, h->stream));
-    if (pl) HIPCHECK(hipMemcpyAsync(c.label.p, pl, sizeof(uint32_t) * n, hipMemcpyHostToDevice, h->stream));
-  }
+  HIPCHECK(c.label.reserve(m)); HIPCHECK(c.inv.reserve(m));
+  HIPCHECK(c.pts4.reserve(pts4.size() + 1)); HIPCHECK(c.box_lo.reserve(blo.size() + 1));
+  HIPCHECK(c.box_hi.reserve(bhi.size() + 1)); HIPCHECK(c.lut.reserve(lut.size() + 1));
+  auto up = [&](void* dst, const void* src, size_t bytes) {
+    return bytes ? hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream) : hipSuccess;
+  };
+  HIPCHECK(up(c.x.p, gx.data(), sizeof(float) * n));
+  HIPCHECK(up(c.y.p, gy.data(), sizeof(float) * n));
+  HIPCHECK(up(c.z.p, gz.data(), sizeof(float) * n));
+  if (c.has_label) HIPCHECK(up(c.label.p, gl.data(), sizeof(uint32_t) * n));
+  HIPCHECK(up(c.inv.p, inv.data(), sizeof(int) * n));
+  HIPCHECK(up(c.pts4.p, pts4.data(), sizeof(float4) * pts4.size()));
+  HIPCHECK(up(c.box_lo.p, blo.data(), sizeof(float4) * blo.size()));
+  HIPCHECK(up(c.box_hi.p, bhi.data(), sizeof(float4) * bhi.size()));
+  HIPCHECK(up(c.lut.p, lut.data(), sizeof(int) * lut.size()));
   HIPCHECK(hipStreamSynchronize(h->stream));  // staging vectors go out of scope
   c.layout = want;
   c.feat_valid = false;
@@ -203,10 +251,36 @@ int prepare_cloud(sicp_context* h, Cloud& c) {
 }
 
 // ---- brute-force kNN driver -------------------------------------------------------------------
-int run_nn(sicp_context* h, int K, const float* qx, const float* qy, const float* qz, int q_begin,
-           int q_count, const double* M34, const float* tx, const float* ty, const float* tz,
-           int t_begin, int t_count, float gate_sq, int* out_i, float* out_d, int timer_bit) {
+// queries: points [q_begin, q_begin+q_count) of cloud Q (device order), optionally transformed
+// by M34; targets: segment `tseg` of cloud T.  Writes device indices of T (or -1) and distances.
+int run_nn(sicp_context* h, int K, const Cloud& Qc, int q_begin, int q_count, const double* M34, const Cloud& Tc,
+           int tseg, bool self, float gate_sq, int* out_i, float* out_d, int timer_bit) {
   if (q_count <= 0) return SICP_OK;
+  const Cloud::SegTree& tr = Tc.trees[tseg];
+  auto account = [&](double ms) {
+    if (timer_bit == SICP_PROFILE_NN) { h->st.nn_kernel_ms += ms; h->st.nn_launches += 1; }
+    else { h->st.cov_kernel_ms += ms; h->st.cov_launches += 1; }
+  };
+  if (h->params.nn_method == 1) {
+    sicp::KnnArgs a;
+    a.qx = Qc.x.p; a.qy = Qc.y.p; a.qz = Qc.z.p;
+    a.q_begin = q_begin; a.q_count = q_count;
+    a.do_xform = M34 ? 1 : 0;
+    for (int i = 0; i < 12; ++i) a.M[i] = M34 ? M34[i] : 0.0;
+    a.tree.pts4 = Tc.pts4.p; a.tree.box_lo = Tc.box_lo.p; a.tree.box_hi = Tc.box_hi.p; a.tree.lut = Tc.lut.p;
+    a.tree.lv = tr.lv; a.tree.n = tr.n; a.tree.pt_begin = tr.pt_begin; a.tree.node_begin = tr.node_begin;
+    a.tree.lut_begin = tr.lut_begin;
+    a.tree.lo[0] = tr.lo[0]; a.tree.lo[1] = tr.lo[1]; a.tree.lo[2] = tr.lo[2]; a.tree.scale = tr.scale;
+    a.self = self ? 1 : 0;
+    a.gate_sq = gate_sq;
+    a.inv = Tc.inv.p;
+    a.out_i = out_i; a.out_d = out_d;
+    KernelTimer kt(h, timer_bit);
+    HIPCHECK(sicp::launch_bvh_knn(K, a, h->stream));
+    account(kt.stop());
+    return SICP_OK;
+  }
+  const int t_count = tr.n;
   const int Q = sicp::nn_queries_per_thread(K);
   const int qblocks = (q_count + 256 * Q - 1) / (256 * Q);
   // >= ~8 workgroups per CU so the search fills the chip, but never chunks below one LDS tile
@@ -219,28 +293,26 @@ int run_nn(sicp_context* h, int K, const float* qx, const float* qy, const float
   if (chunk_len < 1024) chunk_len = 1024;
   chunks = t_count > 0 ? (t_count + chunk_len - 1) / chunk_len : 1;
   const size_t need = (size_t)chunks * q_count * K;
-  HIPCHECK(h->part_d.reserve(need));
-  HIPCHECK(h->part_i.reserve(need));
+  HIPCHECK(h->part.reserve(need));
   sicp::NNArgs a;
-  a.qx = qx; a.qy = qy; a.qz = qz;
+  a.qx = Qc.x.p; a.qy = Qc.y.p; a.qz = Qc.z.p;
   a.q_begin = q_begin; a.q_count = q_count;
   a.do_xform = M34 ? 1 : 0;
   for (int i = 0; i < 12; ++i) a.M[i] = M34 ? M34[i] : 0.0;
-  a.tx = tx; a.ty = ty; a.tz = tz;
-  a.t_begin = t_begin; a.t_count = t_count;
+  a.pts4 = Tc.pts4.p;
+  a.t_begin = tr.pt_begin; a.t_count = t_count;
   a.chunk_len = chunk_len;
-  a.part_d = h->part_d.p; a.part_i = h->part_i.p;
+  a.part = h->part.p;
   sicp::MergeArgs m;
-  m.q_begin = q_begin; m.q_count = q_count; m.n_chunks = chunks; m.t_begin = t_begin;
-  m.part_d = h->part_d.p; m.part_i = h->part_i.p;
+  m.q_begin = q_begin; m.q_count = q_count; m.n_chunks = chunks;
+  m.part = h->part.p;
+  m.inv = Tc.inv.p;
   m.gate_sq = gate_sq;
   m.out_i = out_i; m.out_d = out_d;
   {
     KernelTimer kt(h, timer_bit);
     HIPCHECK(sicp::launch_nn_partial(K, a, chunks, h->stream));
-    const double ms = kt.stop();
-    if (timer_bit == SICP_PROFILE_NN) { h->st.nn_kernel_ms += ms; h->st.nn_launches += 1; }
-    else { h->st.cov_kernel_ms += ms; h->st.cov_launches += 1; }
+    account(kt.stop());
   }
   HIPCHECK(sicp::launch_nn_merge(K, m, h->stream));
   return SICP_OK;
@@ -269,8 +341,8 @@ int compute_features(sicp_context* h, Cloud& c, bool with_hist) {
   if (with_hist) HIPCHECK(c.hist.reserve(m * P.num_classes));
   for (int s = 0; s < c.n_seg(); ++s) {
     const int o = c.seg_off[s], cnt = c.seg_off[s + 1] - o;
-    SICPCHECK(run_nn(h, k, c.x.p, c.y.p, c.z.p, o, cnt, nullptr, c.x.p, c.y.p, c.z.p, o, cnt,
-                     std::numeric_limits<float>::infinity(), c.nn.p, nullptr, SICP_PROFILE_COV));
+    SICPCHECK(run_nn(h, k, c, o, cnt, nullptr, c, s, true, std::numeric_limits<float>::infinity(), c.nn.p, nullptr,
+                     SICP_PROFILE_COV));
   }
   sicp::CovArgs a;
   a.n = n; a.k = k; a.C = with_hist ? P.num_classes : 0;
@@ -344,9 +416,7 @@ int run_correspondences(sicp_context* h, const double* qt, int K, bool weights) 
         if (ts < 0) continue;                    // semantic_icp.hpp:50
         if (!(sn > P.min_class_pts)) continue;   // semantic_icp.hpp:51
       }
-      const int to = T.seg_off[ts], tn = T.seg_off[ts + 1] - to;
-      SICPCHECK(run_nn(h, K, S.x.p, S.y.p, S.z.p, so, sn, M, T.x.p, T.y.p, T.z.p, to, tn,
-                       (float)P.gate_sq, h->idx.p, h->d2.p, SICP_PROFILE_NN));
+      SICPCHECK(run_nn(h, K, S, so, sn, M, T, ts, false, (float)P.gate_sq, h->idx.p, h->d2.p, SICP_PROFILE_NN));
       h->st.total_corr += (int64_t)sn * K;
     }
     h->st.t_nn_ms += now_ms() - t0;
@@ -549,7 +619,7 @@ int sicp_set_params(sicp_handle h, const sicp_params* p) {
   if (!h || !p) return SICP_ERR_INVALID_ARGUMENT;
   if (p->mode < SICP_MODE_GICP || p->mode > SICP_MODE_SEMANTIC) return SICP_ERR_INVALID_ARGUMENT;
   if (!sicp::nn_k_supported(p->knn) || !sicp::nn_k_supported(p->k_cov)) return SICP_ERR_INVALID_ARGUMENT;
-  if (!(p->epsilon > 0) || !(p->cauchy_a > 0) || p->nn_method != 0) return SICP_ERR_INVALID_ARGUMENT;
+  if (!(p->epsilon > 0) || !(p->cauchy_a > 0) || p->nn_method < 0 || p->nn_method > 1) return SICP_ERR_INVALID_ARGUMENT;
   h->params = *p;
   h->corr_valid = false;
   return SICP_OK;

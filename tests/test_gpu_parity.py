@@ -57,6 +57,12 @@ def oracle_params(mode, C=0, **kw):
     return p
 
 
+@pytest.fixture(params=[0, 1], ids=["bruteforce", "boxtree"])
+def nn(request):
+    """Both exact kNN engines (sicp_params.nn_method) must give bit-identical results."""
+    return request.param
+
+
 @pytest.fixture(scope="module")
 def pair1():
     return synth.config1_pair(seed=1, n_per_label=700)
@@ -71,9 +77,9 @@ def lidar20k():
 # correspondence search: bit-exact
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("mode,K", [(sicp.MODE_GICP, 1), (sicp.MODE_EM, 4)])
-def test_knn_bit_exact_vs_oracle(lidar20k, mode, K):
+def test_knn_bit_exact_vs_oracle(lidar20k, mode, K, nn):
     src, sl, tgt, tl, T_gt, cm = lidar20k
-    e, p = make_engine(mode, 11, cm, gate_sq=1e30)
+    e, p = make_engine(mode, 11, cm, gate_sq=1e30, nn_method=nn)
     e.set_source(src, sl)
     e.set_target(tgt, tl)
     qt = mat_to_qt(synth.pose_matrix(1.3, (0.1, 0.2, 1.0), (0.4, -0.2, 0.05)))
@@ -85,10 +91,10 @@ def test_knn_bit_exact_vs_oracle(lidar20k, mode, K):
     assert (np.diff(d2, axis=1) >= 0).all()  # ascending, like FLANN's result set
 
 
-def test_knn_ties_ragged_sizes_and_gate():
+def test_knn_ties_ragged_sizes_and_gate(nn):
     g = np.load(os.path.join(G, "knn.npz"))
     q, t = g["q"], g["t"]  # contains exact duplicate targets: lowest index must win
-    e, p = make_engine(sicp.MODE_EM, 3, synth.confusion_matrix(3), gate_sq=4.0)
+    e, p = make_engine(sicp.MODE_EM, 3, synth.confusion_matrix(3), gate_sq=4.0, nn_method=nn)
     lab_q = np.ones(len(q), dtype=np.uint32)
     lab_t = np.ones(len(t), dtype=np.uint32)
     e.set_source(q, lab_q)
@@ -98,7 +104,7 @@ def test_knn_ties_ragged_sizes_and_gate():
     want_i[~(want_d < np.float32(4.0))] = -1  # strict <
     assert np.array_equal(idx, want_i) and np.array_equal(d2, want_d)
     # GICP K=1, targets fewer than one LDS tile, queries not a multiple of the block
-    e2, _ = make_engine(sicp.MODE_GICP)
+    e2, _ = make_engine(sicp.MODE_GICP, nn_method=nn)
     e2.set_source(q[:257])
     e2.set_target(t[:37])
     idx, d2, _ = e2.correspondences(IDENT)
@@ -130,12 +136,12 @@ def test_too_few_targets_and_bad_labels_are_errors():
 # ------------------------------------------------------------------------------------------------
 # covariances / normals / histograms
 # ------------------------------------------------------------------------------------------------
-def test_covariances_vs_oracle_and_golden(lidar20k):
+def test_covariances_vs_oracle_and_golden(lidar20k, nn):
     g = np.load(os.path.join(G, "cov.npz"))
-    e, p = make_engine(sicp.MODE_EM, int(g["C"]), synth.confusion_matrix(int(g["C"])))
+    e, p = make_engine(sicp.MODE_EM, int(g["C"]), synth.confusion_matrix(int(g["C"])), nn_method=nn)
     e.set_source(g["p"], g["labels"])
-    cov, nrm, hist, nn = e.covariances(sicp.SOURCE, want_hist=True, want_nn=True)
-    assert np.array_equal(nn, g["nn"])                       # k = 20 self-kNN: bit exact
+    cov, nrm, hist, nbr = e.covariances(sicp.SOURCE, want_hist=True, want_nn=True)
+    assert np.array_equal(nbr, g["nn"])                       # k = 20 self-kNN: bit exact
     assert np.array_equal(hist.astype(np.float64) / 20.0, g["hist"]) or np.allclose(hist / 20.0, g["hist"], atol=1e-15)
     assert np.array_equal(hist, np.rint(g["hist"] * 20).astype(np.uint8))
     ok = g["gaps"] > 1e-6
@@ -144,12 +150,12 @@ def test_covariances_vs_oracle_and_golden(lidar20k):
     assert np.allclose(cov[ok], g["cov"][ok], atol=1e-9, rtol=0)
     # bigger, LiDAR-like cloud against the oracle (float-product quirk matters at 40 m range)
     src, sl, *_ = lidar20k
-    e2, _ = make_engine(sicp.MODE_EM, 11, synth.confusion_matrix(11))
+    e2, _ = make_engine(sicp.MODE_EM, 11, synth.confusion_matrix(11), nn_method=nn)
     e2.set_source(src, sl)
-    cov, nrm, hist, nn = e2.covariances(sicp.SOURCE, want_hist=True, want_nn=True)
+    cov, nrm, hist, nbr = e2.covariances(sicp.SOURCE, want_hist=True, want_nn=True)
     ocov, onrm, ohist = O.covariances(src, sl, 20, 1e-3, 11, kdtree=True)
     onn, _ = O.knn(src, src, 20, kdtree=True)
-    assert np.array_equal(nn, onn)
+    assert np.array_equal(nbr, onn)
     assert np.array_equal(hist, np.rint(ohist * 20).astype(np.uint8))
     # normals agree wherever the PCA direction is well conditioned
     dots = np.abs(np.einsum("ni,ni->n", nrm, onrm))
@@ -157,15 +163,15 @@ def test_covariances_vs_oracle_and_golden(lidar20k):
     assert np.median(np.abs(cov - ocov).reshape(len(src), -1).max(axis=1)) < 1e-12
 
 
-def test_small_class_divides_by_k_quirk():
+def test_small_class_divides_by_k_quirk(nn):
     # quirk Q3: fewer than k points -> still divided by k (em_icp.hpp:317,320)
     rng = np.random.default_rng(3)
     pts = rng.normal(size=(12, 3)).astype(np.float32)
-    e, _ = make_engine(sicp.MODE_GICP)
+    e, _ = make_engine(sicp.MODE_GICP, nn_method=nn)
     e.set_source(pts)
-    cov, nrm, _, nn = e.covariances(sicp.SOURCE, want_nn=True)
+    cov, nrm, _, nbr = e.covariances(sicp.SOURCE, want_nn=True)
     ocov, onrm, _ = O.covariances(pts, None, 20, 1e-3)
-    assert (nn[:, 12:] == -1).all() and (np.sort(nn[:, :12], axis=1) == np.arange(12)).all()
+    assert (nbr[:, 12:] == -1).all() and (np.sort(nbr[:, :12], axis=1) == np.arange(12)).all()
     assert (1 - np.abs(np.einsum("ni,ni->n", nrm, onrm))).max() < 1e-10
 
 
@@ -173,11 +179,11 @@ def test_small_class_divides_by_k_quirk():
 # weights + accumulation
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("mode", [sicp.MODE_GICP, sicp.MODE_EM, sicp.MODE_SEMANTIC])
-def test_weights_and_accumulate_vs_oracle(pair1, mode):
+def test_weights_and_accumulate_vs_oracle(pair1, mode, nn):
     src, sl, tgt, tl, T_gt = pair1
     C = 4
     cm = synth.confusion_matrix(C)
-    e, p = make_engine(mode, C, cm)
+    e, p = make_engine(mode, C, cm, nn_method=nn)
     e.set_source(src, sl)
     e.set_target(tgt, tl)
     qt = mat_to_qt(synth.pose_matrix(1.0, (0, 1, 0), (0.05, 0.0, -0.02)))
@@ -233,10 +239,10 @@ def test_weights_and_accumulate_vs_oracle(pair1, mode):
 # full align(): the three reference classes
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("mode,key", [(sicp.MODE_GICP, "gicp"), (sicp.MODE_EM, "em"), (sicp.MODE_SEMANTIC, "sem")])
-def test_align_vs_oracle_and_golden(mode, key):
+def test_align_vs_oracle_and_golden(mode, key, nn):
     g = np.load(os.path.join(G, "align.npz"))
     C = 4
-    e, p = make_engine(mode, C, g["cm"])
+    e, p = make_engine(mode, C, g["cm"], nn_method=nn)
     e.set_source(g["src"], g["sl"])
     e.set_target(g["tgt"], g["tl"])
     qt, st = e.align(IDENT)
@@ -269,7 +275,7 @@ def test_align_config1_all_modes(pair1):
         assert rot < 3e-3 and tr < 2e-2
 
 
-def test_semantic_skips_small_and_missing_classes():
+def test_semantic_skips_small_and_missing_classes(nn):
     src, sl, tgt, tl, T_gt = synth.config1_pair(seed=5, n_per_label=450)
     # class 7: only in the source; class 9: in both but <= 400 source points
     rng = np.random.default_rng(1)
@@ -277,7 +283,7 @@ def test_semantic_skips_small_and_missing_classes():
     small = rng.uniform(0, 5, (300, 3)).astype(np.float32)
     src2 = np.concatenate([src, extra_s, small]); sl2 = np.concatenate([sl, np.full(500, 7), np.full(300, 9)]).astype(np.uint32)
     tgt2 = np.concatenate([tgt, small + 0.5]); tl2 = np.concatenate([tl, np.full(300, 9)]).astype(np.uint32)
-    e, p = make_engine(sicp.MODE_SEMANTIC)
+    e, p = make_engine(sicp.MODE_SEMANTIC, nn_method=nn)
     e.set_source(src2, sl2)
     e.set_target(tgt2, tl2)
     idx, d2, w = e.correspondences(IDENT)
@@ -288,9 +294,9 @@ def test_semantic_skips_small_and_missing_classes():
     assert rot < 1e-7 and tr < 1e-7 and st["outer_iters"] == ost["outer_iters"]
 
 
-def test_em_lidar20k_vs_oracle_and_fused_labels(lidar20k):
+def test_em_lidar20k_vs_oracle_and_fused_labels(lidar20k, nn):
     src, sl, tgt, tl, T_gt, cm = lidar20k
-    e, p = make_engine(sicp.MODE_EM, 11, cm)
+    e, p = make_engine(sicp.MODE_EM, 11, cm, nn_method=nn)
     e.set_source(src, sl)
     e.set_target(tgt, tl)
     qt, st = e.align()
@@ -328,9 +334,9 @@ def lidar100k():
     return synth.lidar_pair(seed=2, n_points=100_000)
 
 
-def test_metric_size_properties(lidar100k):
+def test_metric_size_properties(lidar100k, nn):
     src, sl, tgt, tl, T_gt, cm = lidar100k
-    e, p = make_engine(sicp.MODE_EM, 11, cm)
+    e, p = make_engine(sicp.MODE_EM, 11, cm, nn_method=nn)
     e.set_source(src, sl)
     e.set_target(tgt, tl)
     # kNN: sorted, gated, self-consistent distances; spot-check rows against the oracle kd-tree
