@@ -1,7 +1,7 @@
 // bvh.hpp -- host-side build of the exact-search structure the kNN kernels traverse.
 //
 // The reference searches with pcl::KdTreeFLANN (built in setSourceCloud / setTargetCloud,
-// em_icp.h:50-66); here every cloud segment is stored in Morton order and covered by an implicit
+// em_icp.h:50-66); here every cloud segment is stored in Hilbert-curve order and covered by an implicit
 // 4-ary tree of axis-aligned boxes over leaves of LEAF consecutive points:
 //   level 0 : leaf j covers points [j*LEAF, (j+1)*LEAF) of the segment
 //   level k : node j covers nodes [4j, 4j+4) of level k-1
@@ -22,7 +22,6 @@ namespace sicp {
 constexpr int kLeaf = 16;        // points per leaf
 constexpr int kFan = 4;          // children per node
 constexpr int kMaxLevels = 14;   // 16 * 4^13 points
-constexpr int kLutBits = 15;     // seed look-up table: top 5 bits per axis of the Morton code
 
 struct TreeLevels {
   int n_levels;            // >= 1
@@ -35,35 +34,58 @@ struct HostTree {
   TreeLevels lv;
   std::vector<float> box_lo;       // 4 floats per node (x y z pad), all levels
   std::vector<float> box_hi;
-  std::vector<int> lut;            // 1 << kLutBits leaf indices
+  std::vector<uint64_t> leaf_code; // curve index of the first point of every leaf (seed search)
   float lo[3] = {0, 0, 0};
   float scale = 0;                 // quantisation: cell = (p - lo) * scale, 21 bits per axis
   int total_nodes() const { return (int)(box_lo.size() / 4); }
 };
 
-inline uint64_t expand21(uint32_t v) {
-  uint64_t x = v & 0x1fffffu;
-  x = (x | x << 32) & 0x1f00000000ffffull;
-  x = (x | x << 16) & 0x1f0000ff0000ffull;
-  x = (x | x << 8) & 0x100f00f00f00f00full;
-  x = (x | x << 4) & 0x10c30c30c30c30c3ull;
-  x = (x | x << 2) & 0x1249249249249249ull;
-  return x;
+// 63-bit 3-D Hilbert index of the 21-bit cell coordinates (Skilling, "Programming the Hilbert
+// curve", 2004: axes -> transposed index, then bit interleave).  Unlike Morton order, cells that
+// are consecutive on the curve are always face neighbours, so LEAF consecutive points (and the
+// 64-point seed group) are always spatially compact.  SICP_HD is empty on the host and
+// __host__ __device__ when kernels.hip includes this header, so both sides share one definition.
+#ifndef SICP_HD
+#define SICP_HD
+#endif
+SICP_HD inline uint64_t hilbert63_cells(uint32_t cx, uint32_t cy, uint32_t cz) {
+  uint32_t X[3] = {cx, cy, cz};
+  const uint32_t M = 1u << 20;
+  for (uint32_t Q = M; Q > 1; Q >>= 1) {
+    const uint32_t P = Q - 1;
+    for (int i = 0; i < 3; ++i) {
+      if (X[i] & Q) {
+        X[0] ^= P;
+      } else {
+        const uint32_t t = (X[0] ^ X[i]) & P;
+        X[0] ^= t;
+        X[i] ^= t;
+      }
+    }
+  }
+  X[1] ^= X[0];
+  X[2] ^= X[1];
+  uint32_t t = 0;
+  for (uint32_t Q = M; Q > 1; Q >>= 1)
+    if (X[2] & Q) t ^= Q - 1;
+  X[0] ^= t; X[1] ^= t; X[2] ^= t;
+  // interleave: X[0] holds the most significant bit of every 3-bit digit
+  uint64_t h = 0;
+  for (int b = 20; b >= 0; --b)
+    h = (h << 3) | (uint64_t)((((X[0] >> b) & 1u) << 2) | (((X[1] >> b) & 1u) << 1) | ((X[2] >> b) & 1u));
+  return h;
 }
 
-inline uint32_t quant21(float p, float lo, float scale) {
-  float v = (p - lo) * scale;
-  if (!(v > 0.f)) return 0;
-  if (v >= 2097151.f) return 2097151u;
-  return (uint32_t)v;
+SICP_HD inline uint32_t quant21_cell(float p, float lo, float scale) {
+  const float v = (p - lo) * scale;
+  return !(v > 0.f) ? 0u : (v >= 2097151.f ? 2097151u : (uint32_t)v);
 }
 
-inline uint64_t morton63(float x, float y, float z, const float lo[3], float scale) {
-  return expand21(quant21(x, lo[0], scale)) | (expand21(quant21(y, lo[1], scale)) << 1) |
-         (expand21(quant21(z, lo[2], scale)) << 2);
+SICP_HD inline uint64_t curve_code(float x, float y, float z, float lox, float loy, float loz, float scale) {
+  return hilbert63_cells(quant21_cell(x, lox, scale), quant21_cell(y, loy, scale), quant21_cell(z, loz, scale));
 }
 
-// Orders the points of one segment (indices `ids`, caller order) by (Morton code, caller index)
+// Orders the points of one segment (indices `ids`, caller order) by (curve index, caller index)
 // and builds the boxes.  On return `ids` is the device order of the segment.
 inline void build_segment_tree(const float* x, const float* y, const float* z, std::vector<int>& ids, HostTree& t) {
   const int n = (int)ids.size();
@@ -84,7 +106,7 @@ inline void build_segment_tree(const float* x, const float* y, const float* z, s
   std::vector<std::pair<uint64_t, int>> keyed(n);
   for (int e = 0; e < n; ++e) {
     const int i = ids[e];
-    keyed[e] = {morton63(x[i], y[i], z[i], t.lo, t.scale), i};
+    keyed[e] = {curve_code(x[i], y[i], z[i], t.lo[0], t.lo[1], t.lo[2], t.scale), i};
   }
   std::sort(keyed.begin(), keyed.end());
   for (int e = 0; e < n; ++e) ids[e] = keyed[e].second;
@@ -122,15 +144,10 @@ inline void build_segment_tree(const float* x, const float* y, const float* z, s
       const size_t o = 4 * (size_t)(lv.off[k] + j);
       for (int d = 0; d < 3; ++d) { t.box_lo[o + d] = bl[d]; t.box_hi[o + d] = bh[d]; }
     }
-  // seed table: Morton prefix -> a leaf near that prefix (any leaf is a valid seed; a near one
-  // gives a tight first bound)
-  const int nl = 1 << kLutBits, shift = 63 - kLutBits;
-  t.lut.assign(nl, 0);
-  int e = 0;
-  for (int p = 0; p < nl; ++p) {
-    while (e < n && (int)(keyed[e].first >> shift) < p) ++e;
-    t.lut[p] = std::min(std::max(0, n - 1), e) / kLeaf;
-  }
+  // seed search: a query's Morton code is located among these by binary search; the leaf found
+  // is spatially adjacent to the query, which gives a tight first bound
+  t.leaf_code.assign(lv.cnt[0], 0);
+  for (int j = 0; j < lv.cnt[0]; ++j) t.leaf_code[j] = j * kLeaf < n ? keyed[(size_t)j * kLeaf].first : ~0ull;
 }
 
 }  // namespace sicp

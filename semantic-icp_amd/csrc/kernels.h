@@ -50,12 +50,12 @@ struct TreeArgs {
   const float4* pts4;     // packed points of the whole cloud, every segment padded to kLeaf
   const float4* box_lo;   // boxes of all segments
   const float4* box_hi;
-  const int* lut;         // seed tables of all segments
+  const unsigned long long* leaf_code;  // first Morton code of every leaf, all segments
   TreeLevels lv;
   int n;                  // points in this segment
   int pt_begin;           // first packed point of the segment
   int node_begin;         // first box of the segment
-  int lut_begin;
+  int code_begin;
   float lo[3];
   float scale;
 };
@@ -71,6 +71,7 @@ struct KnnArgs {
   const int* inv;
   int* out_i;
   float* out_d;
+  int* dbg;        // nullable: [q_count][2] = (boxes tested, leaves scanned), debugging only
 };
 
 struct CovArgs {

@@ -10,16 +10,17 @@
 //                           Ceres' Corrector, summed to 28 doubles
 //                                                        gicp_cost_function.h:27-73
 //
-// Design notes (MI355X): clouds live in HBM in Morton order (SoA float32 + a packed float4
+// Design notes (MI355X): clouds live in HBM in Hilbert-curve order (SoA float32 + a packed float4
 // x,y,z,caller-index copy for the search kernels).  Two exact kNN engines produce identical
 // results: an LDS-tiled brute force (target tiles broadcast from LDS, 2-D grid of query blocks x
-// target chunks, deterministic merge) and a stackless walk of a 4-ary box tree over the Morton
+// target chunks, deterministic merge) and a stackless walk of a 4-ary box tree over the curve
 // order.  Top-K lists are 64-bit (distance, caller index) keys in statically indexed VGPRs.
 // No floating-point atomics anywhere, so every result is run-to-run reproducible.  Nothing here
 // is GEMM shaped: no MFMA.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#define SICP_HD __host__ __device__
 #include "kernels.h"
 
 namespace sicp {
@@ -59,7 +60,7 @@ __device__ __forceinline__ float l2_simple(float ax, float ay, float az, float b
 // bit pattern orders like the value and one unsigned compare is the lexicographic order
 // "smaller distance first, lower caller index on exact ties" (the tie rule this build defines;
 // FLANN leaves tie order unspecified) --
-// independent of the order in which candidates are visited (device order is Morton order).
+// independent of the order in which candidates are visited (device order is curve order).
 typedef unsigned long long u64;
 static constexpr u64 KEY_EMPTY = ~0ull;  // high word = NaN pattern: above every real distance
 
@@ -184,25 +185,11 @@ __global__ __launch_bounds__(256) void nn_merge_kernel(MergeArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// exact kNN through the Morton-ordered 4-ary box tree (bvh.hpp): one query per lane, seed leaf
+// exact kNN through the Hilbert-ordered 4-ary box tree (bvh.hpp): one query per lane, seed leaf
 // for a first bound, then a stackless fixed-order depth-first walk pruned by the float32 box
 // distance.  Result sets are order independent (keys), so the output equals brute force bit for
 // bit.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned spread5(unsigned v) {
-  v &= 31u;
-  v = (v | (v << 8)) & 0x100fu;
-  v = (v | (v << 4)) & 0x10c3u;
-  v = (v | (v << 2)) & 0x1249u;
-  return v;
-}
-
-__device__ __forceinline__ unsigned quant5(float p, float lo, float scale) {
-  const float v = (p - lo) * scale;
-  unsigned q = !(v > 0.f) ? 0u : (v >= 2097151.f ? 2097151u : (unsigned)v);
-  return q >> 16;
-}
-
 template <int K>
 __device__ __forceinline__ void scan_leaf(const float4* __restrict__ pts, float px, float py, float pz, u64 (&bk)[K], float& wd) {
   float4 t[kLeaf];
@@ -210,6 +197,34 @@ __device__ __forceinline__ void scan_leaf(const float4* __restrict__ pts, float 
   for (int p = 0; p < kLeaf; ++p) t[p] = pts[p];  // padded with (+inf, +inf, +inf, -1): no bounds test
 #pragma unroll
   for (int p = 0; p < kLeaf; ++p) consider<K>(bk, wd, l2_simple(px, py, pz, t[p].x, t[p].y, t[p].z), __float_as_uint(t[p].w));
+}
+
+__device__ __forceinline__ float box_lb(const float4 lo, const float4 hi, float px, float py, float pz) {
+  const float ex = fmaxf(fmaxf(lo.x - px, px - hi.x), 0.f);
+  const float ey = fmaxf(fmaxf(lo.y - py, py - hi.y), 0.f);
+  const float ez = fmaxf(fmaxf(lo.z - pz, pz - hi.z), 0.f);
+  return (ex * ex + ey * ey) + ez * ez;  // lower bound of l2_simple over the box (monotone rounding)
+}
+
+// 4-bit mask of the children of node (level, parent) whose box can still hold a neighbour
+__device__ __forceinline__ unsigned child_mask(const float4* __restrict__ blo, const float4* __restrict__ bhi, int child_off,
+                                               int child_cnt, int parent, float px, float py, float pz, float wd) {
+  const int c0 = parent * kFan;
+  unsigned m = 0;
+  float4 lo[kFan], hi[kFan];
+#pragma unroll
+  for (int c = 0; c < kFan; ++c) {  // 8 independent loads; indices clamped, validity applied below
+    const int node = child_off + min(c0 + c, child_cnt - 1);
+    lo[c] = blo[node];
+    hi[c] = bhi[node];
+  }
+#pragma unroll
+  for (int c = 0; c < kFan; ++c) {
+    const float lb = box_lb(lo[c], hi[c], px, py, pz);
+    // lb == wd may still hide an equal distance with a lower caller index: keep it
+    if (c0 + c < child_cnt && !(lb > wd)) m |= 1u << c;
+  }
+  return m;
 }
 
 template <int K>
@@ -228,48 +243,83 @@ __global__ __launch_bounds__(64) void bvh_knn_kernel(KnnArgs a) {
   const float4* __restrict__ pts = a.tree.pts4 + a.tree.pt_begin;
   const float4* __restrict__ blo = a.tree.box_lo + a.tree.node_begin;
   const float4* __restrict__ bhi = a.tree.box_hi + a.tree.node_begin;
-
-  int seed;
-  if (a.self) {
-    seed = q / kLeaf;
-  } else {
-    const unsigned prefix = spread5(quant5(px, a.tree.lo[0], a.tree.scale)) | (spread5(quant5(py, a.tree.lo[1], a.tree.scale)) << 1) |
-                            (spread5(quant5(pz, a.tree.lo[2], a.tree.scale)) << 2);
-    seed = a.tree.lut[a.tree.lut_begin + prefix];
-  }
-  scan_leaf<K>(pts + (size_t)seed * kLeaf, px, py, pz, bk, wd);
-
   const int top = a.tree.lv.n_levels - 1;
-  int k = top, j = 0;
-  for (;;) {
-    if (!(k == 0 && j == seed)) {
-      const int node = s_off[k] + j;
-      const float4 lo = blo[node], hi = bhi[node];
-      const float ex = fmaxf(fmaxf(lo.x - px, px - hi.x), 0.f);
-      const float ey = fmaxf(fmaxf(lo.y - py, py - hi.y), 0.f);
-      const float ez = fmaxf(fmaxf(lo.z - pz, pz - hi.z), 0.f);
-      const float lb = (ex * ex + ey * ey) + ez * ez;  // lower bound of l2_simple over the box (monotone rounding)
-      if (!(lb > wd)) {  // lb == wd may still hide an equal distance with a lower caller index
-        if (k == 0) {
-          scan_leaf<K>(pts + (size_t)j * kLeaf, px, py, pz, bk, wd);
-        } else {
-          --k;
-          j *= kFan;
+  const int n_leaf = s_cnt[0];
+  int dbg_nodes = 0, dbg_leaves = 0;
+
+  // --- seed: a level-1 node (<= 4 leaves, 64 points) next to the query gives the first bound:
+  // the query's own node for the covariance self-query, the node of its curve index otherwise.
+  int seed = 0;  // index at level min(1, top)
+  if (top >= 1) {
+    if (a.self) {
+      seed = (q / kLeaf) / kFan;
+    } else {
+      // locate the query's curve index among the leaves' first indices (last leaf with code <= qc)
+      const u64 qc = curve_code(px, py, pz, a.tree.lo[0], a.tree.lo[1], a.tree.lo[2], a.tree.scale);
+      const u64* __restrict__ codes = a.tree.leaf_code + a.tree.code_begin;
+      int lo_i = 0, hi_i = n_leaf - 1;
+      while (lo_i < hi_i) {
+        const int mid = (lo_i + hi_i + 1) >> 1;
+        if (codes[mid] <= qc) lo_i = mid; else hi_i = mid - 1;
+      }
+      seed = lo_i / kFan;
+    }
+    const int l0 = seed * kFan, l1 = min(l0 + kFan, n_leaf);
+    for (int l = l0; l < l1; ++l) { scan_leaf<K>(pts + (size_t)l * kLeaf, px, py, pz, bk, wd); ++dbg_leaves; }
+  } else {
+    scan_leaf<K>(pts, px, py, pz, bk, wd);
+  }
+
+  // --- depth-first walk of everything else.  State: the level L whose nodes are being iterated,
+  // the index `base` of the first sibling of the current group at L, and one 4-bit mask per level
+  // of the siblings still to visit.  "while-while": each lane walks boxes until it holds a leaf,
+  // then the wave scans leaves together (the scan is the expensive, divergence-sensitive part).
+  if (top >= 2) {
+    unsigned masks = 0;  // 4 bits per level, levels 0..top-1 (top <= 13 needs two words)
+    unsigned masks_hi = 0;
+    auto get = [&](int L) -> unsigned { return L < 8 ? (masks >> (4 * L)) & 15u : (masks_hi >> (4 * (L - 8))) & 15u; };
+    auto put = [&](int L, unsigned m) {
+      if (L < 8) masks = (masks & ~(15u << (4 * L))) | (m << (4 * L));
+      else masks_hi = (masks_hi & ~(15u << (4 * (L - 8)))) | (m << (4 * (L - 8)));
+    };
+    int L = top - 1, base = 0;
+    put(L, child_mask(blo, bhi, s_off[L], s_cnt[L], 0, px, py, pz, wd));
+    ++dbg_nodes;
+    bool done = false;
+    while (!done) {
+      int leaf = -1;
+      while (leaf < 0 && !done) {
+        const unsigned m = get(L);
+        if (m == 0) {  // this sibling group is exhausted: back to the parent's group
+          if (L == top - 1) { done = true; break; }
+          ++L;
+          base = (base / kFan) & ~(kFan - 1);
           continue;
         }
+        const int c = __ffs(m) - 1;
+        put(L, m & (m - 1));
+        const int node = base + c;
+        if (L == 1 && node == seed) continue;  // already scanned as the seed group
+        if (L == 0) {
+          leaf = node;
+        } else {
+          put(L - 1, child_mask(blo, bhi, s_off[L - 1], s_cnt[L - 1], node, px, py, pz, wd));
+          ++dbg_nodes;
+          --L;
+          base = node * kFan;
+        }
+      }
+      if (leaf >= 0) {
+        // the bound may have tightened since the mask was computed: re-test before paying for the scan
+        const int bn = s_off[0] + leaf;
+        if (!(box_lb(blo[bn], bhi[bn], px, py, pz) > wd)) { scan_leaf<K>(pts + (size_t)leaf * kLeaf, px, py, pz, bk, wd); ++dbg_leaves; }
       }
     }
-    bool done = false;
-    for (;;) {  // next node in depth-first order
-      ++j;
-      if ((j & (kFan - 1)) != 0 && j < s_cnt[k]) break;
-      if (k == top) { done = true; break; }
-      j = (j - 1) / kFan;
-      ++k;
-    }
-    if (done) break;
+  } else if (top == 1) {
+    // two levels: the seed group was one level-1 node == the root; nothing else exists
   }
   emit<K>(bk, a.inv, a.gate_sq, a.out_i, a.out_d, (size_t)(a.q_begin + q) * K);
+  if (a.dbg) { a.dbg[2 * q] = dbg_nodes; a.dbg[2 * q + 1] = dbg_leaves; }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -9,6 +9,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -64,12 +65,13 @@ struct Cloud {
   // search structure (bvh.hpp): packed points (x, y, z, caller index), boxes, seed tables
   struct SegTree {
     sicp::TreeLevels lv;
-    int n, pt_begin, node_begin, lut_begin;
+    int n, pt_begin, node_begin, code_begin;
     float lo[3], scale;
   };
   std::vector<SegTree> trees;
   DevBuf<float4> pts4, box_lo, box_hi;
-  DevBuf<int> lut, inv;  // inv: caller index -> device index
+  DevBuf<unsigned long long> leaf_code;
+  DevBuf<int> inv;  // caller index -> device index
   DevBuf<double> nx, ny, nz;
   DevBuf<uint8_t> hist;
   DevBuf<int> nn;
@@ -184,7 +186,7 @@ int prepare_cloud(sicp_context* h, Cloud& c) {
   c.trees.assign(n_seg, Cloud::SegTree());
   c.perm.resize(n);
   std::vector<float4> pts4, blo, bhi;
-  std::vector<int> lut;
+  std::vector<unsigned long long> codes;
   const float inf = std::numeric_limits<float>::infinity();
   float4 pad;
   pad.x = pad.y = pad.z = inf;
@@ -196,7 +198,7 @@ int prepare_cloud(sicp_context* h, Cloud& c) {
     c.seg_off[sg + 1] = o + cnt;
     Cloud::SegTree& st = c.trees[sg];
     st.lv = t.lv; st.n = cnt;
-    st.pt_begin = (int)pts4.size(); st.node_begin = (int)blo.size(); st.lut_begin = (int)lut.size();
+    st.pt_begin = (int)pts4.size(); st.node_begin = (int)blo.size(); st.code_begin = (int)codes.size();
     st.lo[0] = t.lo[0]; st.lo[1] = t.lo[1]; st.lo[2] = t.lo[2]; st.scale = t.scale;
     for (int e = 0; e < cnt; ++e) {
       const int i = seg_ids[sg][e];
@@ -215,7 +217,7 @@ int prepare_cloud(sicp_context* h, Cloud& c) {
       u.x = t.box_hi[4 * k]; u.y = t.box_hi[4 * k + 1]; u.z = t.box_hi[4 * k + 2]; u.w = 0;
       blo.push_back(l); bhi.push_back(u);
     }
-    lut.insert(lut.end(), t.lut.begin(), t.lut.end());
+    codes.insert(codes.end(), t.leaf_code.begin(), t.leaf_code.end());
   }
   std::vector<float> gx(n), gy(n), gz(n);
   std::vector<uint32_t> gl(c.has_label ? n : 0);
@@ -230,7 +232,7 @@ int prepare_cloud(sicp_context* h, Cloud& c) {
   HIPCHECK(c.x.reserve(m)); HIPCHECK(c.y.reserve(m)); HIPCHECK(c.z.reserve(m));
   HIPCHECK(c.label.reserve(m)); HIPCHECK(c.inv.reserve(m));
   HIPCHECK(c.pts4.reserve(pts4.size() + 1)); HIPCHECK(c.box_lo.reserve(blo.size() + 1));
-  HIPCHECK(c.box_hi.reserve(bhi.size() + 1)); HIPCHECK(c.lut.reserve(lut.size() + 1));
+  HIPCHECK(c.box_hi.reserve(bhi.size() + 1)); HIPCHECK(c.leaf_code.reserve(codes.size() + 1));
   auto up = [&](void* dst, const void* src, size_t bytes) {
     return bytes ? hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream) : hipSuccess;
   };
@@ -242,7 +244,7 @@ int prepare_cloud(sicp_context* h, Cloud& c) {
   HIPCHECK(up(c.pts4.p, pts4.data(), sizeof(float4) * pts4.size()));
   HIPCHECK(up(c.box_lo.p, blo.data(), sizeof(float4) * blo.size()));
   HIPCHECK(up(c.box_hi.p, bhi.data(), sizeof(float4) * bhi.size()));
-  HIPCHECK(up(c.lut.p, lut.data(), sizeof(int) * lut.size()));
+  HIPCHECK(up(c.leaf_code.p, codes.data(), sizeof(unsigned long long) * codes.size()));
   HIPCHECK(hipStreamSynchronize(h->stream));  // staging vectors go out of scope
   c.layout = want;
   c.feat_valid = false;
@@ -267,17 +269,36 @@ int run_nn(sicp_context* h, int K, const Cloud& Qc, int q_begin, int q_count, co
     a.q_begin = q_begin; a.q_count = q_count;
     a.do_xform = M34 ? 1 : 0;
     for (int i = 0; i < 12; ++i) a.M[i] = M34 ? M34[i] : 0.0;
-    a.tree.pts4 = Tc.pts4.p; a.tree.box_lo = Tc.box_lo.p; a.tree.box_hi = Tc.box_hi.p; a.tree.lut = Tc.lut.p;
+    a.tree.pts4 = Tc.pts4.p; a.tree.box_lo = Tc.box_lo.p; a.tree.box_hi = Tc.box_hi.p; a.tree.leaf_code = Tc.leaf_code.p;
     a.tree.lv = tr.lv; a.tree.n = tr.n; a.tree.pt_begin = tr.pt_begin; a.tree.node_begin = tr.node_begin;
-    a.tree.lut_begin = tr.lut_begin;
+    a.tree.code_begin = tr.code_begin;
     a.tree.lo[0] = tr.lo[0]; a.tree.lo[1] = tr.lo[1]; a.tree.lo[2] = tr.lo[2]; a.tree.scale = tr.scale;
     a.self = self ? 1 : 0;
     a.gate_sq = gate_sq;
     a.inv = Tc.inv.p;
     a.out_i = out_i; a.out_d = out_d;
+    a.dbg = nullptr;
+    static const bool want_dbg = std::getenv("SICP_KNN_STATS") != nullptr;  // developer aid, off by default
+    DevBuf<int> dbg;
+    if (want_dbg) { HIPCHECK(dbg.reserve((size_t)2 * q_count)); a.dbg = dbg.p; }
     KernelTimer kt(h, timer_bit);
     HIPCHECK(sicp::launch_bvh_knn(K, a, h->stream));
     account(kt.stop());
+    if (want_dbg) {
+      std::vector<int> hd((size_t)2 * q_count);
+      HIPCHECK(hipMemcpy(hd.data(), dbg.p, sizeof(int) * hd.size(), hipMemcpyDeviceToHost));
+      double sn = 0, sl = 0; int mn = 0, ml = 0;
+      for (int i = 0; i < q_count; ++i) { sn += hd[2 * i]; sl += hd[2 * i + 1]; mn = std::max(mn, hd[2 * i]); ml = std::max(ml, hd[2 * i + 1]); }
+      // per-wave maxima drive the run time: a wave is as slow as its slowest lane
+      double wsum_n = 0, wsum_l = 0; int nw = 0;
+      for (int w0 = 0; w0 < q_count; w0 += 64, ++nw) {
+        int wn = 0, wl = 0;
+        for (int i = w0; i < std::min(q_count, w0 + 64); ++i) { wn = std::max(wn, hd[2 * i]); wl = std::max(wl, hd[2 * i + 1]); }
+        wsum_n += wn; wsum_l += wl;
+      }
+      std::fprintf(stderr, "[sicp knn stats] K=%d self=%d n=%d: boxes/query avg %.1f max %d (wave-max avg %.1f), leaves/query avg %.1f max %d (wave-max avg %.1f)\n",
+                   K, (int)self, q_count, sn / q_count, mn, wsum_n / nw, sl / q_count, ml, wsum_l / nw);
+    }
     return SICP_OK;
   }
   const int t_count = tr.n;
@@ -565,6 +586,7 @@ int sicp_default_params(int mode, sicp_params* p) {
   p->jacobi_scaling = 1;
   p->quirk_bool_probability = 1;
   p->quirk_float_products = 1;
+  p->nn_method = 1;  // exact box-tree search; 0 = LDS-tiled brute force (same results)
   if (mode == SICP_MODE_EM) {
     p->knn = 4; p->cauchy_a = 3.0; p->use_sqloss = 1;  // em_icp.hpp:60,111,115
     p->outer_tol = 1e-5; p->max_outer = 50;            // em_icp.hpp:180
