@@ -44,6 +44,9 @@ def parse_args():
     ap.add_argument("--points", type=int, default=N_POINTS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--nn-method", type=int, default=None, help="0 brute force, 1 box tree (default: library default)")
+    ap.add_argument("--lm-on-device", type=int, default=None, help="0 host LM loop, 1 device-resident (default: library default)")
+    ap.add_argument("--lm-batch", type=int, default=None)
+    ap.add_argument("--profile", type=int, default=1, help="SICP_PROFILE_* mask (1 = NN kernel only; 8 adds the accumulate kernels)")
     ap.add_argument("--dry-run", action="store_true", help="exercise the multi-process plumbing without a GPU")
     return ap.parse_args()
 
@@ -139,9 +142,13 @@ def main():
             raise SystemExit("bench.py: no HIP device visible (there is no CPU fallback)")
         p = sicp.default_params(sicp.MODE_EM)
         p.num_classes = N_CLASSES
-        p.profile = 1  # SICP_PROFILE_NN: HIP events around the dominant kernel, on its own stream
+        p.profile = args.profile  # default SICP_PROFILE_NN: HIP events around the dominant kernel, on its own stream
         if args.nn_method is not None:
             p.nn_method = args.nn_method
+        if args.lm_on_device is not None:
+            p.lm_on_device = args.lm_on_device
+        if args.lm_batch is not None:
+            p.lm_batch = args.lm_batch
         nn_method = p.nn_method
         engine = sicp.Engine(dist.local_rank % ndev, p)
         engine.set_confusion(cm)
@@ -157,14 +164,15 @@ def main():
         engine.synchronize()
     dist.barrier()
     t0 = time.perf_counter()
-    corr = outer = evals = nn_launches = lm_iters = 0
-    nn_ms = cov_ms = 0.0
+    corr = outer = evals = nn_launches = lm_iters = acc_launches = 0
+    nn_ms = cov_ms = acc_ms = 0.0
     qt = ident
     for _ in range(args.steps):
         qt, st = step()
         corr += st["total_corr"]; outer += st["outer_iters"]; evals += st["total_evals"]
         nn_ms += st["nn_kernel_ms"]; nn_launches += st["nn_launches"]; cov_ms += st["t_cov_ms"]
         lm_iters += st["total_lm_iters"]
+        acc_ms += st.get("acc_kernel_ms", 0.0); acc_launches += st.get("acc_launches", 0)
     if engine:
         engine.synchronize()
     dist.barrier()
@@ -201,6 +209,8 @@ def main():
             "accumulate_passes_per_outer_iter": evals / max(1, outer),
             "lm_iters_per_outer_iter": lm_iters / max(1, outer),
         }
+        if acc_ms > 0:
+            out["accumulate_kernel_us_per_launch"] = 1e3 * acc_ms / max(1, acc_launches)
         if nn_launches and not args.dry_run:
             avg_ms = nn_ms / nn_launches
             alg_bytes = 12 * n + 12 * n + 8 * K_CORR * n     # src+tgt xyz once, idx+dist^2 out

@@ -105,6 +105,11 @@ typedef struct sicp_params {
                                      both exact, bit-identical results                  */
   int32_t profile;                /* SICP_PROFILE_* bit mask: bracket those kernels with
                                      HIP events on the handle's stream (sicp_stats)     */
+  int32_t lm_on_device;           /* 1 = trust-region state lives on the GPU, the host
+                                     polls once per batch of evaluations; 0 = host loop
+                                     (one synchronisation per evaluation).  Same machine
+                                     (csrc/lm.hpp), same iterates.                       */
+  int32_t lm_batch;               /* evaluations queued per host poll (lm_on_device)    */
 } sicp_params;
 
 /* Per-align() counters; times in milliseconds.  *_kernel_ms are HIP-event

@@ -59,6 +59,8 @@ class SicpParams(C.Structure):
         ("quirk_float_products", C.c_int32),
         ("nn_method", C.c_int32),
         ("profile", C.c_int32),
+        ("lm_on_device", C.c_int32),
+        ("lm_batch", C.c_int32),
     ]
 
 

@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include "bvh.hpp"
+#include "lm.hpp"
 
 namespace sicp {
 
@@ -84,14 +85,20 @@ struct CovArgs {
   uint8_t* hist;          // [n][C] or nullptr
 };
 
+struct ProjArgs {
+  int n, C;
+  const uint8_t* hist;  // [n][C] neighbour counts
+  const double* cm;     // C*C row-major
+  const double* hval;   // hval[c] = c additions of 1/k (em_icp.hpp:279,301)
+  double* proj;         // [n][C]
+};
+
 struct WeightArgs {
   int n_s, K, C;
   const int* idx;
   const float *sx, *sy, *sz, *tx, *ty, *tz;
   const double *snx, *sny, *snz, *tnx, *tny, *tnz;
-  const uint8_t *s_hist, *t_hist;
-  const double* cm;    // C*C row-major
-  const double* hval;  // hval[c] = c additions of 1/k (em_icp.hpp:279,301)
+  const double *s_proj, *t_proj;  // [n][C] label distributions projected through CM (proj_kernel)
   Pose pose;
   double one_m_eps;
   int bool_probability;
@@ -104,7 +111,8 @@ struct AccArgs {
   const double* w;  // nullable (weight 1)
   const float *sx, *sy, *sz, *tx, *ty, *tz;
   const double *snx, *sny, *snz, *tnx, *tny, *tnz;
-  Pose pose;
+  Pose pose;            // used when lm == nullptr
+  const LmState* lm;    // device-resident solve: evaluate at lm->pose, skip when it has finished
   double one_m_eps;
   LossArgs loss;
   double* partials;  // [accumulate_blocks][28]
@@ -116,10 +124,13 @@ hipError_t launch_nn_partial(int K, const NNArgs& a, int n_chunks, hipStream_t s
 hipError_t launch_nn_merge(int K, const MergeArgs& m, hipStream_t st);
 hipError_t launch_bvh_knn(int K, const KnnArgs& a, hipStream_t st);
 hipError_t launch_cov(const CovArgs& a, hipStream_t st);
+hipError_t launch_proj(const ProjArgs& a, hipStream_t st);
 hipError_t launch_em_weight(const WeightArgs& a, hipStream_t st);
 hipError_t launch_fused_labels(const WeightArgs& a, uint32_t* out, hipStream_t st);
 int accumulate_blocks(int total);
 hipError_t launch_accumulate(const AccArgs& a, double* out28, hipStream_t st);
+// one evaluation of the device-resident solve: accumulate at lm->pose, then feed the LM machine
+hipError_t launch_accumulate_lm(const AccArgs& a, LmState* lm, hipStream_t st);
 hipError_t launch_count_active(const int* idx, int n, unsigned long long* out, hipStream_t st);
 hipError_t launch_transform_float(int n, const float* x, const float* y, const float* z, const Mat4f& M,
                                   float* ox, float* oy, float* oz, hipStream_t st);

@@ -19,6 +19,7 @@
 // is GEMM shaped: no MFMA.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #define SICP_HD __host__ __device__
 #include "kernels.h"
@@ -408,16 +409,29 @@ __global__ __launch_bounds__(256) void cov_kernel(CovArgs a) {
   a.nx[i] = nx; a.ny[i] = ny; a.nz[i] = nz;
   if (a.hist) {
     // label histogram as neighbour counts (em_icp.hpp:301: dist(label-1) += 1/k)
-    uint8_t* h = a.hist + (size_t)i * a.C;
-    for (int c = 0; c < a.C; ++c) {
-      int cnt = 0;
-      for (int j = 0; j < a.k; ++j) {
-        const int g = nn[j];
-        if (g >= 0) cnt += (a.label[g] == (uint32_t)(c + 1)) ? 1 : 0;
-      }
-      h[c] = (uint8_t)cnt;
+    uint8_t* h = a.hist + (size_t)i * a.C;  // this lane owns the row
+    for (int c = 0; c < a.C; ++c) h[c] = 0;
+    for (int j = 0; j < a.k; ++j) {
+      const int g = nn[j];
+      if (g < 0) continue;
+      const uint32_t l = a.label[g];
+      if (l >= 1u && l <= (uint32_t)a.C) h[l - 1] = (uint8_t)(h[l - 1] + 1);
     }
   }
+}
+
+// per-point projections of the label distribution through the confusion matrix:
+//   proj[i][s] = dist_i^T * CM[:, s]   (the two factors of em_icp.hpp:86-87), dist = counts * 1/k
+// accumulated over r in ascending order exactly like the reference's dot product.  Computed once per
+// align() per cloud, so the per-correspondence weight is a C-term product-sum of two such rows.
+__global__ __launch_bounds__(256) void proj_kernel(ProjArgs a) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= a.n * a.C) return;
+  const int i = e / a.C, s = e - i * a.C;
+  const uint8_t* h = a.hist + (size_t)i * a.C;
+  double temp = 0.0;
+  for (int r = 0; r < a.C; ++r) temp += a.hval[h[r]] * a.cm[r * a.C + s];
+  a.proj[e] = temp;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -503,26 +517,18 @@ __device__ __forceinline__ void loss_eval(const LossArgs& L, double s, double w,
 // EM weight: label posterior from the confusion matrix x the (bool) geometric gate
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void em_weight_kernel(WeightArgs a) {
-  extern __shared__ __attribute__((aligned(16))) double cm_lds[];  // C*C confusion matrix
-  for (int e = threadIdx.x; e < a.C * a.C; e += blockDim.x) cm_lds[e] = a.cm[e];
-  __syncthreads();
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= a.n_s * a.K) return;
   const int i = e / a.K;
   const int j = a.idx[e];
   if (j < 0) { a.w[e] = 0.0; return; }
-  const uint8_t* hs = a.s_hist + (size_t)i * a.C;
-  const uint8_t* ht = a.t_hist + (size_t)j * a.C;
-  // em_icp.hpp:84-89
+  // em_icp.hpp:84-89 with the two dot products of each term taken from the per-point projections
+  const double* __restrict__ ps = a.s_proj + (size_t)i * a.C;
+  const double* __restrict__ pt = a.t_proj + (size_t)j * a.C;
   double prob = 0.0;
   for (int s = 0; s < a.C; ++s) {
-    double temp = 0.0, temp2 = 0.0;
-    for (int r = 0; r < a.C; ++r) {
-      const double cm = cm_lds[r * a.C + s];
-      temp += a.hval[ht[r]] * cm;
-      temp2 += a.hval[hs[r]] * cm;
-    }
-    temp *= temp2;
+    double temp = pt[s];
+    temp *= ps[s];
     prob += temp;
   }
   // em_icp.hpp:108 -> gicp_cost_function.h:75-87
@@ -542,10 +548,26 @@ __global__ __launch_bounds__(256) void em_weight_kernel(WeightArgs a) {
 // ------------------------------------------------------------------------------------------
 // accumulate: 28 doubles = [H upper 21 | g 6 | cost] over all correspondence slots
 // ------------------------------------------------------------------------------------------
+// Sum over the 64 lanes of a wave without touching the LDS crossbar: four DPP butterfly steps
+// inside each 16-lane row (quad_perm xor 1, xor 2, row_half_mirror, row_mirror), then the four
+// row sums are read into SGPRs and added.  Every lane returns the same value; the order of
+// additions is fixed, so the result is run-to-run reproducible.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+  const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi2, lo2);
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;
+  v += dpp_f64<0xB1>(v);   // quad_perm:[1,0,3,2]
+  v += dpp_f64<0x4E>(v);   // quad_perm:[2,3,0,1]
+  v += dpp_f64<0x141>(v);  // row_half_mirror
+  v += dpp_f64<0x140>(v);  // row_mirror
+  return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
 }
 
 template <int BS>
@@ -554,13 +576,23 @@ __global__ __launch_bounds__(BS) void accumulate_kernel(AccArgs a) {
   double acc[28];
 #pragma unroll
   for (int k = 0; k < 28; ++k) acc[k] = 0.0;
+  Pose P;
+  if (a.lm) {
+    // device-resident solve: the pose to evaluate lives in the LM state; once the solve has
+    // finished, the launches still queued behind it do nothing (uniform exit)
+    if (a.lm->status != LM_RUNNING) return;
+    se3::rotation(a.lm->pose, P.R);
+    P.t[0] = a.lm->pose[4]; P.t[1] = a.lm->pose[5]; P.t[2] = a.lm->pose[6];
+  } else {
+    P = a.pose;
+  }
   const int total = a.n_s * a.K;
   for (int e = blockIdx.x * BS + threadIdx.x; e < total; e += gridDim.x * BS) {
     const int j = a.idx[e];
     if (j < 0) continue;
     const int i = e / a.K;
     Corr c;
-    corr_eval<true>(a.pose, a.one_m_eps, a.sx[i], a.sy[i], a.sz[i], a.snx[i], a.sny[i], a.snz[i],
+    corr_eval<true>(P, a.one_m_eps, a.sx[i], a.sy[i], a.sz[i], a.snx[i], a.sny[i], a.snz[i],
                     a.tx[j], a.ty[j], a.tz[j], a.tnx[j], a.tny[j], a.tnz[j], c);
     const double w = a.w ? a.w[e] : 1.0;
     double rho0, rho1;
@@ -586,18 +618,48 @@ __global__ __launch_bounds__(BS) void accumulate_kernel(AccArgs a) {
     double s = 0.0;
 #pragma unroll
     for (int wv = 0; wv < BS / 64; ++wv) s += red[wv][threadIdx.x];
-    a.partials[(size_t)blockIdx.x * 28 + threadIdx.x] = s;
+    a.partials[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = s;  // [28][blocks]: coalesced for the reducer
   }
 }
 
-// sum the per-block partials in a fixed order: one wave per output (16 waves, 28 outputs)
-__global__ __launch_bounds__(1024) void finalize_kernel(const double* partials, int n_blocks, double* out28) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int k = wave; k < 28; k += 16) {
-    double s = 0.0;
-    for (int b = lane; b < n_blocks; b += 64) s += partials[(size_t)b * 28 + k];
-    s = wave_sum(s);
-    if (lane == 0) out28[k] = s;
+// fixed-order sum of the block partials (layout [28][n_blocks]) by one wave: every lane owns rows
+// lane, lane+64, ... ; the 28 loads of one trip are independent and coalesced
+__device__ __forceinline__ void reduce_partials(const double* __restrict__ partials, int n_blocks, int lane, double (&o)[28]) {
+  double s[28];
+#pragma unroll
+  for (int k = 0; k < 28; ++k) s[k] = 0.0;
+  for (int b = lane; b < n_blocks; b += 64) {
+#pragma unroll
+    for (int k = 0; k < 28; ++k) s[k] += partials[(size_t)k * n_blocks + b];
+  }
+#pragma unroll
+  for (int k = 0; k < 28; ++k) o[k] = wave_sum(s[k]);
+}
+
+// host-loop solve: sum the per-block partials in a fixed order
+__global__ __launch_bounds__(64) void finalize_kernel(const double* partials, int n_blocks, double* out28) {
+  double o[28];
+  reduce_partials(partials, n_blocks, threadIdx.x, o);
+  if (threadIdx.x < 28) {
+    double v = 0.0;
+#pragma unroll
+    for (int k = 0; k < 28; ++k) v = threadIdx.x == k ? o[k] : v;
+    out28[threadIdx.x] = v;
+  }
+}
+
+// device-resident solve: reduce the block partials and advance the LM machine by one evaluation
+// (lm.hpp: the same lm_feed the host loop runs).  One wave: 512 VGPRs are available to it, so the
+// whole 6x6 trust-region step stays in registers; lane 0 does the serial part.
+__global__ __launch_bounds__(64) void lm_step_kernel(LmState* lm, const double* partials, int n_blocks) {
+  if (lm->status != LM_RUNNING) return;
+  const int lane = threadIdx.x;
+  double o[28];
+  reduce_partials(partials, n_blocks, lane, o);
+  if (lane == 0) {
+    LmState st = *lm;
+    lm_feed(st, o);
+    *lm = st;
   }
 }
 
@@ -616,32 +678,36 @@ __global__ void transform_float_kernel(int n, const float* x, const float* y, co
 
 // fused label = arg max_s sum_c prob_c * (t_c . CM[:,s]) (s_i . CM[:,s])   (em_icp.hpp:224-266)
 __global__ __launch_bounds__(256) void fused_label_kernel(WeightArgs a, uint32_t* out_labels) {
-  extern __shared__ __attribute__((aligned(16))) double cm_lds[];
-  for (int e = threadIdx.x; e < a.C * a.C; e += blockDim.x) cm_lds[e] = a.cm[e];
-  __syncthreads();
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.n_s) return;
-  const uint8_t* hs = a.s_hist + (size_t)i * a.C;
-  double max_prob = 0.0;
-  int max_s = 0;
-  for (int s = 0; s < a.C; ++s) {
-    double temp2 = 0.0;
-    for (int r = 0; r < a.C; ++r) temp2 += a.hval[hs[r]] * cm_lds[r * a.C + s];
-    double sprob = 0.0;
-    for (int c = 0; c < a.K; ++c) {
-      const int j = a.idx[(size_t)i * a.K + c];
-      if (j < 0) continue;
-      const uint8_t* ht = a.t_hist + (size_t)j * a.C;
-      double temp = 0.0;
-      for (int r = 0; r < a.C; ++r) temp += a.hval[ht[r]] * cm_lds[r * a.C + s];
+  // the geometric factor of each of the K correspondences does not depend on s
+  double gprob[4];
+  int jj[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int j = c < a.K ? a.idx[(size_t)i * a.K + c] : -1;
+    jj[c] = j;
+    gprob[c] = 0.0;
+    if (j >= 0) {
       Corr cr;
       corr_eval<false>(a.pose, a.one_m_eps, a.sx[i], a.sy[i], a.sz[i], a.snx[i], a.sny[i], a.snz[i],
                        a.tx[j], a.ty[j], a.tz[j], a.tnx[j], a.tny[j], a.tnz[j], cr);
       const double two_pi = 6.283185307179586;
       const double probability = pow(two_pi * two_pi * two_pi * cr.detA, -0.5) * exp(-0.5 * cr.r);
-      const double prob = a.bool_probability ? ((probability != 0.0) ? 1.0 : 0.0) : probability;
-      temp *= temp2;
-      sprob += temp * prob;
+      gprob[c] = a.bool_probability ? ((probability != 0.0) ? 1.0 : 0.0) : probability;
+    }
+  }
+  const double* __restrict__ ps = a.s_proj + (size_t)i * a.C;
+  double max_prob = 0.0;
+  int max_s = 0;
+  for (int s = 0; s < a.C; ++s) {
+    double sprob = 0.0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (jj[c] < 0) continue;
+      double temp = a.t_proj[(size_t)jj[c] * a.C + s];
+      temp *= ps[s];
+      sprob += temp * gprob[c];  // em_icp.hpp:249-253
     }
     if (sprob > max_prob) { max_s = s; max_prob = sprob; }  // first max wins (em_icp.hpp:259)
   }
@@ -649,11 +715,15 @@ __global__ __launch_bounds__(256) void fused_label_kernel(WeightArgs a, uint32_t
 }
 
 // statistics: number of live correspondence slots (integer atomics: order independent)
-__global__ void count_active_kernel(const int* idx, int n, unsigned long long* out) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = e < n && idx[e] >= 0;
-  const unsigned long long m = __ballot(live);
-  if ((threadIdx.x & 63) == 0 && m) atomicAdd(out, (unsigned long long)__popcll(m));
+__global__ __launch_bounds__(256) void count_active_kernel(const int* idx, int n, unsigned long long* out) {
+  __shared__ unsigned cnt[4];
+  unsigned c = 0;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) c += idx[e] >= 0 ? 1u : 0u;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+  if ((threadIdx.x & 63) == 0) cnt[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, (unsigned long long)(cnt[0] + cnt[1] + cnt[2] + cnt[3]));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -711,22 +781,32 @@ hipError_t launch_cov(const CovArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 
+hipError_t launch_proj(const ProjArgs& a, hipStream_t st) {
+  const int total = a.n * a.C;
+  if (total <= 0) return hipSuccess;
+  hipLaunchKernelGGL(proj_kernel, dim3((total + 255) / 256), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_em_weight(const WeightArgs& a, hipStream_t st) {
   const int total = a.n_s * a.K;
   if (total <= 0) return hipSuccess;
-  hipLaunchKernelGGL(em_weight_kernel, dim3((total + 255) / 256), dim3(256), sizeof(double) * a.C * a.C, st, a);
+  hipLaunchKernelGGL(em_weight_kernel, dim3((total + 255) / 256), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 
 hipError_t launch_fused_labels(const WeightArgs& a, uint32_t* out, hipStream_t st) {
   if (a.n_s <= 0) return hipSuccess;
-  hipLaunchKernelGGL(fused_label_kernel, dim3((a.n_s + 255) / 256), dim3(256), sizeof(double) * a.C * a.C, st, a, out);
+  hipLaunchKernelGGL(fused_label_kernel, dim3((a.n_s + 255) / 256), dim3(256), 0, st, a, out);
   return hipGetLastError();
 }
 
 int accumulate_blocks(int total) {
+  // each lane sums several slots in registers before the (LDS-bound) wave reduction; the grid
+  // still covers every CU.  SICP_ACC_SLOTS_PER_LANE is a tuning aid.
+  static const int per_lane = [] { const char* e = getenv("SICP_ACC_SLOTS_PER_LANE"); return e ? atoi(e) : 4; }();
   const int bs = 256;
-  int nb = (total + bs - 1) / bs;
+  int nb = (total + bs * per_lane - 1) / (bs * per_lane);
   if (nb > 1024) nb = 1024;
   if (nb < 1) nb = 1;
   return nb;
@@ -737,13 +817,22 @@ hipError_t launch_accumulate(const AccArgs& a, double* out28, hipStream_t st) {
   hipLaunchKernelGGL((accumulate_kernel<256>), dim3(nb), dim3(256), 0, st, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(1024), 0, st, a.partials, nb, out28);
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, st, a.partials, nb, out28);
+  return hipGetLastError();
+}
+
+hipError_t launch_accumulate_lm(const AccArgs& a, LmState* lm, hipStream_t st) {
+  const int nb = accumulate_blocks(a.n_s * a.K);
+  hipLaunchKernelGGL((accumulate_kernel<256>), dim3(nb), dim3(256), 0, st, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(lm_step_kernel, dim3(1), dim3(64), 0, st, lm, a.partials, nb);
   return hipGetLastError();
 }
 
 hipError_t launch_count_active(const int* idx, int n, unsigned long long* out, hipStream_t st) {
   if (n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(count_active_kernel, dim3((n + 255) / 256), dim3(256), 0, st, idx, n, out);
+  hipLaunchKernelGGL(count_active_kernel, dim3(min(256, (n + 255) / 256)), dim3(256), 0, st, idx, n, out);
   return hipGetLastError();
 }
 

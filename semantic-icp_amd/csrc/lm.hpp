@@ -1,4 +1,4 @@
-// lm.hpp -- host-side 6-DoF Levenberg-Marquardt driver (product code).
+// lm.hpp -- 6-DoF Levenberg-Marquardt as a re-entrant state machine (product code, host + device).
 //
 // Replaces the inner ceres::Solve of the reference (em_icp.hpp:162-177, gicp.hpp:138-151,
 // semantic_icp.hpp:136-149): one SE3 parameter block (7 ambient / 6 tangent), trust-region +
@@ -8,16 +8,31 @@
 // to anyway: H = J^T J (robustified), g = J^T r, cost.  DENSE_QR on [J; D] and Cholesky on
 // H + D^2 solve the same 6x6 system.
 //
+// The machine consumes one evaluation at a time:
+//     lm_init(s, opt, x0);                 // s.pose = x0 is the first point to evaluate
+//     while (s.status == LM_RUNNING) { evaluate out28 at s.pose;  lm_feed(s, out28); }
+// so the same code drives the host loop (sicp_api.cpp) and the device-resident solve, where
+// lm_feed runs in a one-block kernel right after each accumulate kernel and the host only looks at
+// s.status once per batch of launches (kernels.hip: lm_step_kernel).
+//
 // Unlike Ceres, one evaluation returns cost, gradient and H together, so an accepted step does
 // not need a second sweep at the same point (Ceres evaluates the candidate cost first and the
 // Jacobian again after accepting); the iterates are the same.
 #ifndef SICP_LM_HPP_
 #define SICP_LM_HPP_
 
-#include <cmath>
-#include <cstring>
+#include <math.h>
+#include <string.h>
 
 #include "se3.hpp"
+
+// the 6x6 loops must unroll completely on the GPU, or their local arrays are indexed dynamically
+// and land in scratch memory (the one-lane lm_feed then takes tens of microseconds)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SICP_UNROLL _Pragma("unroll")
+#else
+#define SICP_UNROLL
+#endif
 
 namespace sicp {
 
@@ -33,147 +48,196 @@ struct LmOptions {
   double min_lm_diagonal = 1e-6;
   double max_lm_diagonal = 1e32;
   int max_consecutive_invalid_steps = 5;
-  bool jacobi_scaling = true;
+  int jacobi_scaling = 1;
 };
 
-struct LmResult {
-  int status = 0;  // 0 converged, 1 iteration cap, 2 too many invalid steps, <0 evaluation failed
-  int iterations = 0;
-  int evaluations = 0;
-  double cost = 0;
+enum { LM_RUNNING = -1, LM_CONVERGED = 0, LM_ITERATION_CAP = 1, LM_INVALID_STEPS = 2, LM_EVAL_FAILED = 3 };
+
+struct LmState {
+  LmOptions opt;
+  double pose[7];  // the point whose evaluation lm_feed expects next
+  double x[7];     // last accepted iterate (the answer when status != LM_RUNNING)
+  double H[36], g[6], cost, x_norm;
+  double scale[6], diag[6];
+  double radius, decrease_factor, model_change;
+  int reuse_diagonal, invalid, iterations, evaluations;
+  int phase;   // 0: pose == x (first evaluation), 1: pose is a candidate step
+  int status;  // LM_*
 };
 
 namespace detail {
 
-inline bool chol6_solve(const double* A, const double* b, double* y) {
-  double L[36] = {0};
+SICP_HD inline bool chol6_solve(const double* A, const double* b, double* y) {
+  double L[36];
+  SICP_UNROLL
+  for (int i = 0; i < 36; ++i) L[i] = 0;
+  SICP_UNROLL
   for (int i = 0; i < 6; ++i)
+    SICP_UNROLL
     for (int j = 0; j <= i; ++j) {
       double s = A[6 * i + j];
+      SICP_UNROLL
       for (int k = 0; k < j; ++k) s -= L[6 * i + k] * L[6 * j + k];
       if (i == j) {
         if (!(s > 0)) return false;
-        L[6 * i + i] = std::sqrt(s);
+        L[6 * i + i] = sqrt(s);
       } else {
         L[6 * i + j] = s / L[6 * j + j];
       }
     }
   double z[6];
+  SICP_UNROLL
   for (int i = 0; i < 6; ++i) {
     double s = b[i];
+    SICP_UNROLL
     for (int k = 0; k < i; ++k) s -= L[6 * i + k] * z[k];
     z[i] = s / L[6 * i + i];
   }
+  SICP_UNROLL
   for (int i = 5; i >= 0; --i) {
     double s = z[i];
+    SICP_UNROLL
     for (int k = i + 1; k < 6; ++k) s -= L[6 * k + i] * y[k];
     y[i] = s / L[6 * i + i];
   }
   return true;
 }
 
-inline void unpack28(const double* o, double* H, double* g, double* cost) {
+SICP_HD inline void unpack28(const double* o, double* H, double* g, double* cost) {
   int k = 0;
+  SICP_UNROLL
   for (int a = 0; a < 6; ++a)
+    SICP_UNROLL
     for (int b = a; b < 6; ++b) { H[6 * a + b] = o[k]; H[6 * b + a] = o[k]; ++k; }
+  SICP_UNROLL
   for (int a = 0; a < 6; ++a) g[a] = o[21 + a];
   *cost = o[27];
 }
 
 // Ceres: ||x - Plus(x, -g)||_inf  (ambient coordinates)
-inline double gradient_max_norm(const double* x, const double* g) {
+SICP_HD inline double gradient_max_norm(const double* x, const double* g) {
   double ng[6], xp[7], m = 0;
+  SICP_UNROLL
   for (int i = 0; i < 6; ++i) ng[i] = -g[i];
   se3::plus(x, ng, xp);
-  for (int i = 0; i < 7; ++i) m = std::fmax(m, std::fabs(x[i] - xp[i]));
+  SICP_UNROLL
+  for (int i = 0; i < 7; ++i) m = fmax(m, fabs(x[i] - xp[i]));
   return m;
 }
 
-}  // namespace detail
-
-// eval(qt, out28) -> 0 on success
-template <class Eval>
-LmResult lm_solve(const LmOptions& opt, Eval&& eval, const double* init_qt, double* out_qt) {
-  using namespace detail;
-  LmResult res;
-  double x[7], o[28], H[36], g[6], cost;
-  std::memcpy(x, init_qt, sizeof x);
-  if (eval(x, o) != 0) { res.status = -1; std::memcpy(out_qt, x, sizeof x); return res; }
-  res.evaluations++;
-  unpack28(o, H, g, &cost);
-  double x_norm = se3::norm7(x);
-  double scale[6];
-  for (int j = 0; j < 6; ++j) scale[j] = opt.jacobi_scaling ? 1.0 / (1.0 + std::sqrt(H[6 * j + j])) : 1.0;
-  double radius = opt.initial_radius, decrease_factor = 2.0, diag[6] = {0, 0, 0, 0, 0, 0};
-  bool reuse_diagonal = false;
-  int invalid = 0;
+// From the accepted iterate: terminate, or compute the next trust-region step and publish the
+// candidate in s.pose.
+SICP_HD inline void lm_propose(LmState& s) {
+  const LmOptions& opt = s.opt;
   for (;;) {
-    if (res.iterations >= opt.max_iterations) { res.status = 1; break; }
-    if (gradient_max_norm(x, g) <= opt.gradient_tolerance) break;
-    if (radius <= opt.min_radius) break;
-    res.iterations++;
+    if (s.iterations >= opt.max_iterations) { s.status = LM_ITERATION_CAP; return; }
+    if (gradient_max_norm(s.x, s.g) <= opt.gradient_tolerance) { s.status = LM_CONVERGED; return; }
+    if (s.radius <= opt.min_radius) { s.status = LM_CONVERGED; return; }
+    s.iterations++;
     double Hs[36], gs[6];
+    SICP_UNROLL
     for (int a = 0; a < 6; ++a) {
-      gs[a] = g[a] * scale[a];
-      for (int b = 0; b < 6; ++b) Hs[6 * a + b] = H[6 * a + b] * scale[a] * scale[b];
+      gs[a] = s.g[a] * s.scale[a];
+      SICP_UNROLL
+      for (int b = 0; b < 6; ++b) Hs[6 * a + b] = s.H[6 * a + b] * s.scale[a] * s.scale[b];
     }
-    if (!reuse_diagonal)
-      for (int j = 0; j < 6; ++j) diag[j] = std::fmin(std::fmax(Hs[6 * j + j], opt.min_lm_diagonal), opt.max_lm_diagonal);
+    if (!s.reuse_diagonal)
+      SICP_UNROLL
+      for (int j = 0; j < 6; ++j) s.diag[j] = fmin(fmax(Hs[6 * j + j], opt.min_lm_diagonal), opt.max_lm_diagonal);
     double A[36], y[6], step[6];
-    std::memcpy(A, Hs, sizeof A);
+    SICP_UNROLL
+    for (int i = 0; i < 36; ++i) A[i] = Hs[i];
+    SICP_UNROLL
     for (int j = 0; j < 6; ++j) {
-      const double lm = std::sqrt(diag[j] / radius);
+      const double lm = sqrt(s.diag[j] / s.radius);  // lm_diagonal_
       A[6 * j + j] += lm * lm;
     }
-    reuse_diagonal = true;
+    s.reuse_diagonal = 1;
     const bool ok = chol6_solve(A, gs, y);
     double model_change = 0;
     if (ok) {
       double sg = 0, sHs = 0;
+      SICP_UNROLL
       for (int a = 0; a < 6; ++a) step[a] = -y[a];
+      SICP_UNROLL
       for (int a = 0; a < 6; ++a) {
         sg += step[a] * gs[a];
         double r = 0;
+        SICP_UNROLL
         for (int b = 0; b < 6; ++b) r += Hs[6 * a + b] * step[b];
         sHs += step[a] * r;
       }
       model_change = -(sg + 0.5 * sHs);
     }
     if (!ok || !(model_change > 0.0)) {
-      if (++invalid >= opt.max_consecutive_invalid_steps) { res.status = 2; break; }
-      radius *= 0.5;
+      if (++s.invalid >= opt.max_consecutive_invalid_steps) { s.status = LM_INVALID_STEPS; return; }
+      s.radius *= 0.5;
       continue;
     }
-    invalid = 0;
-    double delta[6], cand[7], oc[28];
-    for (int j = 0; j < 6; ++j) delta[j] = step[j] * scale[j];
-    se3::plus(x, delta, cand);
-    if (eval(cand, oc) != 0) { res.status = -1; break; }
-    res.evaluations++;
-    const double cand_cost = oc[27];
+    s.invalid = 0;
+    double delta[6];
+    SICP_UNROLL
+    for (int j = 0; j < 6; ++j) delta[j] = step[j] * s.scale[j];
+    se3::plus(s.x, delta, s.pose);
+    s.model_change = model_change;
+    s.phase = 1;
+    return;
+  }
+}
+
+}  // namespace detail
+
+SICP_HD inline void lm_init(LmState& s, const LmOptions& opt, const double* x0) {
+  s.opt = opt;
+  SICP_UNROLL
+  for (int i = 0; i < 7; ++i) { s.pose[i] = x0[i]; s.x[i] = x0[i]; }
+  SICP_UNROLL
+  for (int i = 0; i < 36; ++i) s.H[i] = 0;
+  SICP_UNROLL
+  for (int i = 0; i < 6; ++i) { s.g[i] = 0; s.scale[i] = 1; s.diag[i] = 0; }
+  s.cost = 0; s.x_norm = 0;
+  s.radius = opt.initial_radius; s.decrease_factor = 2.0; s.model_change = 0;
+  s.reuse_diagonal = 0; s.invalid = 0; s.iterations = 0; s.evaluations = 0;
+  s.phase = 0;
+  s.status = LM_RUNNING;
+}
+
+// out28 = [H upper 21 | g 6 | cost] evaluated at s.pose
+SICP_HD inline void lm_feed(LmState& s, const double* o) {
+  using namespace detail;
+  if (s.status != LM_RUNNING) return;
+  const LmOptions& opt = s.opt;
+  s.evaluations++;
+  if (s.phase == 0) {
+    unpack28(o, s.H, s.g, &s.cost);
+    s.x_norm = se3::norm7(s.x);
+    SICP_UNROLL
+    for (int j = 0; j < 6; ++j) s.scale[j] = opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(s.H[6 * j + j])) : 1.0;
+  } else {
+    const double cand_cost = o[27];
     double diff[7];
-    for (int i = 0; i < 7; ++i) diff[i] = x[i] - cand[i];
-    if (se3::norm7(diff) <= opt.parameter_tolerance * (x_norm + opt.parameter_tolerance)) break;
-    const double cost_change = cost - cand_cost;
-    if (std::fabs(cost_change) <= opt.function_tolerance * cost) break;
-    const double rel = cost_change / model_change;
+    SICP_UNROLL
+    for (int i = 0; i < 7; ++i) diff[i] = s.x[i] - s.pose[i];
+    if (se3::norm7(diff) <= opt.parameter_tolerance * (s.x_norm + opt.parameter_tolerance)) { s.status = LM_CONVERGED; return; }
+    const double cost_change = s.cost - cand_cost;
+    if (fabs(cost_change) <= opt.function_tolerance * s.cost) { s.status = LM_CONVERGED; return; }
+    const double rel = cost_change / s.model_change;
     if (rel > opt.min_relative_decrease) {
-      std::memcpy(x, cand, sizeof x);
-      x_norm = se3::norm7(x);
-      unpack28(oc, H, g, &cost);
+      SICP_UNROLL
+      for (int i = 0; i < 7; ++i) s.x[i] = s.pose[i];
+      s.x_norm = se3::norm7(s.x);
+      unpack28(o, s.H, s.g, &s.cost);
       const double t = 2.0 * rel - 1.0;
-      radius = std::fmin(opt.max_radius, radius / std::fmax(1.0 / 3.0, 1.0 - t * t * t));
-      decrease_factor = 2.0;
-      reuse_diagonal = false;
+      s.radius = fmin(opt.max_radius, s.radius / fmax(1.0 / 3.0, 1.0 - t * t * t));
+      s.decrease_factor = 2.0;
+      s.reuse_diagonal = 0;
     } else {
-      radius /= decrease_factor;
-      decrease_factor *= 2.0;
-      reuse_diagonal = true;
+      s.radius /= s.decrease_factor;
+      s.decrease_factor *= 2.0;
+      s.reuse_diagonal = 1;
     }
   }
-  std::memcpy(out_qt, x, sizeof x);
-  res.cost = cost;
-  return res;
+  lm_propose(s);
 }
 
 }  // namespace sicp

@@ -7,17 +7,28 @@
 #ifndef SICP_SE3_HPP_
 #define SICP_SE3_HPP_
 
-#include <cmath>
-#include <cstring>
+#include <math.h>
+#include <string.h>
+
+// empty on the host; kernels.hip defines it as __host__ __device__ so that the device-resident
+// solve (lm.hpp) runs the very same SE(3) code
+#ifndef SICP_HD
+#define SICP_HD
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SICP_SE3_UNROLL _Pragma("unroll")
+#else
+#define SICP_SE3_UNROLL
+#endif
 
 namespace sicp {
 namespace se3 {
 
-constexpr double kEps = 1e-10;  // Sophus::Constants<double>::epsilon()
-constexpr double kPi = 3.14159265358979323846;
+#define SICP_SE3_EPS 1e-10  /* Sophus::Constants<double>::epsilon() */
+#define SICP_SE3_PI 3.14159265358979323846
 
 // Eigen Quaternion::toRotationMatrix (no normalisation), row-major
-inline void rotation(const double* qt, double* R) {
+SICP_HD inline void rotation(const double* qt, double* R) {
   const double x = qt[0], y = qt[1], z = qt[2], w = qt[3];
   const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
   const double twx = tx * w, twy = ty * w, twz = tz * w;
@@ -28,7 +39,7 @@ inline void rotation(const double* qt, double* R) {
   R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
 }
 
-inline void matvec3(const double* A, const double* v, double* o) {
+SICP_HD inline void matvec3(const double* A, const double* v, double* o) {
   const double a = A[0] * v[0] + A[1] * v[1] + A[2] * v[2];
   const double b = A[3] * v[0] + A[4] * v[1] + A[5] * v[2];
   const double c = A[6] * v[0] + A[7] * v[1] + A[8] * v[2];
@@ -36,9 +47,10 @@ inline void matvec3(const double* A, const double* v, double* o) {
 }
 
 // rows 0..2 of the 4x4 matrix, row-major 3x4 (what pcl::transformPointCloud consumes)
-inline void matrix34(const double* qt, double* M) {
+SICP_HD inline void matrix34(const double* qt, double* M) {
   double R[9];
   rotation(qt, R);
+  SICP_SE3_UNROLL
   for (int i = 0; i < 3; ++i) {
     M[4 * i + 0] = R[3 * i + 0]; M[4 * i + 1] = R[3 * i + 1]; M[4 * i + 2] = R[3 * i + 2];
     M[4 * i + 3] = qt[4 + i];
@@ -46,31 +58,34 @@ inline void matrix34(const double* qt, double* M) {
 }
 
 // Sophus SE3::exp
-inline void exp(const double* a, double* qt) {
+SICP_HD inline void exp(const double* a, double* qt) {
   const double* w = a + 3;
   const double theta_sq = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
-  const double theta = std::sqrt(theta_sq);
+  const double theta = sqrt(theta_sq);
   double imag, real;
-  if (theta < kEps) {
+  if (theta < SICP_SE3_EPS) {
     const double t4 = theta_sq * theta_sq;
     imag = 0.5 - theta_sq / 48.0 + t4 / 3840.0;
     real = 1.0 - theta_sq / 8.0 + t4 / 384.0;
   } else {
-    imag = std::sin(0.5 * theta) / theta;
-    real = std::cos(0.5 * theta);
+    imag = sin(0.5 * theta) / theta;
+    real = cos(0.5 * theta);
   }
   qt[0] = imag * w[0]; qt[1] = imag * w[1]; qt[2] = imag * w[2]; qt[3] = real;
   // V = I + (1-cos)/th^2 * W + (th - sin)/th^3 * W^2 ; small angle: V = R
   double V[9];
-  if (theta < kEps) {
+  if (theta < SICP_SE3_EPS) {
     rotation(qt, V);
   } else {
-    const double c1 = (1 - std::cos(theta)) / theta_sq, c2 = (theta - std::sin(theta)) / (theta_sq * theta);
+    const double c1 = (1 - cos(theta)) / theta_sq, c2 = (theta - sin(theta)) / (theta_sq * theta);
     const double W[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
     double W2[9];
+    SICP_SE3_UNROLL
     for (int i = 0; i < 3; ++i)
+      SICP_SE3_UNROLL
       for (int j = 0; j < 3; ++j)
         W2[3 * i + j] = W[3 * i] * W[j] + W[3 * i + 1] * W[3 + j] + W[3 * i + 2] * W[6 + j];
+    SICP_SE3_UNROLL
     for (int i = 0; i < 9; ++i) V[i] = c1 * W[i] + c2 * W2[i];
     V[0] += 1; V[4] += 1; V[8] += 1;
   }
@@ -78,29 +93,31 @@ inline void exp(const double* a, double* qt) {
 }
 
 // Sophus SE3::log
-inline void log(const double* qt, double* a) {
+SICP_HD inline void log(const double* qt, double* a) {
   const double sqn = qt[0] * qt[0] + qt[1] * qt[1] + qt[2] * qt[2];
-  const double n = std::sqrt(sqn), qw = qt[3];
+  const double n = sqrt(sqn), qw = qt[3];
   double f;
-  if (n < kEps) {
+  if (n < SICP_SE3_EPS) {
     f = 2.0 / qw - (2.0 / 3.0) * sqn / (qw * qw * qw);
-  } else if (std::fabs(qw) < kEps) {
-    f = (qw > 0 ? kPi : -kPi) / n;
+  } else if (fabs(qw) < SICP_SE3_EPS) {
+    f = (qw > 0 ? SICP_SE3_PI : -SICP_SE3_PI) / n;
   } else {
-    f = 2.0 * std::atan(n / qw) / n;
+    f = 2.0 * atan(n / qw) / n;
   }
   const double theta = f * n;
   const double w[3] = {f * qt[0], f * qt[1], f * qt[2]};
   double c;
-  if (std::fabs(theta) < kEps) {
+  if (fabs(theta) < SICP_SE3_EPS) {
     c = 1.0 / 12.0;
   } else {
     const double h = 0.5 * theta;
-    c = (1.0 - theta * std::cos(h) / (2.0 * std::sin(h))) / (theta * theta);
+    c = (1.0 - theta * cos(h) / (2.0 * sin(h))) / (theta * theta);
   }
   const double W[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
   double Vi[9];
+  SICP_SE3_UNROLL
   for (int i = 0; i < 3; ++i)
+    SICP_SE3_UNROLL
     for (int j = 0; j < 3; ++j) {
       const double w2 = W[3 * i] * W[j] + W[3 * i + 1] * W[3 + j] + W[3 * i + 2] * W[6 + j];
       Vi[3 * i + j] = -0.5 * W[3 * i + j] + c * w2 + (i == j ? 1.0 : 0.0);
@@ -110,7 +127,7 @@ inline void log(const double* qt, double* a) {
 }
 
 // group product (Sophus: quaternion product + first-order renormalisation)
-inline void mul(const double* a, const double* b, double* out) {
+SICP_HD inline void mul(const double* a, const double* b, double* out) {
   const double ax = a[0], ay = a[1], az = a[2], aw = a[3];
   const double bx = b[0], by = b[1], bz = b[2], bw = b[3];
   double q[4];
@@ -127,29 +144,32 @@ inline void mul(const double* a, const double* b, double* out) {
   rotation(a, R);
   matvec3(R, b + 4, t);
   const double o[7] = {q[0], q[1], q[2], q[3], a[4] + t[0], a[5] + t[1], a[6] + t[2]};
-  std::memcpy(out, o, sizeof o);
+  SICP_SE3_UNROLL
+  for (int i = 0; i < 7; ++i) out[i] = o[i];
 }
 
-inline void inverse(const double* a, double* out) {
+SICP_HD inline void inverse(const double* a, double* out) {
   const double c[7] = {-a[0], -a[1], -a[2], a[3], 0, 0, 0};
   double R[9], t[3];
   rotation(c, R);
   matvec3(R, a + 4, t);
   const double o[7] = {c[0], c[1], c[2], c[3], -t[0], -t[1], -t[2]};
-  std::memcpy(out, o, sizeof o);
+  SICP_SE3_UNROLL
+  for (int i = 0; i < 7; ++i) out[i] = o[i];
 }
 
 // LocalParameterizationSE3::Plus
-inline void plus(const double* qt, const double* delta, double* out) {
+SICP_HD inline void plus(const double* qt, const double* delta, double* out) {
   double e[7];
   exp(delta, e);
   mul(qt, e, out);
 }
 
-inline double norm7(const double* a) {
+SICP_HD inline double norm7(const double* a) {
   double s = 0;
+  SICP_SE3_UNROLL
   for (int i = 0; i < 7; ++i) s += a[i] * a[i];
-  return std::sqrt(s);
+  return sqrt(s);
 }
 
 }  // namespace se3

@@ -74,6 +74,8 @@ struct Cloud {
   DevBuf<int> inv;  // caller index -> device index
   DevBuf<double> nx, ny, nz;
   DevBuf<uint8_t> hist;
+  DevBuf<double> proj;  // [n][C] label distribution x confusion matrix
+  bool proj_valid = false;
   DevBuf<int> nn;
   bool feat_valid = false;
   int feat_k = 0, feat_C = 0, feat_float_products = 0;
@@ -92,7 +94,8 @@ double now_ms() {
 struct sicp_context {
   int device = 0;
   hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipStream_t stream2 = nullptr;  // second cloud's feature kernels run beside the first's
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_join = nullptr;
   sicp_params params;
   Cloud cloud[2];
   int C = 0;
@@ -108,6 +111,8 @@ struct sicp_context {
   DevBuf<unsigned long long> part;
   DevBuf<double> partials, out28;
   DevBuf<long long> d_count;
+  DevBuf<sicp::LmState> d_lm;
+  sicp::LmState* h_lm = nullptr;  // pinned mirror of the device-resident LM state
   double* h_out28 = nullptr;      // pinned, 28 doubles
   long long* h_count = nullptr;   // pinned
   DevBuf<float> tmpx, tmpy, tmpz;
@@ -256,7 +261,7 @@ int prepare_cloud(sicp_context* h, Cloud& c) {
 // queries: points [q_begin, q_begin+q_count) of cloud Q (device order), optionally transformed
 // by M34; targets: segment `tseg` of cloud T.  Writes device indices of T (or -1) and distances.
 int run_nn(sicp_context* h, int K, const Cloud& Qc, int q_begin, int q_count, const double* M34, const Cloud& Tc,
-           int tseg, bool self, float gate_sq, int* out_i, float* out_d, int timer_bit) {
+           int tseg, bool self, float gate_sq, int* out_i, float* out_d, int timer_bit, hipStream_t stream) {
   if (q_count <= 0) return SICP_OK;
   const Cloud::SegTree& tr = Tc.trees[tseg];
   auto account = [&](double ms) {
@@ -281,8 +286,8 @@ int run_nn(sicp_context* h, int K, const Cloud& Qc, int q_begin, int q_count, co
     static const bool want_dbg = std::getenv("SICP_KNN_STATS") != nullptr;  // developer aid, off by default
     DevBuf<int> dbg;
     if (want_dbg) { HIPCHECK(dbg.reserve((size_t)2 * q_count)); a.dbg = dbg.p; }
-    KernelTimer kt(h, timer_bit);
-    HIPCHECK(sicp::launch_bvh_knn(K, a, h->stream));
+    KernelTimer kt(h, stream == h->stream ? timer_bit : 0);
+    HIPCHECK(sicp::launch_bvh_knn(K, a, stream));
     account(kt.stop());
     if (want_dbg) {
       std::vector<int> hd((size_t)2 * q_count);
@@ -331,11 +336,11 @@ int run_nn(sicp_context* h, int K, const Cloud& Qc, int q_begin, int q_count, co
   m.gate_sq = gate_sq;
   m.out_i = out_i; m.out_d = out_d;
   {
-    KernelTimer kt(h, timer_bit);
-    HIPCHECK(sicp::launch_nn_partial(K, a, chunks, h->stream));
+    KernelTimer kt(h, stream == h->stream ? timer_bit : 0);
+    HIPCHECK(sicp::launch_nn_partial(K, a, chunks, stream));
     account(kt.stop());
   }
-  HIPCHECK(sicp::launch_nn_merge(K, m, h->stream));
+  HIPCHECK(sicp::launch_nn_merge(K, m, stream));
   return SICP_OK;
 }
 
@@ -353,7 +358,22 @@ int ensure_hval(sicp_context* h, int k) {
   return SICP_OK;
 }
 
-int compute_features(sicp_context* h, Cloud& c, bool with_hist) {
+// projections of the label histograms through the confusion matrix (once per cloud per align)
+int ensure_proj(sicp_context* h, Cloud& c) {
+  if (c.proj_valid) return SICP_OK;
+  const sicp_params& P = h->params;
+  SICPCHECK(ensure_hval(h, P.k_cov));
+  HIPCHECK(c.proj.reserve((size_t)(c.n > 0 ? c.n : 1) * P.num_classes));
+  sicp::ProjArgs a;
+  a.n = c.n; a.C = P.num_classes;
+  a.hist = c.hist.p; a.cm = h->d_cm.p; a.hval = h->d_hval.p; a.proj = c.proj.p;
+  HIPCHECK(sicp::launch_proj(a, h->stream));
+  c.proj_valid = true;
+  return SICP_OK;
+}
+
+int compute_features(sicp_context* h, Cloud& c, bool with_hist, hipStream_t stream = nullptr) {
+  if (!stream) stream = h->stream;
   const sicp_params& P = h->params;
   const int k = P.k_cov, n = c.n;
   const size_t m = (size_t)(n > 0 ? n : 1);
@@ -363,7 +383,7 @@ int compute_features(sicp_context* h, Cloud& c, bool with_hist) {
   for (int s = 0; s < c.n_seg(); ++s) {
     const int o = c.seg_off[s], cnt = c.seg_off[s + 1] - o;
     SICPCHECK(run_nn(h, k, c, o, cnt, nullptr, c, s, true, std::numeric_limits<float>::infinity(), c.nn.p, nullptr,
-                     SICP_PROFILE_COV));
+                     SICP_PROFILE_COV, stream));
   }
   sicp::CovArgs a;
   a.n = n; a.k = k; a.C = with_hist ? P.num_classes : 0;
@@ -373,8 +393,9 @@ int compute_features(sicp_context* h, Cloud& c, bool with_hist) {
   a.float_products = P.quirk_float_products;
   a.nx = c.nx.p; a.ny = c.ny.p; a.nz = c.nz.p;
   a.hist = with_hist ? c.hist.p : nullptr;
-  HIPCHECK(sicp::launch_cov(a, h->stream));
+  HIPCHECK(sicp::launch_cov(a, stream));
   c.feat_valid = true;
+  c.proj_valid = false;
   c.feat_k = k; c.feat_C = with_hist ? P.num_classes : 0;
   c.feat_float_products = P.quirk_float_products;
   c.feat_hist = with_hist;
@@ -437,7 +458,7 @@ int run_correspondences(sicp_context* h, const double* qt, int K, bool weights) 
         if (ts < 0) continue;                    // semantic_icp.hpp:50
         if (!(sn > P.min_class_pts)) continue;   // semantic_icp.hpp:51
       }
-      SICPCHECK(run_nn(h, K, S, so, sn, M, T, ts, false, (float)P.gate_sq, h->idx.p, h->d2.p, SICP_PROFILE_NN));
+      SICPCHECK(run_nn(h, K, S, so, sn, M, T, ts, false, (float)P.gate_sq, h->idx.p, h->d2.p, SICP_PROFILE_NN, h->stream));
       h->st.total_corr += (int64_t)sn * K;
     }
     h->st.t_nn_ms += now_ms() - t0;
@@ -446,14 +467,14 @@ int run_correspondences(sicp_context* h, const double* qt, int K, bool weights) 
   if (weights && P.mode == SICP_MODE_EM) {
     KernelTimer kt(h, SICP_PROFILE_WEIGHT);
     const double t0 = now_ms();
-    SICPCHECK(ensure_hval(h, P.k_cov));
     sicp::WeightArgs a;
     a.n_s = S.n; a.K = K; a.C = P.num_classes;
     a.idx = h->idx.p;
     a.sx = S.x.p; a.sy = S.y.p; a.sz = S.z.p; a.tx = T.x.p; a.ty = T.y.p; a.tz = T.z.p;
     a.snx = S.nx.p; a.sny = S.ny.p; a.snz = S.nz.p; a.tnx = T.nx.p; a.tny = T.ny.p; a.tnz = T.nz.p;
-    a.s_hist = S.hist.p; a.t_hist = T.hist.p;
-    a.cm = h->d_cm.p; a.hval = h->d_hval.p;
+    SICPCHECK(ensure_proj(h, S));
+    SICPCHECK(ensure_proj(h, T));
+    a.s_proj = S.proj.p; a.t_proj = T.proj.p;
     fill_pose(qt, a.pose);
     a.one_m_eps = 1.0 - P.epsilon;
     a.bool_probability = P.quirk_bool_probability;
@@ -470,23 +491,28 @@ int run_correspondences(sicp_context* h, const double* qt, int K, bool weights) 
   return SICP_OK;
 }
 
-int eval28(sicp_context* h, const double* qt, double* out28) {
+void fill_acc(sicp_context* h, sicp::AccArgs& a) {
   const sicp_params& P = h->params;
   Cloud &S = h->cloud[0], &T = h->cloud[1];
-  const int nb = sicp::accumulate_blocks(h->corr_n * h->corr_K);
-  HIPCHECK(h->partials.reserve((size_t)nb * 28));
-  HIPCHECK(h->out28.reserve(28));
-  sicp::AccArgs a;
   a.n_s = h->corr_n; a.K = h->corr_K;
   a.idx = h->idx.p;
   a.w = h->corr_weighted ? h->w.p : nullptr;
   a.sx = S.x.p; a.sy = S.y.p; a.sz = S.z.p; a.tx = T.x.p; a.ty = T.y.p; a.tz = T.z.p;
   a.snx = S.nx.p; a.sny = S.ny.p; a.snz = S.nz.p; a.tnx = T.nx.p; a.tny = T.ny.p; a.tnz = T.nz.p;
-  fill_pose(qt, a.pose);
+  a.lm = nullptr;
   a.one_m_eps = 1.0 - P.epsilon;
   a.loss.cauchy_a = P.cauchy_a;
   a.loss.use_sqloss = P.use_sqloss;
   a.partials = h->partials.p;
+}
+
+int eval28(sicp_context* h, const double* qt, double* out28) {
+  const int nb = sicp::accumulate_blocks(h->corr_n * h->corr_K);
+  HIPCHECK(h->partials.reserve((size_t)nb * 28));
+  HIPCHECK(h->out28.reserve(28));
+  sicp::AccArgs a;
+  fill_acc(h, a);
+  fill_pose(qt, a.pose);
   KernelTimer kt(h, SICP_PROFILE_ACC);
   HIPCHECK(sicp::launch_accumulate(a, h->out28.p, h->stream));
   h->st.acc_launches += 1;
@@ -511,18 +537,57 @@ sicp::LmOptions lm_options(const sicp_params& P) {
   o.min_lm_diagonal = P.min_lm_diagonal;
   o.max_lm_diagonal = P.max_lm_diagonal;
   o.max_consecutive_invalid_steps = P.max_consecutive_invalid_steps;
-  o.jacobi_scaling = P.jacobi_scaling != 0;
+  o.jacobi_scaling = P.jacobi_scaling != 0 ? 1 : 0;
   return o;
 }
 
-int run_solve(sicp_context* h, const double* init_qt, double* out_qt, sicp::LmResult* res) {
-  int hip_status = SICP_OK;
-  auto eval = [&](const double* qt, double* o) {
-    hip_status = eval28(h, qt, o);
-    return hip_status;
-  };
-  *res = sicp::lm_solve(lm_options(h->params), eval, init_qt, out_qt);
-  return hip_status;
+struct SolveResult {
+  int status = 0, iterations = 0, evaluations = 0;
+  double cost = 0;
+};
+
+// the inner ceres::Solve (em_icp.hpp:162-177) on the current correspondences
+int run_solve(sicp_context* h, const double* init_qt, double* out_qt, SolveResult* res) {
+  const sicp_params& P = h->params;
+  if (!P.lm_on_device) {
+    // host loop: one kernel pair + one 224-byte read-back + one synchronisation per evaluation
+    sicp::LmState s;
+    sicp::lm_init(s, lm_options(P), init_qt);
+    while (s.status == sicp::LM_RUNNING) {
+      double o[28];
+      SICPCHECK(eval28(h, s.pose, o));
+      sicp::lm_feed(s, o);
+    }
+    std::memcpy(out_qt, s.x, sizeof s.x);
+    res->status = s.status; res->iterations = s.iterations; res->evaluations = s.evaluations; res->cost = s.cost;
+    return SICP_OK;
+  }
+  // device-resident: the trust-region state stays in HBM; every evaluation is an accumulate kernel
+  // followed by a one-block kernel that feeds the same LM machine; the host polls the status once
+  // per batch.  Launches queued behind a finished solve exit at their first instruction.
+  const int nb = sicp::accumulate_blocks(h->corr_n * h->corr_K);
+  HIPCHECK(h->partials.reserve((size_t)nb * 28));
+  HIPCHECK(h->d_lm.reserve(1));
+  sicp::lm_init(*h->h_lm, lm_options(P), init_qt);
+  HIPCHECK(hipMemcpyAsync(h->d_lm.p, h->h_lm, sizeof(sicp::LmState), hipMemcpyHostToDevice, h->stream));
+  sicp::AccArgs a;
+  fill_acc(h, a);
+  a.lm = h->d_lm.p;
+  const int batch = P.lm_batch > 0 ? P.lm_batch : 12;
+  for (;;) {
+    KernelTimer kt(h, SICP_PROFILE_ACC);
+    for (int b = 0; b < batch; ++b) HIPCHECK(sicp::launch_accumulate_lm(a, h->d_lm.p, h->stream));
+    h->st.acc_launches += batch;
+    h->st.acc_kernel_ms += kt.stop();
+    HIPCHECK(hipMemcpyAsync(h->h_lm, h->d_lm.p, sizeof(sicp::LmState), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    if (h->h_lm->status != sicp::LM_RUNNING) break;
+  }
+  const sicp::LmState& s = *h->h_lm;
+  std::memcpy(out_qt, s.x, sizeof s.x);
+  res->status = s.status; res->iterations = s.iterations; res->evaluations = s.evaluations; res->cost = s.cost;
+  h->st.total_evals += s.evaluations;
+  return SICP_OK;
 }
 
 // statistics only: add the number of live slots of the current search to the device counter
@@ -587,6 +652,8 @@ int sicp_default_params(int mode, sicp_params* p) {
   p->quirk_bool_probability = 1;
   p->quirk_float_products = 1;
   p->nn_method = 1;  // exact box-tree search; 0 = LDS-tiled brute force (same results)
+  p->lm_on_device = 1;
+  p->lm_batch = 12;
   if (mode == SICP_MODE_EM) {
     p->knn = 4; p->cauchy_a = 3.0; p->use_sqloss = 1;  // em_icp.hpp:60,111,115
     p->outer_tol = 1e-5; p->max_outer = 50;            // em_icp.hpp:180
@@ -613,9 +680,12 @@ int sicp_create(int device_id, sicp_handle* out) {
   std::memset(&h->st, 0, sizeof h->st);
   bool ok = hipSetDevice(device_id) == hipSuccess &&
             hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) == hipSuccess &&
+            hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) == hipSuccess &&
             hipEventCreate(&h->ev0) == hipSuccess && hipEventCreate(&h->ev1) == hipSuccess &&
             hipHostMalloc((void**)&h->h_out28, sizeof(double) * 28, hipHostMallocDefault) == hipSuccess &&
-            hipHostMalloc((void**)&h->h_count, sizeof(long long), hipHostMallocDefault) == hipSuccess;
+            hipHostMalloc((void**)&h->h_count, sizeof(long long), hipHostMallocDefault) == hipSuccess &&
+            hipHostMalloc((void**)&h->h_lm, sizeof(sicp::LmState), hipHostMallocDefault) == hipSuccess;
   if (!ok) {
     sicp_destroy(h);
     return SICP_ERR_NO_DEVICE;
@@ -630,8 +700,11 @@ int sicp_destroy(sicp_handle h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->h_out28) (void)hipHostFree(h->h_out28);
   if (h->h_count) (void)hipHostFree(h->h_count);
+  if (h->h_lm) (void)hipHostFree(h->h_lm);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+  if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return SICP_OK;
@@ -695,6 +768,7 @@ int sicp_set_confusion(sicp_handle h, int32_t C, const double* cm) {
   SICPCHECK(set_device(h));
   h->C = C;
   h->cm.assign(cm, cm + (size_t)C * C);
+  h->cloud[0].proj_valid = h->cloud[1].proj_valid = false;
   HIPCHECK(h->d_cm.reserve((size_t)C * C));
   HIPCHECK(hipMemcpyAsync(h->d_cm.p, h->cm.data(), sizeof(double) * C * C, hipMemcpyHostToDevice, h->stream));
   HIPCHECK(hipStreamSynchronize(h->stream));
@@ -718,8 +792,17 @@ int sicp_align(sicp_handle h, const double init_qt[7], double out_qt[7], int32_t
     // em_icp.hpp:28-29 / gicp.hpp:33-34 recompute the covariances on every align(); for
     // SemanticICP they belong to cloud construction (semantic_point_cloud.hpp:25-84)
     const double t0 = now_ms();
+    // the two clouds' feature kernels are independent and latency bound: run them side by side
+    // (not with brute force, which shares one scratch buffer, nor while those kernels are timed)
+    const bool side_by_side = P.nn_method == 1 && !(P.profile & SICP_PROFILE_COV);
     if (!sem || !features_current(h, S, false)) SICPCHECK(compute_features(h, S, em));
-    if (!sem || !features_current(h, T, false)) SICPCHECK(compute_features(h, T, em));
+    if (!sem || !features_current(h, T, false)) {
+      SICPCHECK(compute_features(h, T, em, side_by_side ? h->stream2 : h->stream));
+      if (side_by_side) {
+        HIPCHECK(hipEventRecord(h->ev_join, h->stream2));
+        HIPCHECK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
+      }
+    }
     if (P.profile) HIPCHECK(hipStreamSynchronize(h->stream));
     h->st.t_cov_ms = now_ms() - t0;
   }
@@ -733,7 +816,7 @@ int sicp_align(sicp_handle h, const double init_qt[7], double out_qt[7], int32_t
     SICPCHECK(run_correspondences(h, cur, P.knn, true));
     {
       const double t0 = now_ms();
-      sicp::LmResult r;
+      SolveResult r;
       SICPCHECK(run_solve(h, est, est, &r));
       h->st.total_lm_iters += r.iterations;
       h->st.final_cost = r.cost;
@@ -894,7 +977,7 @@ int sicp_solve(sicp_handle h, const double init_qt[7], double out_qt[7], int32_t
   if (!h || !init_qt || !out_qt) return SICP_ERR_INVALID_ARGUMENT;
   if (!h->corr_valid) return SICP_ERR_NOT_READY;
   SICPCHECK(set_device(h));
-  sicp::LmResult r;
+  SolveResult r;
   SICPCHECK(run_solve(h, init_qt, out_qt, &r));
   if (lm_iters) *lm_iters = r.iterations;
   if (evals) *evals = r.evaluations;
@@ -917,14 +1000,14 @@ int sicp_fused_labels(sicp_handle h, const double qt[7], uint32_t* out_labels) {
   if (!features_current(h, T, true)) SICPCHECK(compute_features(h, T, true));
   SICPCHECK(run_correspondences(h, qt, 4, false));  // K = 4 is a literal here (em_icp.hpp:221)
   h->corr_valid = false;                            // K may differ from params.knn
-  SICPCHECK(ensure_hval(h, P.k_cov));
   sicp::WeightArgs a;
   a.n_s = S.n; a.K = 4; a.C = P.num_classes;
   a.idx = h->idx.p;
   a.sx = S.x.p; a.sy = S.y.p; a.sz = S.z.p; a.tx = T.x.p; a.ty = T.y.p; a.tz = T.z.p;
   a.snx = S.nx.p; a.sny = S.ny.p; a.snz = S.nz.p; a.tnx = T.nx.p; a.tny = T.ny.p; a.tnz = T.nz.p;
-  a.s_hist = S.hist.p; a.t_hist = T.hist.p;
-  a.cm = h->d_cm.p; a.hval = h->d_hval.p;
+  SICPCHECK(ensure_proj(h, S));
+  SICPCHECK(ensure_proj(h, T));
+  a.s_proj = S.proj.p; a.t_proj = T.proj.p;
   fill_pose(qt, a.pose);
   a.one_m_eps = 1.0 - P.epsilon;
   a.bool_probability = P.quirk_bool_probability;

@@ -63,6 +63,12 @@ def nn(request):
     return request.param
 
 
+@pytest.fixture(params=[0, 1], ids=["hostlm", "devicelm"])
+def lm(request):
+    """Host-loop and device-resident inner solve run the same LM machine (csrc/lm.hpp)."""
+    return request.param
+
+
 @pytest.fixture(scope="module")
 def pair1():
     return synth.config1_pair(seed=1, n_per_label=700)
@@ -179,11 +185,11 @@ def test_small_class_divides_by_k_quirk(nn):
 # weights + accumulation
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("mode", [sicp.MODE_GICP, sicp.MODE_EM, sicp.MODE_SEMANTIC])
-def test_weights_and_accumulate_vs_oracle(pair1, mode, nn):
+def test_weights_and_accumulate_vs_oracle(pair1, mode, nn, lm):
     src, sl, tgt, tl, T_gt = pair1
     C = 4
     cm = synth.confusion_matrix(C)
-    e, p = make_engine(mode, C, cm, nn_method=nn)
+    e, p = make_engine(mode, C, cm, nn_method=nn, lm_on_device=lm)
     e.set_source(src, sl)
     e.set_target(tgt, tl)
     qt = mat_to_qt(synth.pose_matrix(1.0, (0, 1, 0), (0.05, 0.0, -0.02)))
@@ -233,16 +239,17 @@ def test_weights_and_accumulate_vs_oracle(pair1, mode, nn):
     rot, tr = pose_delta(est, oest)
     assert rot < 1e-7 and tr < 1e-7
     assert np.isclose(info["cost"], oinfo["cost"], rtol=1e-9)
+    assert info["lm_iters"] == oinfo["lm_iters"]  # same trust-region path as the Ceres-style oracle
 
 
 # ------------------------------------------------------------------------------------------------
 # full align(): the three reference classes
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("mode,key", [(sicp.MODE_GICP, "gicp"), (sicp.MODE_EM, "em"), (sicp.MODE_SEMANTIC, "sem")])
-def test_align_vs_oracle_and_golden(mode, key, nn):
+def test_align_vs_oracle_and_golden(mode, key, nn, lm):
     g = np.load(os.path.join(G, "align.npz"))
     C = 4
-    e, p = make_engine(mode, C, g["cm"], nn_method=nn)
+    e, p = make_engine(mode, C, g["cm"], nn_method=nn, lm_on_device=lm)
     e.set_source(g["src"], g["sl"])
     e.set_target(g["tgt"], g["tl"])
     qt, st = e.align(IDENT)
@@ -334,9 +341,9 @@ def lidar100k():
     return synth.lidar_pair(seed=2, n_points=100_000)
 
 
-def test_metric_size_properties(lidar100k, nn):
+def test_metric_size_properties(lidar100k, nn, lm):
     src, sl, tgt, tl, T_gt, cm = lidar100k
-    e, p = make_engine(sicp.MODE_EM, 11, cm, nn_method=nn)
+    e, p = make_engine(sicp.MODE_EM, 11, cm, nn_method=nn, lm_on_device=lm)
     e.set_source(src, sl)
     e.set_target(tgt, tl)
     # kNN: sorted, gated, self-consistent distances; spot-check rows against the oracle kd-tree
