@@ -449,6 +449,9 @@ __device__ __forceinline__ void corr_eval(const Pose& P, double one_m_eps, doubl
                                           double psz, double nsx, double nsy, double nsz,
                                           double ptx, double pty, double ptz, double ntx,
                                           double nty, double ntz, Corr& o) {
+  // pure float64 algebra with tolerance-level parity (1e-9): fused multiply-adds are welcome here,
+  // unlike in the float32 distance / transform code whose rounding must match the reference's
+#pragma clang fp contract(fast)
   const double* R = P.R;
   const double mx = R[0] * nsx + R[1] * nsy + R[2] * nsz;
   const double my = R[3] * nsx + R[4] * nsy + R[5] * nsz;
@@ -496,6 +499,7 @@ __device__ __forceinline__ void corr_eval(const Pose& P, double one_m_eps, doubl
 // gicp.hpp:98-104, semantic_icp.hpp:96; Ceres CauchyLoss/ScaledLoss/ComposedLoss, sqloss.h).
 // rho2 < 0 for all of them, so Ceres' Corrector scales residual and Jacobian by sqrt(rho1).
 __device__ __forceinline__ void loss_eval(const LossArgs& L, double s, double w, double& rho0, double& rho1) {
+#pragma clang fp contract(fast)
   const double b = L.cauchy_a * L.cauchy_a, c = 1.0 / b;
   if (L.use_sqloss) {
     const double v = s + 2.220446049250313e-16;  // std::numeric_limits<double>::epsilon()
@@ -570,12 +574,13 @@ __device__ __forceinline__ double wave_sum(double v) {
   return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
 }
 
-template <int BS>
+// One lane handles groups of 4 consecutive slots: all index / weight / point / normal loads of the
+// group are issued before the first residual is computed (4 independent gather chains in flight
+// per lane instead of one), then the 28 partial sums are combined across the block through an
+// LDS transpose so that each wave only performs 7 cross-lane reductions.
+template <int K, int BS>
 __global__ __launch_bounds__(BS) void accumulate_kernel(AccArgs a) {
-  __shared__ double red[BS / 64][28];
-  double acc[28];
-#pragma unroll
-  for (int k = 0; k < 28; ++k) acc[k] = 0.0;
+  __shared__ double red[28][BS];
   Pose P;
   if (a.lm) {
     // device-resident solve: the pose to evaluate lives in the LM state; once the solve has
@@ -586,39 +591,71 @@ __global__ __launch_bounds__(BS) void accumulate_kernel(AccArgs a) {
   } else {
     P = a.pose;
   }
-  const int total = a.n_s * a.K;
-  for (int e = blockIdx.x * BS + threadIdx.x; e < total; e += gridDim.x * BS) {
-    const int j = a.idx[e];
-    if (j < 0) continue;
-    const int i = e / a.K;
-    Corr c;
-    corr_eval<true>(P, a.one_m_eps, a.sx[i], a.sy[i], a.sz[i], a.snx[i], a.sny[i], a.snz[i],
-                    a.tx[j], a.ty[j], a.tz[j], a.tnx[j], a.tny[j], a.tnz[j], c);
-    const double w = a.w ? a.w[e] : 1.0;
-    double rho0, rho1;
-    loss_eval(a.loss, c.r * c.r, w, rho0, rho1);
-    int o = 0;
+  double acc[28];
 #pragma unroll
-    for (int p = 0; p < 6; ++p) {
-      const double jp = rho1 * c.J[p];
+  for (int k = 0; k < 28; ++k) acc[k] = 0.0;
+  const int total = a.n_s * K;
+  const int n_groups = (total + 3) >> 2;
+  for (int g = blockIdx.x * BS + threadIdx.x; g < n_groups; g += gridDim.x * BS) {
+    const int e0 = g << 2;
+    int j[4], i[4];
+    double w[4];
+    if (e0 + 3 < total) {
+      const int4 jv = *reinterpret_cast<const int4*>(a.idx + e0);
+      j[0] = jv.x; j[1] = jv.y; j[2] = jv.z; j[3] = jv.w;
+    } else {
 #pragma unroll
-      for (int q = p; q < 6; ++q) acc[o++] += jp * c.J[q];
-      acc[21 + p] += jp * c.r;
+      for (int c = 0; c < 4; ++c) j[c] = e0 + c < total ? a.idx[e0 + c] : -1;
     }
-    acc[27] += 0.5 * rho0;
-  }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float sxv[4], syv[4], szv[4], txv[4], tyv[4], tzv[4];
+    double snx[4], sny[4], snz[4], tnx[4], tny[4], tnz[4];
 #pragma unroll
-  for (int k = 0; k < 28; ++k) {
-    const double s = wave_sum(acc[k]);
-    if (lane == 0) red[wave][k] = s;
+    for (int c = 0; c < 4; ++c) {
+      i[c] = min((e0 + c) / K, a.n_s - 1);
+      const int jj = max(j[c], 0);
+      w[c] = a.w ? a.w[min(e0 + c, total - 1)] : 1.0;
+      if (K != 4 || c == 0) {
+        sxv[c] = a.sx[i[c]]; syv[c] = a.sy[i[c]]; szv[c] = a.sz[i[c]];
+        snx[c] = a.snx[i[c]]; sny[c] = a.sny[i[c]]; snz[c] = a.snz[i[c]];
+      } else {  // K == 4: the four slots of a group share one source point
+        sxv[c] = sxv[0]; syv[c] = syv[0]; szv[c] = szv[0];
+        snx[c] = snx[0]; sny[c] = sny[0]; snz[c] = snz[0];
+      }
+      txv[c] = a.tx[jj]; tyv[c] = a.ty[jj]; tzv[c] = a.tz[jj];
+      tnx[c] = a.tnx[jj]; tny[c] = a.tny[jj]; tnz[c] = a.tnz[jj];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma clang fp contract(fast)
+      if (j[c] < 0) continue;
+      Corr cr;
+      corr_eval<true>(P, a.one_m_eps, sxv[c], syv[c], szv[c], snx[c], sny[c], snz[c], txv[c], tyv[c], tzv[c], tnx[c],
+                      tny[c], tnz[c], cr);
+      double rho0, rho1;
+      loss_eval(a.loss, cr.r * cr.r, w[c], rho0, rho1);
+      int o = 0;
+#pragma unroll
+      for (int p = 0; p < 6; ++p) {
+        const double jp = rho1 * cr.J[p];
+#pragma unroll
+        for (int q = p; q < 6; ++q) acc[o++] += jp * cr.J[q];
+        acc[21 + p] += jp * cr.r;
+      }
+      acc[27] += 0.5 * rho0;
+    }
   }
+  // block reduction: transpose through LDS, then wave w owns outputs w, w + BS/64, ...
+#pragma unroll
+  for (int k = 0; k < 28; ++k) red[k][threadIdx.x] = acc[k];
   __syncthreads();
-  if (threadIdx.x < 28) {
-    double s = 0.0;
+  constexpr int NW = BS / 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int k = wave; k < 28; k += NW) {
+    double sum = 0.0;
 #pragma unroll
-    for (int wv = 0; wv < BS / 64; ++wv) s += red[wv][threadIdx.x];
-    a.partials[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = s;  // [28][blocks]: coalesced for the reducer
+    for (int t = 0; t < NW; ++t) sum += red[k][lane + 64 * t];
+    sum = wave_sum(sum);
+    if (lane == 0) a.partials[(size_t)k * gridDim.x + blockIdx.x] = sum;  // [28][blocks]: coalesced for the reducer
   }
 }
 
@@ -629,8 +666,20 @@ __device__ __forceinline__ void reduce_partials(const double* __restrict__ parti
 #pragma unroll
   for (int k = 0; k < 28; ++k) s[k] = 0.0;
   for (int b = lane; b < n_blocks; b += 64) {
+    // issue all 28 loads of the trip before the first add: left to itself hipcc recycles one
+    // address register and keeps only ~3 loads in flight, which serialises ~200 L2 round trips
+    double v[28];
+    const double* __restrict__ p = partials + b;
 #pragma unroll
-    for (int k = 0; k < 28; ++k) s[k] += partials[(size_t)k * n_blocks + b];
+    for (int k = 0; k < 28; ++k) v[k] = __builtin_nontemporal_load(p + (size_t)k * n_blocks);
+    // one empty asm that "uses" all 28 values: every load has to be issued (and waited for once)
+    // before the adds start
+    asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
+                      "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]));
+    asm volatile("" : "+v"(v[14]), "+v"(v[15]), "+v"(v[16]), "+v"(v[17]), "+v"(v[18]), "+v"(v[19]), "+v"(v[20]), "+v"(v[21]),
+                      "+v"(v[22]), "+v"(v[23]), "+v"(v[24]), "+v"(v[25]), "+v"(v[26]), "+v"(v[27]));
+#pragma unroll
+    for (int k = 0; k < 28; ++k) s[k] += v[k];
   }
 #pragma unroll
   for (int k = 0; k < 28; ++k) o[k] = wave_sum(s[k]);
@@ -812,10 +861,19 @@ int accumulate_blocks(int total) {
   return nb;
 }
 
+static hipError_t launch_accumulate_only(const AccArgs& a, int nb, hipStream_t st) {
+  switch (a.K) {
+    case 1: hipLaunchKernelGGL((accumulate_kernel<1, 256>), dim3(nb), dim3(256), 0, st, a); break;
+    case 4: hipLaunchKernelGGL((accumulate_kernel<4, 256>), dim3(nb), dim3(256), 0, st, a); break;
+    case 20: hipLaunchKernelGGL((accumulate_kernel<20, 256>), dim3(nb), dim3(256), 0, st, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
 hipError_t launch_accumulate(const AccArgs& a, double* out28, hipStream_t st) {
   const int nb = accumulate_blocks(a.n_s * a.K);
-  hipLaunchKernelGGL((accumulate_kernel<256>), dim3(nb), dim3(256), 0, st, a);
-  hipError_t e = hipGetLastError();
+  hipError_t e = launch_accumulate_only(a, nb, st);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, st, a.partials, nb, out28);
   return hipGetLastError();
@@ -823,8 +881,7 @@ hipError_t launch_accumulate(const AccArgs& a, double* out28, hipStream_t st) {
 
 hipError_t launch_accumulate_lm(const AccArgs& a, LmState* lm, hipStream_t st) {
   const int nb = accumulate_blocks(a.n_s * a.K);
-  hipLaunchKernelGGL((accumulate_kernel<256>), dim3(nb), dim3(256), 0, st, a);
-  hipError_t e = hipGetLastError();
+  hipError_t e = launch_accumulate_only(a, nb, st);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(lm_step_kernel, dim3(1), dim3(64), 0, st, lm, a.partials, nb);
   return hipGetLastError();
