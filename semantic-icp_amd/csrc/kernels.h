@@ -123,6 +123,7 @@ int nn_queries_per_thread(int K);
 hipError_t launch_nn_partial(int K, const NNArgs& a, int n_chunks, hipStream_t st);
 hipError_t launch_nn_merge(int K, const MergeArgs& m, hipStream_t st);
 hipError_t launch_bvh_knn(int K, const KnnArgs& a, hipStream_t st);
+hipError_t launch_bvh_knn_quad(int K, const KnnArgs& a, hipStream_t st);
 hipError_t launch_cov(const CovArgs& a, hipStream_t st);
 hipError_t launch_proj(const ProjArgs& a, hipStream_t st);
 hipError_t launch_em_weight(const WeightArgs& a, hipStream_t st);

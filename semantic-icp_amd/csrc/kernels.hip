@@ -323,6 +323,173 @@ __global__ __launch_bounds__(64) void bvh_knn_kernel(KnnArgs a) {
   if (a.dbg) { a.dbg[2 * q] = dbg_nodes; a.dbg[2 * q + 1] = dbg_leaves; }
 }
 
+// Quad-per-query variant of the tree search (the default).  With one query per lane a 100 K-point
+// search is only ~1.5 waves per SIMD and a wave lives as long as its slowest lane (measured: mean
+// wave 172 us, kernel 1040 us at K = 20).  Here the four lanes of a DPP quad share one query: each
+// lane tests one of the four children of a node, scans 4 of a leaf's 16 points into its own partial
+// top-K list, and the pruning bound is the quad-minimum of the four lists' K-th distances (each is
+// a valid upper bound of the true K-th distance).  4x more waves that are 4x shorter: the tail
+// shrinks and there are enough waves to hide memory latency.  The four lists are merged through
+// LDS at the end; keys make the result independent of visiting order, so it is bit-identical to
+// the other engines.
+__device__ __forceinline__ float quad_min(float v) {
+  float o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));  // quad_perm [1,0,3,2]
+  v = fminf(v, o);
+  o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));  // quad_perm [2,3,0,1]
+  return fminf(v, o);
+}
+__device__ __forceinline__ float quad_max(float v) {
+  float o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));
+  v = fmaxf(v, o);
+  o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));
+  return fmaxf(v, o);
+}
+
+// Pruning bound of a quad: an upper bound of the query's true K-th smallest distance from the four
+// partial lists (each the K best of a quarter of the candidates seen so far).
+//   (1) any lane's own K-th distance: its K candidates are among all candidates;
+//   (2) max over lanes of the lane's ceil(K/4)-th distance: 4 * ceil(K/4) >= K candidates lie
+//       within it.  The quarters are a quasi-random split, so (2) is close to the true K-th.
+// +inf stands for "not enough entries yet".
+template <int K>
+__device__ __forceinline__ float quad_bound(const u64 (&bk)[K]) {
+  constexpr int M = (K + 3) / 4;
+  const float own_k = bk[K - 1] == KEY_EMPTY ? INFINITY : key_dist(bk[K - 1]);
+  const float own_m = bk[M - 1] == KEY_EMPTY ? INFINITY : key_dist(bk[M - 1]);
+  return fminf(quad_min(own_k), quad_max(own_m));
+}
+
+template <int K>
+__device__ __forceinline__ void scan_leaf_quad(const float4* __restrict__ pts, float px, float py, float pz, u64 (&bk)[K], float& wd) {
+  float4 t[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) t[p] = pts[4 * p];  // lane s of the quad takes points s, s+4, s+8, s+12: a mixed quarter
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const float d = l2_simple(px, py, pz, t[p].x, t[p].y, t[p].z);
+    if (!(d > wd)) {  // beyond the quad bound it cannot be among the K nearest
+      const u64 key = make_key(d, __float_as_uint(t[p].w));
+      if (key < bk[K - 1]) key_insert<K>(bk, key);
+    }
+  }
+  wd = quad_bound<K>(bk);
+}
+
+__device__ __forceinline__ unsigned child_mask_quad(const float4* __restrict__ blo, const float4* __restrict__ bhi, int child_off,
+                                                    int child_cnt, int parent, int sub, int lane, float px, float py, float pz,
+                                                    float wd) {
+  const int c = parent * kFan + sub;
+  const int node = child_off + min(c, child_cnt - 1);
+  const float lb = box_lb(blo[node], bhi[node], px, py, pz);
+  const bool ok = c < child_cnt && !(lb > wd);  // lb == wd may hide an equal distance with a lower index
+  return (unsigned)(__ballot(ok) >> (lane & ~3)) & 15u;  // the quad's lanes are always in the same control path
+}
+
+template <int K>
+__global__ __launch_bounds__(64) void bvh_knn_quad_kernel(KnnArgs a) {
+  __shared__ int s_off[kMaxLevels], s_cnt[kMaxLevels];
+  __shared__ u64 s_merge[16][4][K];
+  if (threadIdx.x < kMaxLevels) { s_off[threadIdx.x] = a.tree.lv.off[threadIdx.x]; s_cnt[threadIdx.x] = a.tree.lv.cnt[threadIdx.x]; }
+  __syncthreads();
+  const int lane = threadIdx.x, sub = lane & 3, slot = lane >> 2;
+  const int q_raw = blockIdx.x * 16 + slot;
+  const int q = min(q_raw, a.q_count - 1);  // a padding quad repeats the last query and is not emitted
+  float px, py, pz;
+  load_query(a.qx, a.qy, a.qz, a.q_begin + q, a.do_xform, a.M, px, py, pz);
+  u64 bk[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) bk[k] = KEY_EMPTY;
+  float wd = INFINITY;
+  const float4* __restrict__ pts = a.tree.pts4 + a.tree.pt_begin + sub;
+  const float4* __restrict__ blo = a.tree.box_lo + a.tree.node_begin;
+  const float4* __restrict__ bhi = a.tree.box_hi + a.tree.node_begin;
+  const int top = a.tree.lv.n_levels - 1;
+  const int n_leaf = s_cnt[0];
+
+  // --- seed group: the level-1 node next to the query
+  int seed = 0;
+  if (top >= 1) {
+    if (a.self) {
+      seed = (q / kLeaf) / kFan;
+    } else {
+      const u64 qc = curve_code(px, py, pz, a.tree.lo[0], a.tree.lo[1], a.tree.lo[2], a.tree.scale);
+      const u64* __restrict__ codes = a.tree.leaf_code + a.tree.code_begin;
+      int lo_i = 0, hi_i = n_leaf - 1;
+      while (lo_i < hi_i) {
+        const int mid = (lo_i + hi_i + 1) >> 1;
+        if (codes[mid] <= qc) lo_i = mid; else hi_i = mid - 1;
+      }
+      seed = lo_i / kFan;
+    }
+    const int l0 = seed * kFan, l1 = min(l0 + kFan, n_leaf);
+    for (int l = l0; l < l1; ++l) scan_leaf_quad<K>(pts + (size_t)l * kLeaf, px, py, pz, bk, wd);
+  } else {
+    scan_leaf_quad<K>(pts, px, py, pz, bk, wd);
+  }
+
+  // --- depth-first walk (quad-uniform state), while-while so that the wave scans leaves together
+  if (top >= 2) {
+    unsigned masks = 0, masks_hi = 0;
+    auto get = [&](int lv) -> unsigned { return lv < 8 ? (masks >> (4 * lv)) & 15u : (masks_hi >> (4 * (lv - 8))) & 15u; };
+    auto put = [&](int lv, unsigned m) {
+      if (lv < 8) masks = (masks & ~(15u << (4 * lv))) | (m << (4 * lv));
+      else masks_hi = (masks_hi & ~(15u << (4 * (lv - 8)))) | (m << (4 * (lv - 8)));
+    };
+    int L = top - 1, base = 0;
+    put(L, child_mask_quad(blo, bhi, s_off[L], s_cnt[L], 0, sub, lane, px, py, pz, wd));
+    bool done = false;
+    while (!done) {
+      int leaf = -1;
+      while (leaf < 0 && !done) {
+        const unsigned m = get(L);
+        if (m == 0) {
+          if (L == top - 1) { done = true; break; }
+          ++L;
+          base = (base / kFan) & ~(kFan - 1);
+          continue;
+        }
+        const int c = __ffs(m) - 1;
+        put(L, m & (m - 1));
+        const int node = base + c;
+        if (L == 1 && node == seed) continue;
+        if (L == 0) {
+          leaf = node;
+        } else {
+          put(L - 1, child_mask_quad(blo, bhi, s_off[L - 1], s_cnt[L - 1], node, sub, lane, px, py, pz, wd));
+          --L;
+          base = node * kFan;
+        }
+      }
+      if (leaf >= 0) {
+        const int bn = s_off[0] + leaf;
+        if (!(box_lb(blo[bn], bhi[bn], px, py, pz) > wd)) scan_leaf_quad<K>(pts + (size_t)leaf * kLeaf, px, py, pz, bk, wd);
+      }
+    }
+  }
+
+  // --- merge the quad's four ascending lists (LDS), lane 0 of the quad emits
+#pragma unroll
+  for (int k = 0; k < K; ++k) s_merge[slot][sub][k] = bk[k];
+  __syncthreads();
+  if (sub == 0 && q_raw < a.q_count) {
+    int p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+    const size_t o = (size_t)(a.q_begin + q) * K;
+    for (int k = 0; k < K; ++k) {
+      const u64 h0 = p0 < K ? s_merge[slot][0][p0] : KEY_EMPTY, h1 = p1 < K ? s_merge[slot][1][p1] : KEY_EMPTY;
+      const u64 h2 = p2 < K ? s_merge[slot][2][p2] : KEY_EMPTY, h3 = p3 < K ? s_merge[slot][3][p3] : KEY_EMPTY;
+      const u64 m01 = h0 <= h1 ? h0 : h1, m23 = h2 <= h3 ? h2 : h3;
+      const u64 best = m01 <= m23 ? m01 : m23;
+      // keys are unique (caller index), except KEY_EMPTY: advance exactly one list
+      if (best == h0 && p0 < K) ++p0; else if (best == h1 && p1 < K) ++p1; else if (best == h2 && p2 < K) ++p2; else ++p3;
+      const unsigned orig = (unsigned)best;
+      const float d = best == KEY_EMPTY ? INFINITY : key_dist(best);
+      const bool keep = orig != 0xffffffffu && d < a.gate_sq;  // strict <, float compare (em_icp.hpp:65)
+      a.out_i[o + k] = keep ? a.inv[orig] : -1;
+      if (a.out_d) a.out_d[o + k] = d;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // covariance / normal / label histogram from the k-neighbour lists   (em_icp.hpp:298-340)
 // ------------------------------------------------------------------------------------------
@@ -805,6 +972,18 @@ hipError_t launch_nn_merge(int K, const MergeArgs& m, hipStream_t st) {
     case 1: hipLaunchKernelGGL((nn_merge_kernel<1>), grid, dim3(256), 0, st, m); break;
     case 4: hipLaunchKernelGGL((nn_merge_kernel<4>), grid, dim3(256), 0, st, m); break;
     case 20: hipLaunchKernelGGL((nn_merge_kernel<20>), grid, dim3(256), 0, st, m); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_bvh_knn_quad(int K, const KnnArgs& a, hipStream_t st) {
+  if (a.q_count <= 0) return hipSuccess;
+  dim3 grid((a.q_count + 15) / 16);
+  switch (K) {
+    case 1: hipLaunchKernelGGL((bvh_knn_quad_kernel<1>), grid, dim3(64), 0, st, a); break;
+    case 4: hipLaunchKernelGGL((bvh_knn_quad_kernel<4>), grid, dim3(64), 0, st, a); break;
+    case 20: hipLaunchKernelGGL((bvh_knn_quad_kernel<20>), grid, dim3(64), 0, st, a); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

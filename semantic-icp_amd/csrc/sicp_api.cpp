@@ -291,8 +291,10 @@ int run_nn(sicp_context* h, int K, const Cloud& Qc, int q_begin, int q_count, co
     static const bool want_dbg = std::getenv("SICP_KNN_STATS") != nullptr;  // developer aid, off by default
     DevBuf<int> dbg;
     if (want_dbg) { HIPCHECK(dbg.reserve((size_t)2 * q_count)); a.dbg = dbg.p; }
+    static const bool lane_per_query = std::getenv("SICP_KNN_LANE_PER_QUERY") != nullptr;  // A/B aid
     KernelTimer kt(h, stream == h->stream ? timer_bit : 0);
-    HIPCHECK(sicp::launch_bvh_knn(K, a, stream));
+    if (lane_per_query || want_dbg) HIPCHECK(sicp::launch_bvh_knn(K, a, stream));
+    else HIPCHECK(sicp::launch_bvh_knn_quad(K, a, stream));
     account(kt.stop());
     if (want_dbg) {
       std::vector<int> hd((size_t)2 * q_count);
