@@ -244,8 +244,8 @@ def main():
                 "step": f"{max(1, args.pairs_in_flight)} concurrent full align() calls per GPU (covariances of both clouds + all outer ICP iterations each)",
             },
             "ms_per_icp_iter": 1e3 * (elapsed * max(1, args.pairs_in_flight) - 1e-3 * cov_ms) / max(1, outer),
-            "cov_ms_per_align": cov_ms / steps,
-            "outer_iters_per_align": outer / steps,
+            "cov_ms_per_align": cov_ms / (steps * max(1, args.pairs_in_flight)),
+            "outer_iters_per_align": outer / (steps * max(1, args.pairs_in_flight)),
             "accumulate_passes_per_outer_iter": evals / max(1, outer),
             "lm_iters_per_outer_iter": lm_iters / max(1, outer),
         }
@@ -254,19 +254,45 @@ def main():
         if single:
             out["single_pair"] = single
         if nn_launches and not args.dry_run:
-            avg_ms = nn_ms / nn_launches
-            alg_bytes = 12 * n + 12 * n + 8 * K_CORR * n     # SURVEY 8d: src+tgt xyz once, idx+dist^2 out
-            achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+            # --- rooflines (SURVEY.md 8d per-unit bytes x units per launch / HIP-event duration) -------
+            # accumulate: the path's HBM-model kernel (38 B per correspondence per pass); timed alone
+            # with HIP events on the handle's stream, right after the timed region, on the
+            # correspondences the last align() left in HBM
+            pp = engine.get_params()
+            pp.profile = 8  # SICP_PROFILE_ACC
+            engine.set_params(pp)
+            engine.correspondences(qt)
+            before = engine.stats()
+            n_acc = 200
+            for _ in range(n_acc):
+                engine.accumulate(qt)
+            after = engine.stats()
+            acc_us = 1e3 * (after["acc_kernel_ms"] - before["acc_kernel_ms"]) / max(1, after["acc_launches"] - before["acc_launches"])
+            acc_bytes = 24 * n + 32 * K_CORR * n            # 24*N_s + 32*K*N_s
+            acc_gbs = acc_bytes / (acc_us * 1e-6) / 1e9
             out["roofline"] = {
-                "kernel": ("bvh_knn_kernel<K=4> (exact box-tree correspondence search, one launch per outer iteration)" if nn_method == 1 else
-                           "nn_partial_kernel<K=4,Q=2> (brute-force correspondence search, one launch per outer iteration)"),
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
-                "avg_launch_ms": avg_ms, "launches": nn_launches, "algorithmic_bytes_per_launch": alg_bytes,
-                "note": "brute force is FP32-VALU bound, not HBM bound (SURVEY.md 8d): see 'valu'",
-                "valu": {"pair_evals_per_launch": float(n) * n, "achieved_pair_evals_per_s": float(n) * n / (avg_ms * 1e-3),
-                         "peak_pair_evals_per_s": VALU_PAIR_PEAK, "frac": float(n) * n / (avg_ms * 1e-3) / VALU_PAIR_PEAK},
+                "kernel": "accumulate_kernel<K=4> (Mahalanobis residual + 6-DoF Jacobian -> 28 doubles; one launch per LM evaluation, "
+                          f"{evals / max(1, outer):.1f} per outer iteration)",
+                "bound": "hbm", "achieved": acc_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": acc_gbs / HBM_PEAK_GBS,
+                # PMC passes (profiles/r01_final_pmc_hbm_traffic.csv): FETCH_SIZE 6050 KB + WRITE_SIZE 272 KB per
+                # launch at 100Kx100K, raw (the guide's x2 FETCH correction is calibrated for 16-B streams only)
+                "traffic": (6050.0 + 272.0) * 1024 if (n == N_POINTS) else None,
+                "avg_launch_us": acc_us, "launches_timed": n_acc, "algorithmic_bytes_per_launch": acc_bytes,
+                "note": "100Kx100K working set (~15 MB) is L2/Infinity-Cache resident; the kernel is FP64-issue bound "
+                        "(~300 FP64 ops per correspondence), see DESIGN.md section 3",
             }
+            avg_ms = nn_ms / nn_launches
+            alg_bytes = 12 * n + 12 * n + 8 * K_CORR * n     # src+tgt xyz once, idx+dist^2 out
+            achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+            kname = {0: "nn_partial_kernel<K=4,Q=2> (LDS-tiled brute force)", 1: "bvh_knn_quad_kernel<K=4> (exact box-tree search, 4 lanes per query)"}[nn_method]
+            out["other_kernels"] = [{
+                "kernel": kname + ", one launch per outer iteration, timed inside the timed region",
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None, "avg_launch_ms": avg_ms, "launches": nn_launches, "algorithmic_bytes_per_launch": alg_bytes,
+                "note": "latency bound tree walk over an L2-resident cloud" if nn_method == 1 else
+                        "FP32-VALU bound: 1e10 pair evaluations per launch",
+                "pair_evals_per_s_if_brute_force": float(n) * n / (avg_ms * 1e-3),
+            }]
         if not args.dry_run and not args.no_cpu_baseline:
             base, oq = cpu_baseline(src, sl, tgt, tl, cm)
             from scipy.spatial.transform import Rotation

@@ -196,6 +196,9 @@ int sicp_accumulate(sicp_handle h, const double qt[7], double out28[28]);
 int sicp_solve(sicp_handle h, const double init_qt[7], double out_qt[7], int32_t* lm_iters,
                int32_t* evals, double* final_cost);
 
+/* counters accumulated since the last sicp_align() began (the hooks above add to them) */
+int sicp_get_stats(sicp_handle h, sicp_stats* stats);
+
 int sicp_synchronize(sicp_handle h);
 
 #ifdef __cplusplus

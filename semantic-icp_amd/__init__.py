@@ -152,6 +152,7 @@ def lib():
             "sicp_correspondences": [C.c_void_p, _dp, _ip, _fp, _dp],
             "sicp_accumulate": [C.c_void_p, _dp, _dp],
             "sicp_solve": [C.c_void_p, _dp, _dp, _ip, _ip, _dp],
+            "sicp_get_stats": [C.c_void_p, C.POINTER(SicpStats)],
             "sicp_synchronize": [C.c_void_p],
         }.items():
             fn = getattr(_lib, name)
@@ -308,6 +309,11 @@ class Engine:
         it, ev, fc = C.c_int32(), C.c_int32(), C.c_double()
         self._check(lib().sicp_solve(self._h, _ptr(init, _dp), _ptr(out, _dp), C.byref(it), C.byref(ev), C.byref(fc)), "sicp_solve")
         return out, dict(lm_iters=it.value, evals=ev.value, cost=fc.value)
+
+    def stats(self):
+        st = SicpStats()
+        self._check(lib().sicp_get_stats(self._h, C.byref(st)), "sicp_get_stats")
+        return st.as_dict()
 
     def synchronize(self):
         self._check(lib().sicp_synchronize(self._h), "sicp_synchronize")

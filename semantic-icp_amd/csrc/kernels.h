@@ -129,7 +129,8 @@ hipError_t launch_proj(const ProjArgs& a, hipStream_t st);
 hipError_t launch_em_weight(const WeightArgs& a, hipStream_t st);
 hipError_t launch_fused_labels(const WeightArgs& a, uint32_t* out, hipStream_t st);
 int accumulate_blocks(int total);
-hipError_t launch_accumulate(const AccArgs& a, double* out28, hipStream_t st);
+hipError_t launch_accumulate_kernel(const AccArgs& a, hipStream_t st);
+hipError_t launch_finalize(const AccArgs& a, double* out28, hipStream_t st);
 // one evaluation of the device-resident solve: accumulate at lm->pose, then feed the LM machine
 hipError_t launch_accumulate_lm(const AccArgs& a, LmState* lm, hipStream_t st);
 hipError_t launch_count_active(const int* idx, int n, unsigned long long* out, hipStream_t st);

@@ -1050,11 +1050,12 @@ static hipError_t launch_accumulate_only(const AccArgs& a, int nb, hipStream_t s
   return hipGetLastError();
 }
 
-hipError_t launch_accumulate(const AccArgs& a, double* out28, hipStream_t st) {
-  const int nb = accumulate_blocks(a.n_s * a.K);
-  hipError_t e = launch_accumulate_only(a, nb, st);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, st, a.partials, nb, out28);
+hipError_t launch_accumulate_kernel(const AccArgs& a, hipStream_t st) {
+  return launch_accumulate_only(a, accumulate_blocks(a.n_s * a.K), st);
+}
+
+hipError_t launch_finalize(const AccArgs& a, double* out28, hipStream_t st) {
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, st, a.partials, accumulate_blocks(a.n_s * a.K), out28);
   return hipGetLastError();
 }
 
