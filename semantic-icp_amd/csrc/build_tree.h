@@ -1,0 +1,45 @@
+// build_tree.h -- interface of the GPU tree build (build_tree.hip).
+#ifndef SICP_BUILD_TREE_H_
+#define SICP_BUILD_TREE_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "bvh.hpp"
+
+namespace sicp {
+
+// one label segment of a cloud (everything here is derived from point counts on the host)
+struct BuildSegment {
+  int off, cnt;        // device-order range of the segment
+  int padded;          // cnt rounded up to whole leaves (>= one leaf)
+  int pt_begin;        // first packed point
+  int node_begin;      // first box
+  int code_begin;      // first leaf code
+  float lo[3], scale;  // curve quantisation of the segment (bounding box corner, cells per metre)
+  TreeLevels lv;
+};
+
+struct BuildBuffers {
+  // in: the cloud in caller order, and (several segments only) caller indices grouped by segment
+  const float *rx, *ry, *rz;
+  const uint32_t* rl;  // nullable
+  const int* ids;      // nullable = identity
+  // scratch
+  unsigned long long *keys_in, *keys_out;
+  int *vals_in, *vals_out;
+  void* sort_temp;
+  size_t sort_temp_bytes;
+  // out
+  float *x, *y, *z;
+  uint32_t* label;
+  int *perm, *inv;
+  float4 *pts4, *box_lo, *box_hi;
+  unsigned long long* leaf_code;
+};
+
+size_t build_sort_temp_bytes(int max_segment_points);
+hipError_t build_tree_device(const BuildBuffers& b, const BuildSegment* segs, int n_seg, hipStream_t st);
+
+}  // namespace sicp
+#endif

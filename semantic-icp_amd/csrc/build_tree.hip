@@ -1,0 +1,126 @@
+// build_tree.hip -- GPU build of the search structure of one cloud (the role of
+// pcl::KdTreeFLANN::setInputCloud in setSourceCloud / setTargetCloud, em_icp.h:50-66).
+//
+// Per label segment: 63-bit Hilbert index of every point -> stable radix sort of (index, caller
+// index) pairs -> gather into curve order -> exact float boxes of the 16-point leaves -> boxes of
+// the upper levels of the implicit 4-ary tree.  The sort is rocPRIM's device radix sort (the one
+// library primitive in this engine; it is not on the align() path); everything else is written
+// here.  The result is identical to the host build in bvh.hpp (same curve function, stable sort).
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+
+#define SICP_HD __host__ __device__
+#include "build_tree.h"
+
+namespace sicp {
+
+namespace {
+
+__global__ __launch_bounds__(256) void codes_kernel(int cnt, const int* __restrict__ ids, int id_base, const float* __restrict__ rx,
+                                                    const float* __restrict__ ry, const float* __restrict__ rz, float lox, float loy,
+                                                    float loz, float scale, unsigned long long* __restrict__ keys, int* __restrict__ vals) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= cnt) return;
+  const int i = ids ? ids[e] : id_base + e;
+  keys[e] = curve_code(rx[i], ry[i], rz[i], lox, loy, loz, scale);
+  vals[e] = i;
+}
+
+// curve order: SoA + packed points (+ padding) + index maps of one segment
+__global__ __launch_bounds__(256) void gather_kernel(int cnt, int padded, int seg_off, int pt_begin, const int* __restrict__ sorted,
+                                                     const float* __restrict__ rx, const float* __restrict__ ry,
+                                                     const float* __restrict__ rz, const uint32_t* __restrict__ rl, float* __restrict__ x,
+                                                     float* __restrict__ y, float* __restrict__ z, uint32_t* __restrict__ label,
+                                                     int* __restrict__ perm, int* __restrict__ inv, float4* __restrict__ pts4) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= padded) return;
+  if (e < cnt) {
+    const int i = sorted[e];
+    const float px = rx[i], py = ry[i], pz = rz[i];
+    const int d = seg_off + e;
+    x[d] = px; y[d] = py; z[d] = pz;
+    if (rl) label[d] = rl[i];
+    perm[d] = i;
+    inv[i] = d;
+    pts4[pt_begin + e] = make_float4(px, py, pz, __uint_as_float((unsigned)i));
+  } else {
+    pts4[pt_begin + e] = make_float4(INFINITY, INFINITY, INFINITY, __uint_as_float(0xffffffffu));
+  }
+}
+
+__global__ __launch_bounds__(256) void leaf_box_kernel(int n_leaf, int cnt, int pt_begin, int node_begin, int code_begin,
+                                                       const float4* __restrict__ pts4, const unsigned long long* __restrict__ sorted_keys,
+                                                       float4* __restrict__ box_lo, float4* __restrict__ box_hi,
+                                                       unsigned long long* __restrict__ leaf_code) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_leaf) return;
+  float lx = INFINITY, ly = INFINITY, lz = INFINITY, hx = -INFINITY, hy = -INFINITY, hz = -INFINITY;
+  const int e0 = j * kLeaf, e1 = min(cnt, e0 + kLeaf);
+  for (int e = e0; e < e1; ++e) {
+    const float4 p = pts4[pt_begin + e];
+    lx = fminf(lx, p.x); ly = fminf(ly, p.y); lz = fminf(lz, p.z);
+    hx = fmaxf(hx, p.x); hy = fmaxf(hy, p.y); hz = fmaxf(hz, p.z);
+  }
+  box_lo[node_begin + j] = make_float4(lx, ly, lz, 0.f);
+  box_hi[node_begin + j] = make_float4(hx, hy, hz, 0.f);
+  leaf_code[code_begin + j] = e0 < cnt ? sorted_keys[e0] : ~0ull;
+}
+
+__global__ __launch_bounds__(256) void level_box_kernel(int n_nodes, int child_cnt, int node_off, int child_off, float4* __restrict__ box_lo,
+                                                        float4* __restrict__ box_hi) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_nodes) return;
+  float lx = INFINITY, ly = INFINITY, lz = INFINITY, hx = -INFINITY, hy = -INFINITY, hz = -INFINITY;
+  const int c0 = kFan * j, c1 = min(child_cnt, c0 + kFan);
+  for (int c = c0; c < c1; ++c) {
+    const float4 lo = box_lo[child_off + c], hi = box_hi[child_off + c];
+    lx = fminf(lx, lo.x); ly = fminf(ly, lo.y); lz = fminf(lz, lo.z);
+    hx = fmaxf(hx, hi.x); hy = fmaxf(hy, hi.y); hz = fmaxf(hz, hi.z);
+  }
+  box_lo[node_off + j] = make_float4(lx, ly, lz, 0.f);
+  box_hi[node_off + j] = make_float4(hx, hy, hz, 0.f);
+}
+
+}  // namespace
+
+size_t build_sort_temp_bytes(int max_segment_points) {
+  size_t bytes = 0;
+  unsigned long long* k = nullptr;
+  int* v = nullptr;
+  (void)rocprim::radix_sort_pairs(nullptr, bytes, k, k, v, v, (size_t)(max_segment_points > 0 ? max_segment_points : 1), 0, 63,
+                                  (hipStream_t) nullptr);
+  return bytes;
+}
+
+hipError_t build_tree_device(const BuildBuffers& b, const BuildSegment* segs, int n_seg, hipStream_t st) {
+  for (int s = 0; s < n_seg; ++s) {
+    const BuildSegment& g = segs[s];
+    if (g.cnt <= 0) {
+      // an empty segment still owns one padded leaf and one (empty) box
+      if (g.padded > 0)
+        hipLaunchKernelGGL(gather_kernel, dim3((g.padded + 255) / 256), dim3(256), 0, st, 0, g.padded, g.off, g.pt_begin, b.vals_out, b.rx, b.ry,
+                           b.rz, b.rl, b.x, b.y, b.z, b.label, b.perm, b.inv, b.pts4);
+      hipLaunchKernelGGL(leaf_box_kernel, dim3(1), dim3(256), 0, st, g.lv.cnt[0], 0, g.pt_begin, g.node_begin, g.code_begin, b.pts4, b.keys_out,
+                         b.box_lo, b.box_hi, b.leaf_code);
+      continue;
+    }
+    const int* ids = b.ids ? b.ids + g.off : nullptr;
+    hipLaunchKernelGGL(codes_kernel, dim3((g.cnt + 255) / 256), dim3(256), 0, st, g.cnt, ids, g.off, b.rx, b.ry, b.rz, g.lo[0], g.lo[1], g.lo[2],
+                       g.scale, b.keys_in, b.vals_in);
+    size_t tmp = b.sort_temp_bytes;
+    hipError_t e = rocprim::radix_sort_pairs(b.sort_temp, tmp, b.keys_in, b.keys_out, b.vals_in, b.vals_out, (size_t)g.cnt, 0, 63, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(gather_kernel, dim3((g.padded + 255) / 256), dim3(256), 0, st, g.cnt, g.padded, g.off, g.pt_begin, b.vals_out, b.rx, b.ry,
+                       b.rz, b.rl, b.x, b.y, b.z, b.label, b.perm, b.inv, b.pts4);
+    hipLaunchKernelGGL(leaf_box_kernel, dim3((g.lv.cnt[0] + 255) / 256), dim3(256), 0, st, g.lv.cnt[0], g.cnt, g.pt_begin, g.node_begin,
+                       g.code_begin, b.pts4, b.keys_out, b.box_lo, b.box_hi, b.leaf_code);
+    for (int k = 1; k < g.lv.n_levels; ++k)
+      hipLaunchKernelGGL(level_box_kernel, dim3((g.lv.cnt[k] + 255) / 256), dim3(256), 0, st, g.lv.cnt[k], g.lv.cnt[k - 1],
+                         g.node_begin + g.lv.off[k], g.node_begin + g.lv.off[k - 1], b.box_lo, b.box_hi);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace sicp

@@ -16,6 +16,7 @@
 #include <string>
 #include <vector>
 
+#include "build_tree.h"
 #include "kernels.h"
 #include "lm.hpp"
 #include "se3.hpp"
@@ -72,6 +73,12 @@ struct Cloud {
   DevBuf<float4> pts4, box_lo, box_hi;
   DevBuf<unsigned long long> leaf_code;
   DevBuf<int> inv;  // caller index -> device index
+  // build scratch: the cloud as the caller gave it, sort buffers
+  DevBuf<float> rx, ry, rz;
+  DevBuf<uint32_t> rl;
+  DevBuf<int> ids, d_perm, vals_in, vals_out;
+  DevBuf<unsigned long long> keys_in, keys_out;
+  DevBuf<unsigned char> sort_temp;
   DevBuf<double> nx, ny, nz;
   DevBuf<uint8_t> hist;
   DevBuf<double> proj;  // [n][C] label distribution x confusion matrix
@@ -173,88 +180,90 @@ int prepare_cloud(sicp_context* h, Cloud& c) {
   if (want == 1 && !c.has_label) return SICP_ERR_NOT_READY;
   if (c.layout == want) return SICP_OK;
   const int n = c.n;
+  // ---- host: segment membership and per-segment bounding boxes (one pass over the cloud)
   c.seg_label.clear();
-  c.seg_off.clear();
-  std::vector<std::vector<int>> seg_ids;
+  std::vector<int> which(want ? n : 0), counts;
   if (want == 0) {
     c.seg_label.push_back(0);
-    seg_ids.emplace_back(n);
-    for (int i = 0; i < n; ++i) seg_ids[0][i] = i;
+    counts.push_back(n);
   } else {
     // pcl_2_semantic.h:24-39: one sub-cloud per label, labels in order of first appearance
     for (int i = 0; i < n; ++i) {
       int sidx = -1;
       for (size_t k = 0; k < c.seg_label.size(); ++k)
         if (c.seg_label[k] == c.hl[i]) { sidx = (int)k; break; }
-      if (sidx < 0) { sidx = (int)c.seg_label.size(); c.seg_label.push_back(c.hl[i]); seg_ids.emplace_back(); }
-      seg_ids[sidx].push_back(i);
+      if (sidx < 0) { sidx = (int)c.seg_label.size(); c.seg_label.push_back(c.hl[i]); counts.push_back(0); }
+      which[i] = sidx;
+      counts[sidx]++;
     }
   }
-  // Morton order + box tree per segment (the role of setInputCloud's kd-tree build, em_icp.h:50-66)
-  const int n_seg = (int)seg_ids.size();
+  const int n_seg = (int)c.seg_label.size();
+  const float inf = std::numeric_limits<float>::infinity();
+  std::vector<float> lo(3 * n_seg, inf), hi(3 * n_seg, -inf);
+  for (int i = 0; i < n; ++i) {
+    const int sg = want ? which[i] : 0;
+    const float p[3] = {c.hx[i], c.hy[i], c.hz[i]};
+    for (int d = 0; d < 3; ++d) {
+      if (p[d] < lo[3 * sg + d]) lo[3 * sg + d] = p[d];
+      if (p[d] > hi[3 * sg + d]) hi[3 * sg + d] = p[d];
+    }
+  }
   c.seg_off.assign(n_seg + 1, 0);
   c.trees.assign(n_seg, Cloud::SegTree());
-  c.perm.resize(n);
-  std::vector<float4> pts4, blo, bhi;
-  std::vector<unsigned long long> codes;
-  const float inf = std::numeric_limits<float>::infinity();
-  float4 pad;
-  pad.x = pad.y = pad.z = inf;
-  { const unsigned m1 = 0xffffffffu; std::memcpy(&pad.w, &m1, 4); }
+  std::vector<sicp::BuildSegment> segs(n_seg);
+  int pt_total = 0, node_total = 0, code_total = 0, max_cnt = 1;
   for (int sg = 0; sg < n_seg; ++sg) {
-    sicp::HostTree t;
-    sicp::build_segment_tree(c.hx.data(), c.hy.data(), c.hz.data(), seg_ids[sg], t);
-    const int cnt = (int)seg_ids[sg].size(), o = c.seg_off[sg];
-    c.seg_off[sg + 1] = o + cnt;
+    sicp::BuildSegment& g = segs[sg];
+    g.off = c.seg_off[sg]; g.cnt = counts[sg];
+    c.seg_off[sg + 1] = g.off + g.cnt;
+    g.padded = std::max(1, (g.cnt + sicp::kLeaf - 1) / sicp::kLeaf) * sicp::kLeaf;
+    g.lv = sicp::make_levels(g.cnt);
+    g.pt_begin = pt_total; g.node_begin = node_total; g.code_begin = code_total;
+    pt_total += g.padded; node_total += sicp::total_nodes(g.lv); code_total += g.lv.cnt[0];
+    float ext = 0.f;
+    for (int d = 0; d < 3; ++d) { g.lo[d] = g.cnt > 0 ? lo[3 * sg + d] : 0.f; if (g.cnt > 0) ext = std::max(ext, hi[3 * sg + d] - lo[3 * sg + d]); }
+    if (!(ext > 0.f) || !std::isfinite(ext)) ext = 1.f;
+    g.scale = 2097151.f / ext;
+    max_cnt = std::max(max_cnt, g.cnt);
     Cloud::SegTree& st = c.trees[sg];
-    st.lv = t.lv; st.n = cnt;
-    st.pt_begin = (int)pts4.size(); st.node_begin = (int)blo.size(); st.code_begin = (int)codes.size();
-    st.lo[0] = t.lo[0]; st.lo[1] = t.lo[1]; st.lo[2] = t.lo[2]; st.scale = t.scale;
-    for (int e = 0; e < cnt; ++e) {
-      const int i = seg_ids[sg][e];
-      c.perm[o + e] = i;
-      float4 v;
-      v.x = c.hx[i]; v.y = c.hy[i]; v.z = c.hz[i];
-      const unsigned ui = (unsigned)i;
-      std::memcpy(&v.w, &ui, 4);
-      pts4.push_back(v);
-    }
-    const int padded = std::max(1, (cnt + sicp::kLeaf - 1) / sicp::kLeaf) * sicp::kLeaf;
-    for (int e = cnt; e < padded; ++e) pts4.push_back(pad);
-    for (int k = 0; k < t.total_nodes(); ++k) {
-      float4 l, u;
-      l.x = t.box_lo[4 * k]; l.y = t.box_lo[4 * k + 1]; l.z = t.box_lo[4 * k + 2]; l.w = 0;
-      u.x = t.box_hi[4 * k]; u.y = t.box_hi[4 * k + 1]; u.z = t.box_hi[4 * k + 2]; u.w = 0;
-      blo.push_back(l); bhi.push_back(u);
-    }
-    codes.insert(codes.end(), t.leaf_code.begin(), t.leaf_code.end());
+    st.lv = g.lv; st.n = g.cnt; st.pt_begin = g.pt_begin; st.node_begin = g.node_begin; st.code_begin = g.code_begin;
+    st.lo[0] = g.lo[0]; st.lo[1] = g.lo[1]; st.lo[2] = g.lo[2]; st.scale = g.scale;
   }
-  std::vector<float> gx(n), gy(n), gz(n);
-  std::vector<uint32_t> gl(c.has_label ? n : 0);
-  std::vector<int> inv(n);
-  for (int d = 0; d < n; ++d) {
-    const int i = c.perm[d];
-    gx[d] = c.hx[i]; gy[d] = c.hy[i]; gz[d] = c.hz[i];
-    if (c.has_label) gl[d] = c.hl[i];
-    inv[i] = d;
+  std::vector<int> ids;
+  if (want) {  // caller indices grouped by segment, cloud order inside a segment
+    ids.resize(n);
+    std::vector<int> fill(c.seg_off.begin(), c.seg_off.end() - 1);
+    for (int i = 0; i < n; ++i) ids[fill[which[i]]++] = i;
   }
+  // ---- device: upload the caller-order cloud, build curve order + boxes (build_tree.hip)
   const size_t m = (size_t)(n > 0 ? n : 1);
+  HIPCHECK(c.rx.reserve(m)); HIPCHECK(c.ry.reserve(m)); HIPCHECK(c.rz.reserve(m)); HIPCHECK(c.rl.reserve(m));
+  HIPCHECK(c.ids.reserve(m)); HIPCHECK(c.d_perm.reserve(m));
+  HIPCHECK(c.keys_in.reserve((size_t)max_cnt)); HIPCHECK(c.keys_out.reserve((size_t)max_cnt));
+  HIPCHECK(c.vals_in.reserve((size_t)max_cnt)); HIPCHECK(c.vals_out.reserve((size_t)max_cnt));
+  const size_t temp_bytes = sicp::build_sort_temp_bytes(max_cnt);
+  HIPCHECK(c.sort_temp.reserve(temp_bytes + 256));
   HIPCHECK(c.x.reserve(m)); HIPCHECK(c.y.reserve(m)); HIPCHECK(c.z.reserve(m));
   HIPCHECK(c.label.reserve(m)); HIPCHECK(c.inv.reserve(m));
-  HIPCHECK(c.pts4.reserve(pts4.size() + 1)); HIPCHECK(c.box_lo.reserve(blo.size() + 1));
-  HIPCHECK(c.box_hi.reserve(bhi.size() + 1)); HIPCHECK(c.leaf_code.reserve(codes.size() + 1));
+  HIPCHECK(c.pts4.reserve((size_t)pt_total + 1)); HIPCHECK(c.box_lo.reserve((size_t)node_total + 1));
+  HIPCHECK(c.box_hi.reserve((size_t)node_total + 1)); HIPCHECK(c.leaf_code.reserve((size_t)code_total + 1));
   auto up = [&](void* dst, const void* src, size_t bytes) {
     return bytes ? hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream) : hipSuccess;
   };
-  HIPCHECK(up(c.x.p, gx.data(), sizeof(float) * n));
-  HIPCHECK(up(c.y.p, gy.data(), sizeof(float) * n));
-  HIPCHECK(up(c.z.p, gz.data(), sizeof(float) * n));
-  if (c.has_label) HIPCHECK(up(c.label.p, gl.data(), sizeof(uint32_t) * n));
-  HIPCHECK(up(c.inv.p, inv.data(), sizeof(int) * n));
-  HIPCHECK(up(c.pts4.p, pts4.data(), sizeof(float4) * pts4.size()));
-  HIPCHECK(up(c.box_lo.p, blo.data(), sizeof(float4) * blo.size()));
-  HIPCHECK(up(c.box_hi.p, bhi.data(), sizeof(float4) * bhi.size()));
-  HIPCHECK(up(c.leaf_code.p, codes.data(), sizeof(unsigned long long) * codes.size()));
+  HIPCHECK(up(c.rx.p, c.hx.data(), sizeof(float) * n));
+  HIPCHECK(up(c.ry.p, c.hy.data(), sizeof(float) * n));
+  HIPCHECK(up(c.rz.p, c.hz.data(), sizeof(float) * n));
+  if (c.has_label) HIPCHECK(up(c.rl.p, c.hl.data(), sizeof(uint32_t) * n));
+  if (want) HIPCHECK(up(c.ids.p, ids.data(), sizeof(int) * n));
+  sicp::BuildBuffers b;
+  b.rx = c.rx.p; b.ry = c.ry.p; b.rz = c.rz.p; b.rl = c.has_label ? c.rl.p : nullptr; b.ids = want ? c.ids.p : nullptr;
+  b.keys_in = c.keys_in.p; b.keys_out = c.keys_out.p; b.vals_in = c.vals_in.p; b.vals_out = c.vals_out.p;
+  b.sort_temp = c.sort_temp.p; b.sort_temp_bytes = temp_bytes;
+  b.x = c.x.p; b.y = c.y.p; b.z = c.z.p; b.label = c.label.p; b.perm = c.d_perm.p; b.inv = c.inv.p;
+  b.pts4 = c.pts4.p; b.box_lo = c.box_lo.p; b.box_hi = c.box_hi.p; b.leaf_code = c.leaf_code.p;
+  HIPCHECK(sicp::build_tree_device(b, segs.data(), n_seg, h->stream));
+  c.perm.resize(n);  // device -> caller order, for returning results in the caller's order
+  if (n > 0) HIPCHECK(hipMemcpyAsync(c.perm.data(), c.d_perm.p, sizeof(int) * n, hipMemcpyDeviceToHost, h->stream));
   HIPCHECK(hipStreamSynchronize(h->stream));  // staging vectors go out of scope
   c.layout = want;
   c.feat_valid = false;
@@ -262,7 +271,6 @@ int prepare_cloud(sicp_context* h, Cloud& c) {
   return SICP_OK;
 }
 
-// ---- brute-force kNN driver -------------------------------------------------------------------
 // queries: points [q_begin, q_begin+q_count) of cloud Q (device order), optionally transformed
 // by M34; targets: segment `tseg` of cloud T.  Writes device indices of T (or -1) and distances.
 int run_nn(sicp_context* h, int K, const Cloud& Qc, int q_begin, int q_count, const double* M34, const Cloud& Tc,
