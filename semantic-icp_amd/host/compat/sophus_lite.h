@@ -45,6 +45,32 @@ class SE3d {
   }
   static SE3d fromData(const double* qt) { SE3d s; std::memcpy(s.d_, qt, sizeof s.d_); return s; }
 
+  // Sophus::SE3::fitToSE3 (used by exec/kitti_metrics.h:24): closest rotation to the 3x3 block.
+  // Sophus takes U V^T of an SVD; the Newton polar iteration R <- (R + R^-T)/2 converges to the same
+  // orthogonal factor for the nearly orthonormal matrices pose files hold.
+  static SE3d fitToSE3(const Eigen::Matrix4d& T) {
+    double R[9];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R[3 * i + j] = T(i, j);
+    for (int it = 0; it < 30; ++it) {
+      const double c00 = R[4] * R[8] - R[5] * R[7], c01 = R[5] * R[6] - R[3] * R[8], c02 = R[3] * R[7] - R[4] * R[6];
+      const double det = R[0] * c00 + R[1] * c01 + R[2] * c02;
+      if (!(std::fabs(det) > 0)) break;
+      const double inv = 1.0 / det;
+      // inverse transpose = cofactor matrix / det
+      const double C[9] = {c00, c01, c02,
+                           R[2] * R[7] - R[1] * R[8], R[0] * R[8] - R[2] * R[6], R[1] * R[6] - R[0] * R[7],
+                           R[1] * R[5] - R[2] * R[4], R[2] * R[3] - R[0] * R[5], R[0] * R[4] - R[1] * R[3]};
+      double delta = 0;
+      for (int i = 0; i < 9; ++i) { const double n = 0.5 * (R[i] + C[i] * inv); delta += std::fabs(n - R[i]); R[i] = n; }
+      if (delta < 1e-15) break;
+    }
+    Eigen::Matrix4d M = T;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) M(i, j) = R[3 * i + j];
+    return SE3d(M);
+  }
+  // rotation part of log(): what `so3().log()` yields in exec/kitti_metrics.h:35
+  Eigen::Vector3d rotationLog() const { Tangent t = log(); return Eigen::Vector3d(t(3), t(4), t(5)); }
+
   double* data() { return d_; }              // [qx qy qz qw tx ty tz], Sophus storage order
   const double* data() const { return d_; }
 

@@ -1,0 +1,118 @@
+// eval_support.h -- host helpers of the headless eval drivers: the pieces of exec/csv.h,
+// exec/read_confusion_matrix.h, exec/filter_range.h and exec/kitti_metrics.h that the drivers need,
+// re-implemented on the compat types (reference definitions cited at each function).
+#ifndef SICP_EVAL_SUPPORT_H_
+#define SICP_EVAL_SUPPORT_H_
+#include <dirent.h>
+
+#include <algorithm>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "sicp_engine.hpp"
+
+namespace evalsupport {
+
+// rows of space separated cells (exec/csv.h:17-47 splits on ' ')
+inline std::vector<std::vector<std::string>> read_rows(const std::string& path) {
+  std::vector<std::vector<std::string>> rows;
+  std::ifstream f(path);
+  std::string line;
+  while (std::getline(f, line)) {
+    std::vector<std::string> cells;
+    std::stringstream ss(line);
+    std::string cell;
+    while (std::getline(ss, cell, ' ')) if (!cell.empty()) cells.push_back(cell);
+    if (!cells.empty()) rows.push_back(cells);
+  }
+  return rows;
+}
+
+// exec/read_confusion_matrix.h:6-19
+template <int N>
+Eigen::Matrix<double, N, N> ReadConfusionMatrix(const std::string& file_name) {
+  Eigen::Matrix<double, N, N> out;
+  const auto rows = read_rows(file_name);
+  for (size_t j = 0; j < rows.size() && j < (size_t)N; ++j)
+    for (size_t k = 0; k < rows[j].size() && k < (size_t)N; ++k) out((int)j, (int)k) = std::stod(rows[j][k]);
+  return out;
+}
+
+// exec/filter_range.h:6-18: drop points farther than `range` (strict >), order preserved
+inline void filterRange(pcl::PointCloud<pcl::PointXYZL>::Ptr cloud, const double range) {
+  std::vector<pcl::PointXYZL> keep;
+  keep.reserve(cloud->size());
+  for (const auto& pt : cloud->points)
+    if (!((pt.x * pt.x + pt.y * pt.y + pt.z * pt.z) > range * range)) keep.push_back(pt);
+  cloud->points.swap(keep);
+  cloud->width = (uint32_t)cloud->points.size();
+  cloud->height = 1;
+}
+
+// exec/kitti_eval.cc:25-43
+inline std::vector<std::string> get_pcd_in_dir(const std::string& dir_name) {
+  std::vector<std::string> out;
+  if (DIR* d = opendir(dir_name.c_str())) {
+    while (struct dirent* e = readdir(d)) {
+      const size_t len = std::strlen(e->d_name);
+      if (len >= 4 && std::strcmp(e->d_name + len - 4, ".pcd") == 0) out.push_back(dir_name + "/" + e->d_name);
+    }
+    closedir(d);
+  }
+  std::sort(out.begin(), out.end());  // exec/kitti_eval.cc:87
+  return out;
+}
+
+// exec/kitti_metrics.h:6-118: ground-truth poses (12 numbers per row -> fitToSE3), the error of an
+// estimate against poseA^-1 * poseB, and one CSV row per evaluation in the reference's column order:
+//   idA, idB, ||log(dT)||^2, ||rot log(dT)||^2, ||trans(dT)||^2, time, dT (16, row major), T (16), outer
+// (time is written in seconds as a real number; the reference truncates it to whole seconds)
+class KittiMetrics {
+ public:
+  explicit KittiMetrics(const std::string& gtFileName, std::ostream* out = &std::cout) : out_(out) {
+    for (const auto& row : read_rows(gtFileName)) {
+      Eigen::Matrix4d mat = Eigen::Matrix4d::Identity();
+      for (size_t n = 0; n < row.size() && n < 12; ++n) mat((int)(n / 4), (int)(n % 4)) = std::stod(row[n]);
+      gtPoses_.push_back(Sophus::SE3d::fitToSE3(mat));
+    }
+  }
+  size_t numPoses() const { return gtPoses_.size(); }
+  Sophus::SE3d getGTtransfrom(size_t poseIDA, size_t poseIDB) const { return gtPoses_[poseIDA].inverse() * gtPoses_[poseIDB]; }
+  double evaluate(const Sophus::SE3d& transform, size_t poseIDA, size_t poseIDB, double timeSeconds, int outer_iter) {
+    const Sophus::SE3d diff = getGTtransfrom(poseIDA, poseIDB) * transform.inverse();
+    const double transformError = diff.log().squaredNorm();
+    const double rotError = diff.rotationLog().squaredNorm();
+    const double transError = diff.translation().squaredNorm();
+    transformMSE_ += transformError; rotMSE_ += rotError; transMSE_ += transError; count_++;
+    std::ostream& o = *out_;
+    o.precision(17);
+    o << poseIDA << ", " << poseIDB << ", " << transformError << ", " << rotError << ", " << transError << ", " << timeSeconds;
+    const Eigen::Matrix4d a = diff.matrix(), b = transform.matrix();
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) o << ", " << a(i, j);
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) o << ", " << b(i, j);
+    o << ", " << outer_iter << std::endl;
+    return transformError;
+  }
+  double getTransformMSE() const { return transformMSE_ / double(count_); }
+  double getRotMSE() const { return rotMSE_ / double(count_); }
+  double getTransMSE() const { return transMSE_ / double(count_); }
+
+ private:
+  std::vector<Sophus::SE3d> gtPoses_;
+  double transformMSE_ = 0, rotMSE_ = 0, transMSE_ = 0;
+  size_t count_ = 0;
+  std::ostream* out_;
+};
+
+inline const char* arg(int argc, char** argv, const char* flag) {
+  for (int i = 1; i + 1 < argc; ++i)
+    if (!std::strcmp(argv[i], flag)) return argv[i + 1];
+  return nullptr;
+}
+
+}  // namespace evalsupport
+#endif

@@ -180,6 +180,29 @@ def lidar_pair(seed: int = 2, n_points: int | None = None, C: int = 11, n_az: in
     return out[0], out[1], out[2], out[3], T_gt, cm
 
 
+def lidar_sequence(seed: int = 5, n_scans: int = 7, n_points: int | None = 20000, C: int = 11, n_az: int = 2250,
+                   max_range: float = 40.0, sigma: float = 0.01, label_noise: float = 0.10, step=(1.0 / 3.0, 2.0 / 3.0)):
+    """KITTI-odometry-like sequence (config 5 stand-in): the sensor of config 2 moves `step[0]` m
+    forward and yaws `step[1]` deg per scan.  Returns [(xyz, labels)], world poses (n,4,4), cm.
+    The reference's driver registers scan n+3 (source) onto scan n (target), exec/kitti_eval.cc:124-129."""
+    rng = np.random.default_rng(seed)
+    boxes, poles = _street(rng)
+    cm = confusion_matrix(C)
+    pose = np.eye(4); pose[:3, 3] = (-3.0, 0.3, 1.73)
+    inc = pose_matrix(step[1], (0, 0, 1), (step[0], 0.0, 0.0))
+    scans, poses = [], []
+    for _ in range(n_scans):
+        p, l = _lidar_scan(rng, pose, boxes, poles, n_az, max_range, sigma)
+        l = _noisy_labels(rng, l, cm, label_noise)
+        if n_points is not None:
+            sel = np.sort(rng.choice(p.shape[0], n_points, replace=False))
+            p, l = p[sel], l[sel]
+        scans.append((p.astype(np.float32), l.astype(np.uint32)))
+        poses.append(pose.copy())
+        pose = pose @ inc
+    return scans, np.stack(poses), cm
+
+
 # -----------------------------------------------------------------------------
 # config 3: RGB-D frame pair of a box room (pinhole depth render)
 # -----------------------------------------------------------------------------

@@ -17,12 +17,12 @@ HOST = os.path.join(ROOT, "semantic-icp_amd", "host")
 sicp = importlib.import_module("semantic-icp_amd")
 
 
-def build_example(tmp_path):
+def build_example(tmp_path, name="test_icp_headless"):
     sicp.build()
-    exe = str(tmp_path / "test_icp_headless")
+    exe = str(tmp_path / name)
     cmd = [
         "g++", "-std=c++17", "-O2", "-DEM_CLASSES=4", "-I", os.path.join(ROOT, "include"), "-I", HOST,
-        os.path.join(HOST, "examples", "test_icp_headless.cc"), "-L", os.path.join(ROOT, "semantic-icp_amd"), "-lsicp",
+        os.path.join(HOST, "examples", name + ".cc"), "-L", os.path.join(ROOT, "semantic-icp_amd"), "-lsicp",
         "-Wl,-rpath," + os.path.join(ROOT, "semantic-icp_amd"), "-Wl,-rpath,/opt/rocm/lib", "-o", exe,
     ]
     subprocess.run(cmd, check=True, capture_output=True)
@@ -103,3 +103,66 @@ def test_headless_test_icp_matches_oracle(tmp_path, binary):
     oq, ost = O.align(p, src, sl, tgt, tl, cm, ident)
     rot, tr = pose_delta(got["EM"][0], oq)
     assert rot < 1e-7 and tr < 1e-7 and got["EM"][1] == ost["outer_iters"]
+
+
+# ------------------------------------------------------------------------------------------------
+# f2: headless kitti_eval (exec/kitti_eval.cc:124-249 + exec/kitti_metrics.h)
+# ------------------------------------------------------------------------------------------------
+def make_sequence(tmp_path, n_scans=7, n_points=6000):
+    scans, poses, cm = synth.lidar_sequence(seed=5, n_scans=n_scans, n_points=n_points)
+    d = tmp_path / "seq"
+    d.mkdir()
+    for k, (p, l) in enumerate(scans):
+        # one point beyond 40 m: the driver's range filter must drop it (exec/filter_range.h)
+        p2 = np.concatenate([p, np.array([[45.0, 1.0, 0.0]], dtype=np.float32)])
+        l2 = np.concatenate([l, np.array([1], dtype=np.uint32)])
+        write_pcd(str(d / f"{k:06d}.pcd"), p2, l2, binary=True)
+    gt = str(tmp_path / "poses.txt")
+    np.savetxt(gt, poses[:, :3, :].reshape(n_scans, 12), fmt="%.17g")
+    cmf = str(tmp_path / "cm.txt")
+    np.savetxt(cmf, cm, fmt="%.17g")
+    return scans, poses, cm, str(d), gt, cmf
+
+
+def test_kitti_eval_compiles_and_fails_loudly_without_gpu(tmp_path):
+    exe = build_example(tmp_path, "kitti_eval_headless")
+    if os.path.exists("/dev/kfd"):
+        pytest.skip("GPU present")
+    _, _, _, d, gt, cmf = make_sequence(tmp_path, n_scans=4, n_points=500)
+    r = subprocess.run([exe, "-s", d, "-t", gt, "-m", cmf, "-o", str(tmp_path / "out_")], capture_output=True, text=True)
+    assert r.returncode == 2 and "no usable HIP device" in r.stderr
+
+
+@pytest.mark.gpu
+def test_kitti_eval_headless_rows_match_oracle(tmp_path):
+    exe = build_example(tmp_path, "kitti_eval_headless")
+    scans, poses, cm, d, gt, cmf = make_sequence(tmp_path)
+    prefix = str(tmp_path / "out_")
+    r = subprocess.run([exe, "-s", d, "-t", gt, "-m", cmf, "-o", prefix], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr
+    ident = np.array([0, 0, 0, 1, 0, 0, 0.0])
+    for fname, mode in (("EMICPkitti.csv", O.MODE_EM), ("se3GICPkitti.csv", O.MODE_GICP)):
+        rows = [[float(v) for v in line.split(",")] for line in open(prefix + fname) if line.strip()]
+        assert [int(r_[0]) for r_ in rows] == [0, 3] and [int(r_[1]) for r_ in rows] == [3, 6]  # stride-3 pairs
+        for row in rows:
+            a, b = int(row[0]), int(row[1])
+            assert len(row) == 6 + 16 + 16 + 1
+            T_est = np.array(row[22:38]).reshape(4, 4)
+            dT = np.array(row[6:22]).reshape(4, 4)
+            T_gt = np.linalg.inv(poses[a]) @ poses[b]
+            assert np.allclose(dT, T_gt @ np.linalg.inv(T_est), atol=1e-9)
+            rv = Rotation.from_matrix(dT[:3, :3]).as_rotvec()
+            assert np.isclose(row[3], rv @ rv, rtol=1e-6, atol=1e-15) and np.isclose(row[4], dT[:3, 3] @ dT[:3, 3], rtol=1e-9)
+            assert row[2] < 1e-4  # registers the pair: ||log(T_gt T^-1)||^2
+            # same inputs through the oracle (EM sees the range-filtered cloud, GICP the raw file)
+            p = O.default_params(mode)
+            p.num_classes = 11
+            (ps, ls), (pt, lt) = scans[b], scans[a]
+            if mode == O.MODE_GICP:
+                far = np.array([[45.0, 1.0, 0.0]], dtype=np.float32)
+                ps, pt = np.concatenate([ps, far]), np.concatenate([pt, far])
+            oq, ost = O.align(p, ps, ls if mode == O.MODE_EM else None, pt, lt if mode == O.MODE_EM else None,
+                              cm if mode == O.MODE_EM else None, ident)
+            D = np.linalg.inv(O.se3_matrix(oq)) @ T_est
+            assert np.linalg.norm(Rotation.from_matrix(D[:3, :3]).as_rotvec()) < 1e-7 and np.linalg.norm(D[:3, 3]) < 1e-7
+            assert int(row[38]) == ost["outer_iters"]
