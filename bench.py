@@ -53,7 +53,9 @@ def parse_args():
     ap.add_argument("--lm-batch", type=int, default=None)
     ap.add_argument("--pairs-in-flight", type=int, default=4,
                     help="independent scan pairs registered concurrently on each GPU (one handle + host thread each)")
-    ap.add_argument("--profile", type=int, default=1, help="SICP_PROFILE_* mask (1 = NN kernel only; 8 adds the accumulate kernels)")
+    ap.add_argument("--profile", type=int, default=0,
+                    help="SICP_PROFILE_* mask applied inside the timed region (default 0: the roofline kernels are timed with "
+                         "HIP events right after it, on the same data and streams)")
     ap.add_argument("--dry-run", action="store_true", help="exercise the multi-process plumbing without a GPU")
     return ap.parse_args()
 
@@ -149,7 +151,7 @@ def main():
             raise SystemExit("bench.py: no HIP device visible (there is no CPU fallback)")
         p = sicp.default_params(sicp.MODE_EM)
         p.num_classes = N_CLASSES
-        p.profile = args.profile  # default SICP_PROFILE_NN: HIP events around the dominant kernel, on its own stream
+        p.profile = args.profile
         if args.nn_method is not None:
             p.nn_method = args.nn_method
         if args.lm_on_device is not None:
@@ -253,15 +255,22 @@ def main():
             out["accumulate_kernel_us_per_launch"] = 1e3 * acc_ms / max(1, acc_launches)
         if single:
             out["single_pair"] = single
-        if nn_launches and not args.dry_run:
+        if not args.dry_run:
             # --- rooflines (SURVEY.md 8d per-unit bytes x units per launch / HIP-event duration) -------
             # accumulate: the path's HBM-model kernel (38 B per correspondence per pass); timed alone
             # with HIP events on the handle's stream, right after the timed region, on the
             # correspondences the last align() left in HBM
             pp = engine.get_params()
+            pp.profile = 1  # SICP_PROFILE_NN: the correspondence-search kernel, 20 launches at the final pose
+            engine.set_params(pp)
+            b0 = engine.stats()
+            for _ in range(20):
+                engine.correspondences(qt)
+            b1 = engine.stats()
+            nn_ms = b1["nn_kernel_ms"] - b0["nn_kernel_ms"]
+            nn_launches = b1["nn_launches"] - b0["nn_launches"]
             pp.profile = 8  # SICP_PROFILE_ACC
             engine.set_params(pp)
-            engine.correspondences(qt)
             before = engine.stats()
             n_acc = 200
             for _ in range(n_acc):
@@ -286,7 +295,7 @@ def main():
             achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
             kname = {0: "nn_partial_kernel<K=4,Q=2> (LDS-tiled brute force)", 1: "bvh_knn_quad_kernel<K=4> (exact box-tree search, 4 lanes per query)"}[nn_method]
             out["other_kernels"] = [{
-                "kernel": kname + ", one launch per outer iteration, timed inside the timed region",
+                "kernel": kname + ", one launch per outer iteration; timed with HIP events right after the timed region",
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None, "avg_launch_ms": avg_ms, "launches": nn_launches, "algorithmic_bytes_per_launch": alg_bytes,
                 "note": "latency bound tree walk over an L2-resident cloud" if nn_method == 1 else

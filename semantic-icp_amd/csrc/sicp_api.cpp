@@ -688,7 +688,7 @@ int sicp_default_params(int mode, sicp_params* p) {
   p->quirk_float_products = 1;
   p->nn_method = 1;  // exact box-tree search; 0 = LDS-tiled brute force (same results)
   p->lm_on_device = 1;
-  p->lm_batch = 16;
+  p->lm_batch = 8;   // 16 kernel nodes per graph: longer graphs replay with a ~50 us bubble every 16 nodes
   if (mode == SICP_MODE_EM) {
     p->knn = 4; p->cauchy_a = 3.0; p->use_sqloss = 1;  // em_icp.hpp:60,111,115
     p->outer_tol = 1e-5; p->max_outer = 50;            // em_icp.hpp:180
@@ -751,8 +751,11 @@ int sicp_set_params(sicp_handle h, const sicp_params* p) {
   if (p->mode < SICP_MODE_GICP || p->mode > SICP_MODE_SEMANTIC) return SICP_ERR_INVALID_ARGUMENT;
   if (!sicp::nn_k_supported(p->knn) || !sicp::nn_k_supported(p->k_cov)) return SICP_ERR_INVALID_ARGUMENT;
   if (!(p->epsilon > 0) || !(p->cauchy_a > 0) || p->nn_method < 0 || p->nn_method > 1) return SICP_ERR_INVALID_ARGUMENT;
+  // engine knobs (profiling, batching) do not invalidate the correspondences held on the device
+  sicp_params a = h->params, b = *p;
+  a.profile = b.profile = 0; a.lm_batch = b.lm_batch = 0; a.lm_on_device = b.lm_on_device = 0;
+  if (std::memcmp(&a, &b, sizeof a) != 0) h->corr_valid = false;
   h->params = *p;
-  h->corr_valid = false;
   return SICP_OK;
 }
 
