@@ -1032,7 +1032,7 @@ hipError_t launch_fused_labels(const WeightArgs& a, uint32_t* out, hipStream_t s
 int accumulate_blocks(int total) {
   // each lane sums several slots in registers before the (LDS-bound) wave reduction; the grid
   // still covers every CU.  SICP_ACC_SLOTS_PER_LANE is a tuning aid.
-  static const int per_lane = [] { const char* e = getenv("SICP_ACC_SLOTS_PER_LANE"); return e ? atoi(e) : 4; }();
+  static const int per_lane = [] { const char* e = getenv("SICP_ACC_SLOTS_PER_LANE"); return e ? atoi(e) : 8; }();
   const int bs = 256;
   int nb = (total + bs * per_lane - 1) / (bs * per_lane);
   if (nb > 1024) nb = 1024;

@@ -318,6 +318,45 @@ def test_em_lidar20k_vs_oracle_and_fused_labels(lidar20k, nn):
     assert np.mean(lab == olab) > 0.9999  # arg-max of float64 sums: ties may flip on rounding
 
 
+def test_config3_rgbd_eps1e6_13_classes_vs_oracle():
+    """BASELINE config 3 settings (exec/scenenet_eval.cc:174: EmIterativeClosestPoint<13>(20, 1e-6)) on a
+    strided RGB-D frame pair, EM and SemanticICP (exec/nyu_eval.cc:139), against the oracle."""
+    src, sl, tgt, tl, T_gt, cm = synth.rgbd_pair(seed=3, stride=4)  # 160x120 -> 19200 points
+    e, p = make_engine(sicp.MODE_EM, 13, cm, epsilon=1e-6)
+    e.set_source(src, sl)
+    e.set_target(tgt, tl)
+    qt, st = e.align()
+    oq, ost = O.align(oracle_params(sicp.MODE_EM, 13, epsilon=1e-6), src, sl, tgt, tl, cm, IDENT)
+    rot, tr = pose_delta(qt, oq)
+    assert rot < ROT_TOL and tr < TRANS_TOL, (rot, tr)
+    assert st["outer_iters"] == ost["outer_iters"] and st["total_active"] == ost["total_active"]
+    lab = e.fused_labels(qt)
+    olab = O.fused_labels(oracle_params(sicp.MODE_EM, 13, epsilon=1e-6), src, sl, tgt, tl, cm, qt)
+    assert np.mean(lab == olab) > 0.9999
+    e2, _ = make_engine(sicp.MODE_SEMANTIC)
+    e2.set_source(src, sl)
+    e2.set_target(tgt, tl)
+    qt2, st2 = e2.align()
+    oq2, ost2 = O.align(oracle_params(sicp.MODE_SEMANTIC), src, sl, tgt, tl, None, IDENT)
+    rot, tr = pose_delta(qt2, oq2)
+    assert rot < ROT_TOL and tr < TRANS_TOL and st2["outer_iters"] == ost2["outer_iters"]
+
+
+def test_config4_facets_20_classes_vs_oracle():
+    """BASELINE config 4 settings (20 classes, full EM outer loop) on a 30K-point facets pair."""
+    src, sl, tgt, tl, T_gt, cm = synth.facets_pair(seed=4, n_points=30000, n_facets=40, cube=30.0)
+    e, p = make_engine(sicp.MODE_EM, 20, cm)
+    e.set_source(src, sl)
+    e.set_target(tgt, tl)
+    qt, st = e.align()
+    oq, ost = O.align(oracle_params(sicp.MODE_EM, 20), src, sl, tgt, tl, cm, IDENT)
+    rot, tr = pose_delta(qt, oq)
+    assert rot < ROT_TOL and tr < TRANS_TOL, (rot, tr)
+    assert st["outer_iters"] == ost["outer_iters"]
+    rot, tr = pose_err_to_matrix(qt, T_gt)
+    assert rot < 2e-3 and tr < 2e-2
+
+
 def test_quirk_flags_change_results(pair1):
     src, sl, tgt, tl, T_gt = pair1
     far = src + np.float32(35.0)  # float32 products only matter away from the origin
