@@ -71,13 +71,19 @@ inline std::vector<std::string> get_pcd_in_dir(const std::string& dir_name) {
 // estimate against poseA^-1 * poseB, and one CSV row per evaluation in the reference's column order:
 //   idA, idB, ||log(dT)||^2, ||rot log(dT)||^2, ||trans(dT)||^2, time, dT (16, row major), T (16), outer
 // (time is written in seconds as a real number; the reference truncates it to whole seconds)
+//
+// The same class serves exec/scenenet_metrics.h:10-75, whose ground-truth rows hold 16 numbers
+// (4x4, row major) + the frame index and are stored INVERTED (scenenet_metrics.h:17-29).
 class KittiMetrics {
  public:
-  explicit KittiMetrics(const std::string& gtFileName, std::ostream* out = &std::cout) : out_(out) {
+  enum Format { KITTI_3x4 = 0, SCENENET_4x4_INVERTED = 1 };
+  explicit KittiMetrics(const std::string& gtFileName, std::ostream* out = &std::cout, Format fmt = KITTI_3x4) : out_(out) {
     for (const auto& row : read_rows(gtFileName)) {
       Eigen::Matrix4d mat = Eigen::Matrix4d::Identity();
-      for (size_t n = 0; n < row.size() && n < 12; ++n) mat((int)(n / 4), (int)(n % 4)) = std::stod(row[n]);
-      gtPoses_.push_back(Sophus::SE3d::fitToSE3(mat));
+      const size_t want = fmt == KITTI_3x4 ? 12 : 16;
+      for (size_t n = 0; n < row.size() && n < want; ++n) mat((int)(n / 4), (int)(n % 4)) = std::stod(row[n]);
+      const Sophus::SE3d T = Sophus::SE3d::fitToSE3(mat);
+      gtPoses_.push_back(fmt == KITTI_3x4 ? T : T.inverse());
     }
   }
   size_t numPoses() const { return gtPoses_.size(); }

@@ -206,10 +206,7 @@ def lidar_sequence(seed: int = 5, n_scans: int = 7, n_points: int | None = 20000
 # -----------------------------------------------------------------------------
 # config 3: RGB-D frame pair of a box room (pinhole depth render)
 # -----------------------------------------------------------------------------
-def rgbd_pair(seed: int = 3, width: int = 640, height: int = 480, C: int = 13,
-              label_noise: float = 0.10, stride: int = 1):
-    rng = np.random.default_rng(seed)
-    cm = confusion_matrix(C)
+def _rgbd_scene(rng, width, height, stride):
     room_lo, room_hi = np.array([-3.0, -2.5, 0.0]), np.array([3.0, 2.5, 2.8])
     cuboids = []
     for k in range(9):
@@ -222,42 +219,72 @@ def rgbd_pair(seed: int = 3, width: int = 640, height: int = 480, C: int = 13,
     d_c /= np.linalg.norm(d_c, axis=1, keepdims=True)
     # camera looks along +x of the room, z up: camera axes (x right, y down, z fwd)
     Rwc = np.array([[0.0, 0.0, 1.0], [-1.0, 0.0, 0.0], [0.0, -1.0, 0.0]])
-    pose_t = np.eye(4); pose_t[:3, :3] = Rwc; pose_t[:3, 3] = (-2.6, 0.1, 1.4)
+    pose0 = np.eye(4); pose0[:3, :3] = Rwc; pose0[:3, 3] = (-2.6, 0.1, 1.4)
+    return room_lo, room_hi, cuboids, d_c, pose0
+
+
+def _rgbd_render(rng, pose, scene):
+    room_lo, room_hi, cuboids, d_c, _ = scene
+    R, o = pose[:3, :3], pose[:3, 3]
+    dw = d_c @ R.T
+    n = dw.shape[0]
+    lab = np.zeros(n, dtype=np.uint32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        inv = 1.0 / dw
+        # inside of the room box: exit distance, label by face (floor 1, ceiling 2, walls 3/4)
+        t0 = (room_lo - o) * inv; t1 = (room_hi - o) * inv
+        tf3 = np.maximum(t0, t1)
+        face = np.argmin(tf3, axis=1)
+        tbest = tf3.min(axis=1)
+        up = dw[np.arange(n), 2] > 0
+        lab[:] = np.where(face == 2, np.where(up, 2, 1), np.where(face == 0, 3, 4))
+        for lo, hi, bl in cuboids:
+            t0 = (lo - o) * inv; t1 = (hi - o) * inv
+            tn = np.minimum(t0, t1).max(axis=1); tf = np.maximum(t0, t1).min(axis=1)
+            ok = (tn <= tf) & (tn > 0.3)
+            upd = ok & (tn < tbest); tbest[upd] = tn[upd]; lab[upd] = bl
+    z = tbest * d_c[:, 2]
+    z = z + rng.normal(0, 1.0, n) * 0.0012 * z * z      # depth noise ~ z^2
+    pts = d_c * (z / d_c[:, 2])[:, None]
+    keep = np.isfinite(z) & (z > 0.3) & (z < 8.0)
+    return pts[keep], lab[keep]
+
+
+def rgbd_pair(seed: int = 3, width: int = 640, height: int = 480, C: int = 13,
+              label_noise: float = 0.10, stride: int = 1):
+    rng = np.random.default_rng(seed)
+    cm = confusion_matrix(C)
+    scene = _rgbd_scene(rng, width, height, stride)
+    pose_t = scene[4]
     step = pose_matrix(3.0, (0.2, 1.0, 0.1), (0.03, 0.01, 0.04))
     pose_s = pose_t @ step
-
-    def render(pose):
-        R, o = pose[:3, :3], pose[:3, 3]
-        dw = d_c @ R.T
-        n = dw.shape[0]
-        tbest = np.full(n, np.inf); lab = np.zeros(n, dtype=np.uint32)
-        with np.errstate(divide="ignore", invalid="ignore"):
-            inv = 1.0 / dw
-            # inside of the room box: exit distance, label by face (floor 1, ceiling 2, walls 3/4)
-            t0 = (room_lo - o) * inv; t1 = (room_hi - o) * inv
-            tf3 = np.maximum(t0, t1)
-            face = np.argmin(tf3, axis=1)
-            tbest = tf3.min(axis=1)
-            up = dw[np.arange(n), 2] > 0
-            lab[:] = np.where(face == 2, np.where(up, 2, 1), np.where(face == 0, 3, 4))
-            for lo, hi, bl in cuboids:
-                t0 = (lo - o) * inv; t1 = (hi - o) * inv
-                tn = np.minimum(t0, t1).max(axis=1); tf = np.maximum(t0, t1).min(axis=1)
-                ok = (tn <= tf) & (tn > 0.3)
-                upd = ok & (tn < tbest); tbest[upd] = tn[upd]; lab[upd] = bl
-        z = tbest * d_c[:, 2]
-        z = z + rng.normal(0, 1.0, n) * 0.0012 * z * z      # depth noise ~ z^2
-        pts = d_c * (z / d_c[:, 2])[:, None]
-        keep = np.isfinite(z) & (z > 0.3) & (z < 8.0)
-        return pts[keep], lab[keep]
-
     out = []
     for pose in (pose_s, pose_t):
-        p, l = render(pose)
+        p, l = _rgbd_render(rng, pose, scene)
         l = _noisy_labels(rng, l, cm, label_noise)
         out += [p.astype(np.float32), l.astype(np.uint32)]
     T_gt = np.linalg.inv(pose_t) @ pose_s
     return out[0], out[1], out[2], out[3], T_gt, cm
+
+
+def rgbd_sequence(seed: int = 6, n_frames: int = 3, width: int = 640, height: int = 480, C: int = 13,
+                  label_noise: float = 0.10, stride: int = 4):
+    """SceneNet-like sequence: the camera of config 3 moves by a small step per frame.  Returns
+    [(xyz, labels)], camera-to-world poses (n,4,4), cm.  exec/scenenet_eval.cc registers frame n+1
+    (source) onto frame n (target)."""
+    rng = np.random.default_rng(seed)
+    cm = confusion_matrix(C)
+    scene = _rgbd_scene(rng, width, height, stride)
+    pose = scene[4]
+    step = pose_matrix(1.5, (0.2, 1.0, 0.1), (0.02, 0.01, 0.03))
+    frames, poses = [], []
+    for _ in range(n_frames):
+        p, l = _rgbd_render(rng, pose, scene)
+        l = _noisy_labels(rng, l, cm, label_noise)
+        frames.append((p.astype(np.float32), l.astype(np.uint32)))
+        poses.append(pose.copy())
+        pose = pose @ step
+    return frames, np.stack(poses), cm
 
 
 # -----------------------------------------------------------------------------

@@ -166,3 +166,55 @@ def test_kitti_eval_headless_rows_match_oracle(tmp_path):
             D = np.linalg.inv(O.se3_matrix(oq)) @ T_est
             assert np.linalg.norm(Rotation.from_matrix(D[:3, :3]).as_rotvec()) < 1e-7 and np.linalg.norm(D[:3, 3]) < 1e-7
             assert int(row[38]) == ost["outer_iters"]
+
+
+# ------------------------------------------------------------------------------------------------
+# f2: headless scenenet_eval (exec/scenenet_eval.cc:110-250 + exec/scenenet_metrics.h)
+# ------------------------------------------------------------------------------------------------
+def read_pcd_ascii(path):
+    lines = open(path).read().splitlines()
+    i = next(k for k, l in enumerate(lines) if l.startswith("DATA"))
+    a = np.array([[float(v) for v in l.split()] for l in lines[i + 1:] if l.strip()])
+    return a[:, :3].astype(np.float32), a[:, 3].astype(np.uint32)
+
+
+@pytest.mark.gpu
+def test_scenenet_eval_headless_rows_and_fused_labels(tmp_path):
+    exe = build_example(tmp_path, "scenenet_eval_headless")
+    frames, poses, cm = synth.rgbd_sequence(seed=6, n_frames=3)
+    d = tmp_path / "seq"
+    d.mkdir()
+    for k, (p, l) in enumerate(frames):
+        write_pcd(str(d / f"{k:04d}.pcd"), p, l, binary=False)
+    gt = str(tmp_path / "gt.txt")
+    with open(gt, "w") as f:  # SceneNet rows: inverse pose (4x4 row major) + frame index
+        for k, P in enumerate(poses):
+            f.write(" ".join(f"{v:.17g}" for v in np.linalg.inv(P).reshape(-1)) + f" {k}\n")
+    cmf = str(tmp_path / "cm.txt")
+    np.savetxt(cmf, cm, fmt="%.17g")
+    prefix = str(tmp_path / "out_")
+    r = subprocess.run([exe, "-s", str(d), "-t", gt, "-m", cmf, "-o", prefix], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr
+    ident = np.array([0, 0, 0, 1, 0, 0, 0.0])
+    for fname, mode in (("EMICPscenenet.csv", O.MODE_EM), ("se3GICPscenenet.csv", O.MODE_GICP)):
+        rows = [[float(v) for v in line.split(",")] for line in open(prefix + fname) if line.strip()]
+        assert [(int(r_[0]), int(r_[1])) for r_ in rows] == [(0, 1), (1, 2)]  # consecutive frames
+        for row in rows:
+            a, b = int(row[0]), int(row[1])
+            T_est = np.array(row[22:38]).reshape(4, 4)
+            T_gt = np.linalg.inv(poses[a]) @ poses[b]
+            assert np.allclose(np.array(row[6:22]).reshape(4, 4), T_gt @ np.linalg.inv(T_est), atol=1e-9)
+            p = O.default_params(mode)
+            p.num_classes = 13
+            p.epsilon = 1e-6
+            (ps, ls), (pt, lt) = frames[b], frames[a]
+            oq, ost = O.align(p, ps, ls if mode == O.MODE_EM else None, pt, lt if mode == O.MODE_EM else None,
+                              cm if mode == O.MODE_EM else None, ident)
+            D = np.linalg.inv(O.se3_matrix(oq)) @ T_est
+            assert np.linalg.norm(Rotation.from_matrix(D[:3, :3]).as_rotvec()) < 1e-4 and np.linalg.norm(D[:3, 3]) < 1e-3
+            assert int(row[38]) == ost["outer_iters"]
+            if mode == O.MODE_EM:  # fused labels written as <prefix><source index>.pcd
+                fp, fl = read_pcd_ascii(f"{prefix}{b}.pcd")
+                assert np.allclose(fp, ps, atol=1e-5)
+                olab = O.fused_labels(p, ps, ls, pt, lt, cm, oq)
+                assert np.mean(fl == olab) > 0.999
