@@ -101,14 +101,18 @@ typedef struct sicp_params {
   int32_t quirk_float_products;   /* Q2: float32 products in the covariance moments
                                      (em_icp.hpp:307-314); 0 = double products       */
   /* engine knobs (no reference counterpart) */
-  int32_t nn_method;              /* 0 = LDS-tiled brute force, 1 = Morton box-tree walk;
-                                     both exact, bit-identical results                  */
+  int32_t nn_method;              /* 0 = LDS-tiled brute force, 1 = Hilbert box-tree, the
+                                     16 queries of a wave walk it together (default),
+                                     2 = box-tree, every query walks alone; all exact,
+                                     bit-identical results                              */
   int32_t profile;                /* SICP_PROFILE_* bit mask: bracket those kernels with
                                      HIP events on the handle's stream (sicp_stats)     */
-  int32_t lm_on_device;           /* 1 = trust-region state lives on the GPU, the host
-                                     polls once per batch of evaluations; 0 = host loop
-                                     (one synchronisation per evaluation).  Same machine
-                                     (csrc/lm.hpp), same iterates.                       */
+  int32_t lm_on_device;           /* 0 = host loop (one synchronisation per evaluation);
+                                     1 = trust-region state lives on the GPU, accumulate
+                                     kernel + one-wave step kernel per evaluation, the
+                                     host polls once per batch; 2 (default) = the same with
+                                     the step fused into the accumulate kernel's last
+                                     block.  Same machine (csrc/lm.hpp), same iterates.  */
   int32_t lm_batch;               /* evaluations queued per host poll (lm_on_device)    */
 } sicp_params;
 

@@ -113,6 +113,8 @@ struct AccArgs {
   const double *snx, *sny, *snz, *tnx, *tny, *tnz;
   Pose pose;            // used when lm == nullptr
   const LmState* lm;    // device-resident solve: evaluate at lm->pose, skip when it has finished
+  LmState* lm_step;     // fused solve step: the last block to finish reduces the partials and feeds *lm_step
+  unsigned* ticket;     // block-arrival counter of the fused step (zero between launches)
   double one_m_eps;
   LossArgs loss;
   double* partials;  // [accumulate_blocks][28]
@@ -124,6 +126,7 @@ hipError_t launch_nn_partial(int K, const NNArgs& a, int n_chunks, hipStream_t s
 hipError_t launch_nn_merge(int K, const MergeArgs& m, hipStream_t st);
 hipError_t launch_bvh_knn(int K, const KnnArgs& a, hipStream_t st);
 hipError_t launch_bvh_knn_quad(int K, const KnnArgs& a, hipStream_t st);
+hipError_t launch_bvh_knn_packet(int K, const KnnArgs& a, hipStream_t st);
 hipError_t launch_cov(const CovArgs& a, hipStream_t st);
 hipError_t launch_proj(const ProjArgs& a, hipStream_t st);
 hipError_t launch_em_weight(const WeightArgs& a, hipStream_t st);
@@ -133,6 +136,7 @@ hipError_t launch_accumulate_kernel(const AccArgs& a, hipStream_t st);
 hipError_t launch_finalize(const AccArgs& a, double* out28, hipStream_t st);
 // one evaluation of the device-resident solve: accumulate at lm->pose, then feed the LM machine
 hipError_t launch_accumulate_lm(const AccArgs& a, LmState* lm, hipStream_t st);
+hipError_t launch_accumulate_fused(const AccArgs& a, hipStream_t st);
 hipError_t launch_count_active(const int* idx, int n, unsigned long long* out, hipStream_t st);
 hipError_t launch_transform_float(int n, const float* x, const float* y, const float* z, const Mat4f& M,
                                   float* ox, float* oy, float* oz, hipStream_t st);

@@ -63,21 +63,61 @@ __device__ __forceinline__ float l2_simple(float ax, float ay, float az, float b
 // FLANN leaves tie order unspecified) --
 // independent of the order in which candidates are visited (device order is curve order).
 typedef unsigned long long u64;
-static constexpr u64 KEY_EMPTY = ~0ull;  // high word = NaN pattern: above every real distance
+// Empty list entry: above every real key (a float d2 pattern is at most 0x7f800000 = +inf), caller
+// index -1, NaN as a float distance -- and, read as a double, the largest FINITE value (see below).
+static constexpr u64 KEY_EMPTY = 0x7fefffffffffffffull;
 
 __device__ __forceinline__ u64 make_key(float d, unsigned orig) { return ((u64)__float_as_uint(d) << 32) | orig; }
 __device__ __forceinline__ float key_dist(u64 k) { return __uint_as_float((unsigned)(k >> 32)); }
 
+// Keys are sorted with TWO instructions per list element.  Every key is a non-negative, non-NaN bit
+// pattern when read as an IEEE double (sign bit clear, exponent field < 0x7ff because the high word
+// is at most 0x7fefffff), and for such patterns the double order IS the unsigned order, so
+// v_min_f64 / v_max_f64 order keys exactly; double denormals (tiny d2, e.g. the query itself at
+// d2 = 0) are preserved because FP64 denormals are never flushed on gfx9.  The u64 formulation
+// costs two 64-bit compares and four v_cndmask per element (8 issue slots with the VCC hazards).
+//
 // Insert into an ascending key list held in registers.  Precondition: key < bk[K-1].
+// The new key travels down from the top as a carry c: slot j+1 receives max(bk[j], c) and c becomes
+// min(bk[j], c).  Every list element is written in its own register (no temporaries, so no copies
+// where the divergent "insert / do not insert" paths join), and bk[K-1] is simply dropped.
+// One asm block per insertion (the compiler pads every inline-asm statement with hazard nops, and
+// the fmin / fmax builtins would add a canonicalising v_max_f64 per element).
 template <int K>
-__device__ __forceinline__ void key_insert(u64 (&bk)[K], u64 key) {
-  bk[K - 1] = key;
+__device__ __forceinline__ void key_insert(u64 (&bk)[K], u64 key);
+
+#define SICP_KI_STEP(hi, lo) "v_max_f64 %" #hi ", %" #lo ", %0\n\tv_min_f64 %0, %" #lo ", %0\n\t"
+template <>
+__device__ __forceinline__ void key_insert<1>(u64 (&bk)[1], u64 key) { bk[0] = key; }
+template <>
+__device__ __forceinline__ void key_insert<4>(u64 (&bk)[4], u64 key) {
+  double c = __longlong_as_double((long long)key);
+  double* b = reinterpret_cast<double*>(bk);
+  asm(SICP_KI_STEP(4, 3) SICP_KI_STEP(3, 2) SICP_KI_STEP(2, 1) "v_mov_b64 %1, %0"
+      : "+v"(c), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+}
+template <>
+__device__ __forceinline__ void key_insert<20>(u64 (&bk)[20], u64 key) {
+  double c = __longlong_as_double((long long)key);
+  double* b = reinterpret_cast<double*>(bk);
+  asm(SICP_KI_STEP(20, 19) SICP_KI_STEP(19, 18) SICP_KI_STEP(18, 17) SICP_KI_STEP(17, 16) SICP_KI_STEP(16, 15) SICP_KI_STEP(15, 14)
+      SICP_KI_STEP(14, 13) SICP_KI_STEP(13, 12) SICP_KI_STEP(12, 11) SICP_KI_STEP(11, 10) SICP_KI_STEP(10, 9) SICP_KI_STEP(9, 8)
+      SICP_KI_STEP(8, 7) SICP_KI_STEP(7, 6) SICP_KI_STEP(6, 5) SICP_KI_STEP(5, 4) SICP_KI_STEP(4, 3) SICP_KI_STEP(3, 2)
+      SICP_KI_STEP(2, 1) "v_mov_b64 %1, %0"
+      : "+v"(c), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]), "+v"(b[8]), "+v"(b[9]),
+        "+v"(b[10]), "+v"(b[11]), "+v"(b[12]), "+v"(b[13]), "+v"(b[14]), "+v"(b[15]), "+v"(b[16]), "+v"(b[17]), "+v"(b[18]),
+        "+v"(b[19]));
+}
+#undef SICP_KI_STEP
+
+// a fresh list; the asm keeps the compiler from treating the K equal constants as one value (it
+// would share one register among them and copy at every control-flow join of the first scans)
+template <int K>
+__device__ __forceinline__ void key_list_init(u64 (&bk)[K]) {
 #pragma unroll
-  for (int j = K - 1; j > 0; --j) {
-    const bool sw = bk[j] < bk[j - 1];
-    const u64 lo = sw ? bk[j] : bk[j - 1], hi = sw ? bk[j - 1] : bk[j];
-    bk[j - 1] = lo;
-    bk[j] = hi;
+  for (int k = 0; k < K; ++k) {
+    bk[k] = KEY_EMPTY;
+    asm volatile("" : "+v"(bk[k]));
   }
 }
 
@@ -397,8 +437,7 @@ __global__ __launch_bounds__(64) void bvh_knn_quad_kernel(KnnArgs a) {
   float px, py, pz;
   load_query(a.qx, a.qy, a.qz, a.q_begin + q, a.do_xform, a.M, px, py, pz);
   u64 bk[K];
-#pragma unroll
-  for (int k = 0; k < K; ++k) bk[k] = KEY_EMPTY;
+  key_list_init<K>(bk);
   float wd = INFINITY;
   const float4* __restrict__ pts = a.tree.pts4 + a.tree.pt_begin + sub;
   const float4* __restrict__ blo = a.tree.box_lo + a.tree.node_begin;
@@ -480,6 +519,155 @@ __global__ __launch_bounds__(64) void bvh_knn_quad_kernel(KnnArgs a) {
       const u64 m01 = h0 <= h1 ? h0 : h1, m23 = h2 <= h3 ? h2 : h3;
       const u64 best = m01 <= m23 ? m01 : m23;
       // keys are unique (caller index), except KEY_EMPTY: advance exactly one list
+      if (best == h0 && p0 < K) ++p0; else if (best == h1 && p1 < K) ++p1; else if (best == h2 && p2 < K) ++p2; else ++p3;
+      const unsigned orig = (unsigned)best;
+      const float d = best == KEY_EMPTY ? INFINITY : key_dist(best);
+      const bool keep = orig != 0xffffffffu && d < a.gate_sq;  // strict <, float compare (em_icp.hpp:65)
+      a.out_i[o + k] = keep ? a.inv[orig] : -1;
+      if (a.out_d) a.out_d[o + k] = d;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Packet search (default): the 16 queries of a wave walk the tree TOGETHER.
+//
+// Queries are consecutive points of a curve-ordered cloud, so the 16 of a wave are neighbours in
+// space (for the covariance search they are exactly one leaf) and need almost the same nodes.
+// The walk is therefore shared: one wave-uniform depth-first traversal (level, sibling masks and
+// node indices live in scalar registers, no divergence), a node is entered when ANY of the 16
+// queries still needs it (each query prunes with its own bound).  Lane (query q, sub c) tests child
+// c against query q, one ballot folds the 64 answers into the 4-bit sibling mask.  At a leaf every
+// quad scans the same 16 points (4 per lane, addresses shared by all quads: one cache line per
+// load).  Compared with the per-quad walk above this removes the per-lane stack bookkeeping and the
+// "wait for the slowest quad" rounds (profile: 6100 -> VALU instructions per wave).  Lists, keys
+// and the final 4-way merge are those of the quad kernel, so the result is bit-identical.
+//
+// Workgroup b runs on XCD b % 8 (observed dispatch order; a speed assumption only): the block
+// index is remapped so that each XCD gets one contiguous run of the curve, i.e. one compact
+// region of space, and its private L2 only has to hold that region of the target.
+__device__ __forceinline__ int xcd_contiguous_block(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7;
+  const int xcd = bid & 7, loc = bid >> 3;
+  return xcd < r ? xcd * (q + 1) + loc : r * (q + 1) + (xcd - r) * q + loc;
+}
+
+__device__ __forceinline__ unsigned child_mask_packet(const float4* __restrict__ blo, const float4* __restrict__ bhi, int child_off,
+                                                      int child_cnt, int parent, int sub, float px, float py, float pz, float wd) {
+  const int c = parent * kFan + sub;
+  const int node = child_off + min(c, child_cnt - 1);
+  const float lb = box_lb(blo[node], bhi[node], px, py, pz);
+  const bool ok = c < child_cnt && !(lb > wd);  // lb == wd may hide an equal distance with a lower index
+  u64 b = __ballot(ok);                         // bit 4*q + c
+  b |= b >> 32; b |= b >> 16; b |= b >> 8; b |= b >> 4;
+  return (unsigned)b & 15u;
+}
+
+template <int K>
+__global__ __launch_bounds__(64) void bvh_knn_packet_kernel(KnnArgs a) {
+  __shared__ u64 s_merge[16][4][K];
+  const int lane = threadIdx.x, sub = lane & 3, slot = lane >> 2;
+  const int bid = xcd_contiguous_block((int)blockIdx.x, (int)gridDim.x);
+  const int q_raw = bid * 16 + slot;
+  const int q = min(q_raw, a.q_count - 1);  // a padding quad repeats the last query and is not emitted
+  float px, py, pz;
+  load_query(a.qx, a.qy, a.qz, a.q_begin + q, a.do_xform, a.M, px, py, pz);
+  u64 bk[K];
+  key_list_init<K>(bk);
+  float wd = INFINITY;
+  const float4* __restrict__ pts = a.tree.pts4 + a.tree.pt_begin + sub;
+  const float4* __restrict__ blo = a.tree.box_lo + a.tree.node_begin;
+  const float4* __restrict__ bhi = a.tree.box_hi + a.tree.node_begin;
+  const int top = a.tree.lv.n_levels - 1;
+  const int n_leaf = a.tree.lv.cnt[0];
+
+  // --- seed group: the level-1 node at the packet's position on the curve
+  int seed = 0;
+  if (top >= 1) {
+    if (a.self) {
+      seed = bid / kFan;  // the 16 queries ARE leaf `bid`
+    } else {
+      // 64-ary search of the middle query's curve index in the leaves' first indices: lane i
+      // probes position lo + (i+1)*step, the ballot's population count is the sub-range
+      const u64 qc_lane = curve_code(px, py, pz, a.tree.lo[0], a.tree.lo[1], a.tree.lo[2], a.tree.scale);
+      const u64 qc = ((u64)(unsigned)__builtin_amdgcn_readlane((int)(qc_lane >> 32), 32) << 32) |
+                     (unsigned)__builtin_amdgcn_readlane((int)qc_lane, 32);
+      const u64* __restrict__ codes = a.tree.leaf_code + a.tree.code_begin;
+      int lo_i = 0, len = n_leaf;  // the answer (last leaf whose first index is <= qc, else 0) is in [lo_i, lo_i+len)
+      while (len > 1) {
+        const int step = (len + 63) >> 6;
+        const int idx = lo_i + (lane + 1) * step;
+        const bool ok = idx < lo_i + len && codes[idx] <= qc;  // sorted: true for a prefix of the lanes
+        const int cnt = __popcll(__ballot(ok));
+        const int nlo = lo_i + cnt * step;
+        len = min(step, lo_i + len - nlo);
+        lo_i = nlo;
+      }
+      seed = lo_i / kFan;
+    }
+    seed = __builtin_amdgcn_readfirstlane(seed);
+  }
+  {
+    const int l0 = seed * kFan, l1 = min(l0 + kFan, n_leaf);  // a one-leaf tree: leaf 0
+#pragma unroll 1
+    for (int l = l0; l < l1; ++l) scan_leaf_quad<K>(pts + (size_t)l * kLeaf, px, py, pz, bk, wd);
+  }
+
+  // --- shared depth-first walk: all of this state is wave-uniform.  Two nested loops: the inner
+  // one only moves through the tree (scalar state, box tests) until it stands on a leaf some
+  // query needs, the outer one scans that leaf -- so the K-entry lists are carried by exactly one
+  // loop with one back edge (with `continue`s in a single loop the compiler kept up to three
+  // copies of the lists alive and moved them at every edge).
+  int n_box = 0, n_scan = 0;  // statistics (a.dbg), dead code otherwise
+  if (top >= 2) {
+    u64 masks = 0;  // 4 sibling bits per level
+    int L = top - 1, base = 0;
+    masks = (u64)child_mask_packet(blo, bhi, a.tree.lv.off[L], a.tree.lv.cnt[L], 0, sub, px, py, pz, wd) << (4 * L);
+    for (;;) {
+      int leaf = -1;
+      for (;;) {
+        const unsigned m = (unsigned)(masks >> (4 * L)) & 15u;
+        if (m == 0) {
+          if (L == top - 1) break;
+          ++L;
+          base = (base / kFan) & ~(kFan - 1);
+          continue;
+        }
+        const int c = __ffs(m) - 1;
+        masks &= ~(1ull << (4 * L + c));
+        const int node = base + c;
+        if (L == 1 && node == seed) continue;
+        if (L == 0) {
+          const int bn = a.tree.lv.off[0] + node;
+          const float lb = box_lb(blo[bn], bhi[bn], px, py, pz);  // the bounds may have tightened since the parent's test
+          if (__ballot(!(lb > wd)) != 0) { leaf = node; break; }
+        } else {
+          ++n_box;
+          const unsigned cm = child_mask_packet(blo, bhi, a.tree.lv.off[L - 1], a.tree.lv.cnt[L - 1], node, sub, px, py, pz, wd);
+          --L;
+          masks = (masks & ~(15ull << (4 * L))) | ((u64)cm << (4 * L));
+          base = node * kFan;
+        }
+      }
+      if (leaf < 0) break;
+      scan_leaf_quad<K>(pts + (size_t)leaf * kLeaf, px, py, pz, bk, wd);
+      ++n_scan;
+    }
+  }
+  if (a.dbg && sub == 0 && q_raw < a.q_count) { a.dbg[2 * q] = n_box; a.dbg[2 * q + 1] = n_scan; }
+
+  // --- merge the quad's four ascending lists (LDS), lane 0 of the quad emits
+#pragma unroll
+  for (int k = 0; k < K; ++k) s_merge[slot][sub][k] = bk[k];
+  __syncthreads();
+  if (sub == 0 && q_raw < a.q_count) {
+    int p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+    const size_t o = (size_t)(a.q_begin + q) * K;
+    for (int k = 0; k < K; ++k) {
+      const u64 h0 = p0 < K ? s_merge[slot][0][p0] : KEY_EMPTY, h1 = p1 < K ? s_merge[slot][1][p1] : KEY_EMPTY;
+      const u64 h2 = p2 < K ? s_merge[slot][2][p2] : KEY_EMPTY, h3 = p3 < K ? s_merge[slot][3][p3] : KEY_EMPTY;
+      const u64 m01 = h0 <= h1 ? h0 : h1, m23 = h2 <= h3 ? h2 : h3;
+      const u64 best = m01 <= m23 ? m01 : m23;
       if (best == h0 && p0 < K) ++p0; else if (best == h1 && p1 < K) ++p1; else if (best == h2 && p2 < K) ++p2; else ++p3;
       const unsigned orig = (unsigned)best;
       const float d = best == KEY_EMPTY ? INFINITY : key_dist(best);
@@ -745,7 +933,12 @@ __device__ __forceinline__ double wave_sum(double v) {
 // group are issued before the first residual is computed (4 independent gather chains in flight
 // per lane instead of one), then the 28 partial sums are combined across the block through an
 // LDS transpose so that each wave only performs 7 cross-lane reductions.
-template <int K, int BS>
+//
+// FUSED (device-resident solve): the last block to finish -- decided by an arrival ticket -- also
+// sums the per-block partials (four waves, seven rows each, same fixed order as reduce_partials)
+// and advances the LM machine (lm.hpp: lm_feed) in its lane 0, so one LM evaluation is ONE kernel
+// and one launch boundary instead of two.
+template <int K, int BS, bool FUSED>
 __global__ __launch_bounds__(BS) void accumulate_kernel(AccArgs a) {
   __shared__ double red[28][BS];
   Pose P;
@@ -822,7 +1015,68 @@ __global__ __launch_bounds__(BS) void accumulate_kernel(AccArgs a) {
 #pragma unroll
     for (int t = 0; t < NW; ++t) sum += red[k][lane + 64 * t];
     sum = wave_sum(sum);
-    if (lane == 0) a.partials[(size_t)k * gridDim.x + blockIdx.x] = sum;  // [28][blocks]: coalesced for the reducer
+    if (lane == 0) {  // [28][blocks]: coalesced for the reducer
+      double* dst = a.partials + (size_t)k * gridDim.x + blockIdx.x;
+      if constexpr (FUSED)  // device-scope store: written through to where every XCD sees it
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst), (unsigned long long)__double_as_longlong(sum), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      else
+        *dst = sum;
+    }
+  }
+  if constexpr (FUSED) {
+    // Arrival ticket WITHOUT fences: a release/acquire fence at device scope writes back and
+    // invalidates the XCD's whole L2 (measured: 2x slower, the other blocks lose the cloud).  The
+    // partials are device-scope atomic stores and loads (sc1: coherent across XCDs by themselves),
+    // so it is enough that a block's stores have completed (vmcnt(0)) before it takes its ticket.
+    __shared__ unsigned s_ticket;
+    __shared__ double s_out[28];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_ticket != gridDim.x - 1) return;
+    const int nb = (int)gridDim.x;
+    for (int k = wave; k < 28; k += NW) {
+      const unsigned long long* __restrict__ row = reinterpret_cast<const unsigned long long*>(a.partials) + (size_t)k * nb;
+      double s = 0.0;
+      for (int b0 = lane; b0 < nb; b0 += 64 * 8) {  // 8 trips of loads in flight, summed in trip order
+        double v[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const int b = b0 + 64 * t;
+          v[t] = b < nb ? __longlong_as_double((long long)__hip_atomic_load(row + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0.0;
+        }
+        asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+          if (b0 + 64 * t < nb) s += v[t];
+      }
+      s = wave_sum(s);
+      if (lane == 0) s_out[k] = s;
+    }
+    // the 0.8 KB state goes HBM -> LDS (all lanes, one round trip) -> lane 0's registers, and back
+    // the same way.  Lane 0 needs it in registers: it runs alone, so every LDS or HBM access
+    // inside lm_feed would be an exposed latency (measured: +5 us with the state left in LDS).
+    __shared__ double s_state[(sizeof(LmState) + 7) / 8];
+    constexpr int NSTATE = (int)((sizeof(LmState) + 7) / 8);
+    static_assert(sizeof(LmState) % 8 == 0, "LmState is copied as doubles");
+    double* g_state = reinterpret_cast<double*>(a.lm_step);
+    for (int i = threadIdx.x; i < NSTATE; i += BS) s_state[i] = g_state[i];
+    __syncthreads();
+    if (wave == 0) {
+      if (lane == 0) {
+        double o[28];
+#pragma unroll
+        for (int k = 0; k < 28; ++k) o[k] = s_out[k];
+        LmState st = *reinterpret_cast<const LmState*>(s_state);
+        lm_feed(st, o);
+        *reinterpret_cast<LmState*>(s_state) = st;
+      }
+      // same wave: lane 0's LDS writes are ordered before these reads
+      for (int i = lane; i < NSTATE; i += 64) g_state[i] = s_state[i];
+      if (lane == 0) *a.ticket = 0u;  // the next launch starts counting from zero
+    }
   }
 }
 
@@ -989,6 +1243,18 @@ hipError_t launch_bvh_knn_quad(int K, const KnnArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 
+hipError_t launch_bvh_knn_packet(int K, const KnnArgs& a, hipStream_t st) {
+  if (a.q_count <= 0) return hipSuccess;
+  dim3 grid((a.q_count + 15) / 16);
+  switch (K) {
+    case 1: hipLaunchKernelGGL((bvh_knn_packet_kernel<1>), grid, dim3(64), 0, st, a); break;
+    case 4: hipLaunchKernelGGL((bvh_knn_packet_kernel<4>), grid, dim3(64), 0, st, a); break;
+    case 20: hipLaunchKernelGGL((bvh_knn_packet_kernel<20>), grid, dim3(64), 0, st, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
 hipError_t launch_bvh_knn(int K, const KnnArgs& a, hipStream_t st) {
   if (a.q_count <= 0) return hipSuccess;
   dim3 grid((a.q_count + 63) / 64);
@@ -1042,9 +1308,21 @@ int accumulate_blocks(int total) {
 
 static hipError_t launch_accumulate_only(const AccArgs& a, int nb, hipStream_t st) {
   switch (a.K) {
-    case 1: hipLaunchKernelGGL((accumulate_kernel<1, 256>), dim3(nb), dim3(256), 0, st, a); break;
-    case 4: hipLaunchKernelGGL((accumulate_kernel<4, 256>), dim3(nb), dim3(256), 0, st, a); break;
-    case 20: hipLaunchKernelGGL((accumulate_kernel<20, 256>), dim3(nb), dim3(256), 0, st, a); break;
+    case 1: hipLaunchKernelGGL((accumulate_kernel<1, 256, false>), dim3(nb), dim3(256), 0, st, a); break;
+    case 4: hipLaunchKernelGGL((accumulate_kernel<4, 256, false>), dim3(nb), dim3(256), 0, st, a); break;
+    case 20: hipLaunchKernelGGL((accumulate_kernel<20, 256, false>), dim3(nb), dim3(256), 0, st, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+// one LM evaluation as one kernel (a.lm, a.lm_step, a.ticket set)
+hipError_t launch_accumulate_fused(const AccArgs& a, hipStream_t st) {
+  const int nb = accumulate_blocks(a.n_s * a.K);
+  switch (a.K) {
+    case 1: hipLaunchKernelGGL((accumulate_kernel<1, 256, true>), dim3(nb), dim3(256), 0, st, a); break;
+    case 4: hipLaunchKernelGGL((accumulate_kernel<4, 256, true>), dim3(nb), dim3(256), 0, st, a); break;
+    case 20: hipLaunchKernelGGL((accumulate_kernel<20, 256, true>), dim3(nb), dim3(256), 0, st, a); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

@@ -67,22 +67,22 @@ struct LmState {
 
 namespace detail {
 
-SICP_HD inline bool chol6_solve(const double* A, const double* b, double* y) {
-  double L[36];
-  SICP_UNROLL
-  for (int i = 0; i < 36; ++i) L[i] = 0;
+// Solves A y = b by Cholesky, IN PLACE: only the lower triangle of A is read, and it is overwritten
+// by L (so the caller's 6x6 costs 21 live values, not 36 + 36: on the GPU this routine runs in one
+// lane and its register footprint sets the allocation of the whole kernel).
+SICP_HD inline bool chol6_solve(double* A, const double* b, double* y) {
   SICP_UNROLL
   for (int i = 0; i < 6; ++i)
     SICP_UNROLL
     for (int j = 0; j <= i; ++j) {
       double s = A[6 * i + j];
       SICP_UNROLL
-      for (int k = 0; k < j; ++k) s -= L[6 * i + k] * L[6 * j + k];
+      for (int k = 0; k < j; ++k) s -= A[6 * i + k] * A[6 * j + k];
       if (i == j) {
         if (!(s > 0)) return false;
-        L[6 * i + i] = sqrt(s);
+        A[6 * i + i] = sqrt(s);
       } else {
-        L[6 * i + j] = s / L[6 * j + j];
+        A[6 * i + j] = s / A[6 * j + j];
       }
     }
   double z[6];
@@ -90,15 +90,15 @@ SICP_HD inline bool chol6_solve(const double* A, const double* b, double* y) {
   for (int i = 0; i < 6; ++i) {
     double s = b[i];
     SICP_UNROLL
-    for (int k = 0; k < i; ++k) s -= L[6 * i + k] * z[k];
-    z[i] = s / L[6 * i + i];
+    for (int k = 0; k < i; ++k) s -= A[6 * i + k] * z[k];
+    z[i] = s / A[6 * i + i];
   }
   SICP_UNROLL
   for (int i = 5; i >= 0; --i) {
     double s = z[i];
     SICP_UNROLL
-    for (int k = i + 1; k < 6; ++k) s -= L[6 * k + i] * y[k];
-    y[i] = s / L[6 * i + i];
+    for (int k = i + 1; k < 6; ++k) s -= A[6 * k + i] * y[k];
+    y[i] = s / A[6 * i + i];
   }
   return true;
 }
@@ -126,27 +126,34 @@ SICP_HD inline double gradient_max_norm(const double* x, const double* g) {
 }
 
 // From the accepted iterate: terminate, or compute the next trust-region step and publish the
-// candidate in s.pose.
+// candidate in s.pose.  The retry loop (an invalid step halves the radius and tries again without a
+// new evaluation) only contains the 6x6 solve: x and g do not change inside it, so the gradient
+// test is done once, before it -- same decisions in the same order as testing it every time.
 SICP_HD inline void lm_propose(LmState& s) {
   const LmOptions& opt = s.opt;
+  if (s.iterations >= opt.max_iterations) { s.status = LM_ITERATION_CAP; return; }
+  if (gradient_max_norm(s.x, s.g) <= opt.gradient_tolerance) { s.status = LM_CONVERGED; return; }
+  double step[6], model_change;
   for (;;) {
-    if (s.iterations >= opt.max_iterations) { s.status = LM_ITERATION_CAP; return; }
-    if (gradient_max_norm(s.x, s.g) <= opt.gradient_tolerance) { s.status = LM_CONVERGED; return; }
+#if defined(__HIP_DEVICE_COMPILE__)
+    // keeps the compiler from hoisting the loop-invariant half of the state into registers for
+    // the (almost never taken) retry: that doubles the register allocation of the kernel
+    asm volatile("" ::: "memory");
+#endif
     if (s.radius <= opt.min_radius) { s.status = LM_CONVERGED; return; }
     s.iterations++;
-    double Hs[36], gs[6];
+    // scaled system Hs = S H S, gs = S g.  Hs is not kept: the lower triangle goes into A (which
+    // the factorisation overwrites) and the model change below recomputes the entries it needs.
+    double A[36], gs[6], y[6];
     SICP_UNROLL
     for (int a = 0; a < 6; ++a) {
       gs[a] = s.g[a] * s.scale[a];
       SICP_UNROLL
-      for (int b = 0; b < 6; ++b) Hs[6 * a + b] = s.H[6 * a + b] * s.scale[a] * s.scale[b];
+      for (int b = 0; b <= a; ++b) A[6 * a + b] = s.H[6 * a + b] * s.scale[a] * s.scale[b];
     }
     if (!s.reuse_diagonal)
       SICP_UNROLL
-      for (int j = 0; j < 6; ++j) s.diag[j] = fmin(fmax(Hs[6 * j + j], opt.min_lm_diagonal), opt.max_lm_diagonal);
-    double A[36], y[6], step[6];
-    SICP_UNROLL
-    for (int i = 0; i < 36; ++i) A[i] = Hs[i];
+      for (int j = 0; j < 6; ++j) s.diag[j] = fmin(fmax(A[6 * j + j], opt.min_lm_diagonal), opt.max_lm_diagonal);
     SICP_UNROLL
     for (int j = 0; j < 6; ++j) {
       const double lm = sqrt(s.diag[j] / s.radius);  // lm_diagonal_
@@ -154,7 +161,7 @@ SICP_HD inline void lm_propose(LmState& s) {
     }
     s.reuse_diagonal = 1;
     const bool ok = chol6_solve(A, gs, y);
-    double model_change = 0;
+    model_change = 0;
     if (ok) {
       double sg = 0, sHs = 0;
       SICP_UNROLL
@@ -164,25 +171,23 @@ SICP_HD inline void lm_propose(LmState& s) {
         sg += step[a] * gs[a];
         double r = 0;
         SICP_UNROLL
-        for (int b = 0; b < 6; ++b) r += Hs[6 * a + b] * step[b];
+        for (int b = 0; b < 6; ++b) r += (s.H[6 * a + b] * s.scale[a] * s.scale[b]) * step[b];
         sHs += step[a] * r;
       }
       model_change = -(sg + 0.5 * sHs);
     }
-    if (!ok || !(model_change > 0.0)) {
-      if (++s.invalid >= opt.max_consecutive_invalid_steps) { s.status = LM_INVALID_STEPS; return; }
-      s.radius *= 0.5;
-      continue;
-    }
-    s.invalid = 0;
-    double delta[6];
-    SICP_UNROLL
-    for (int j = 0; j < 6; ++j) delta[j] = step[j] * s.scale[j];
-    se3::plus(s.x, delta, s.pose);
-    s.model_change = model_change;
-    s.phase = 1;
-    return;
+    if (ok && model_change > 0.0) break;
+    if (++s.invalid >= opt.max_consecutive_invalid_steps) { s.status = LM_INVALID_STEPS; return; }
+    s.radius *= 0.5;
+    if (s.iterations >= opt.max_iterations) { s.status = LM_ITERATION_CAP; return; }
   }
+  s.invalid = 0;
+  double delta[6];
+  SICP_UNROLL
+  for (int j = 0; j < 6; ++j) delta[j] = step[j] * s.scale[j];
+  se3::plus(s.x, delta, s.pose);
+  s.model_change = model_change;
+  s.phase = 1;
 }
 
 }  // namespace detail

@@ -27,6 +27,17 @@ namespace se3 {
 #define SICP_SE3_EPS 1e-10  /* Sophus::Constants<double>::epsilon() */
 #define SICP_SE3_PI 3.14159265358979323846
 
+// sin and cos of one angle; on the GPU one call shares the argument reduction (the one-lane LM
+// step is instruction-count bound), the values are those of sin() and cos()
+SICP_HD inline void sincos_pair(double a, double* s, double* c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  ::sincos(a, s, c);
+#else
+  *s = sin(a);
+  *c = cos(a);
+#endif
+}
+
 // Eigen Quaternion::toRotationMatrix (no normalisation), row-major
 SICP_HD inline void rotation(const double* qt, double* R) {
   const double x = qt[0], y = qt[1], z = qt[2], w = qt[3];
@@ -68,8 +79,10 @@ SICP_HD inline void exp(const double* a, double* qt) {
     imag = 0.5 - theta_sq / 48.0 + t4 / 3840.0;
     real = 1.0 - theta_sq / 8.0 + t4 / 384.0;
   } else {
-    imag = sin(0.5 * theta) / theta;
-    real = cos(0.5 * theta);
+    double sh, ch;
+    sincos_pair(0.5 * theta, &sh, &ch);
+    imag = sh / theta;
+    real = ch;
   }
   qt[0] = imag * w[0]; qt[1] = imag * w[1]; qt[2] = imag * w[2]; qt[3] = real;
   // V = I + (1-cos)/th^2 * W + (th - sin)/th^3 * W^2 ; small angle: V = R
@@ -77,7 +90,9 @@ SICP_HD inline void exp(const double* a, double* qt) {
   if (theta < SICP_SE3_EPS) {
     rotation(qt, V);
   } else {
-    const double c1 = (1 - cos(theta)) / theta_sq, c2 = (theta - sin(theta)) / (theta_sq * theta);
+    double st, ct;
+    sincos_pair(theta, &st, &ct);
+    const double c1 = (1 - ct) / theta_sq, c2 = (theta - st) / (theta_sq * theta);
     const double W[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
     double W2[9];
     SICP_SE3_UNROLL

@@ -119,6 +119,7 @@ struct sicp_context {
   DevBuf<double> partials, out28;
   DevBuf<long long> d_count;
   DevBuf<sicp::LmState> d_lm;
+  DevBuf<unsigned> d_ticket;  // arrival counter of the fused LM step (zero between launches)
   // one batch of the device-resident solve ([accumulate, lm_step] x lm_batch) captured as a graph:
   // a single launch call per batch instead of 2 x lm_batch trips through the runtime's launch path
   hipGraphExec_t lm_graph = nullptr;
@@ -281,7 +282,7 @@ int run_nn(sicp_context* h, int K, const Cloud& Qc, int q_begin, int q_count, co
     if (timer_bit == SICP_PROFILE_NN) { h->st.nn_kernel_ms += ms; h->st.nn_launches += 1; }
     else { h->st.cov_kernel_ms += ms; h->st.cov_launches += 1; }
   };
-  if (h->params.nn_method == 1) {
+  if (h->params.nn_method >= 1) {
     sicp::KnnArgs a;
     a.qx = Qc.x.p; a.qy = Qc.y.p; a.qz = Qc.z.p;
     a.q_begin = q_begin; a.q_count = q_count;
@@ -301,8 +302,9 @@ int run_nn(sicp_context* h, int K, const Cloud& Qc, int q_begin, int q_count, co
     if (want_dbg) { HIPCHECK(dbg.reserve((size_t)2 * q_count)); a.dbg = dbg.p; }
     static const bool lane_per_query = std::getenv("SICP_KNN_LANE_PER_QUERY") != nullptr;  // A/B aid
     KernelTimer kt(h, stream == h->stream ? timer_bit : 0);
-    if (lane_per_query || want_dbg) HIPCHECK(sicp::launch_bvh_knn(K, a, stream));
-    else HIPCHECK(sicp::launch_bvh_knn_quad(K, a, stream));
+    if (lane_per_query) HIPCHECK(sicp::launch_bvh_knn(K, a, stream));
+    else if (h->params.nn_method == 2) HIPCHECK(sicp::launch_bvh_knn_quad(K, a, stream));
+    else HIPCHECK(sicp::launch_bvh_knn_packet(K, a, stream));
     account(kt.stop());
     if (want_dbg) {
       std::vector<int> hd((size_t)2 * q_count);
@@ -592,6 +594,17 @@ int run_solve(sicp_context* h, const double* init_qt, double* out_qt, SolveResul
   std::memset(&a, 0, sizeof a);  // padding bytes take part in the graph-cache comparison
   fill_acc(h, a);
   a.lm = h->d_lm.p;
+  // the fused kernel keeps the solver state in registers (one wave per SIMD): use it while one
+  // round of blocks covers the launch, the two-kernel form beyond (the boundary is then noise)
+  const bool fused = P.lm_on_device >= 2 && nb <= 256;
+  if (fused) {
+    if (!h->d_ticket.p) {
+      HIPCHECK(h->d_ticket.reserve(1));
+      HIPCHECK(hipMemsetAsync(h->d_ticket.p, 0, sizeof(unsigned), h->stream));
+    }
+    a.lm_step = h->d_lm.p;
+    a.ticket = h->d_ticket.p;
+  }
   const int batch = P.lm_batch > 0 ? P.lm_batch : 12;
   if (!h->lm_graph || h->lm_graph_batch != batch || std::memcmp(&h->lm_graph_args, &a, sizeof a) != 0) {
     // (re)capture: the arguments only change when a buffer was reallocated or the mode changed
@@ -599,7 +612,8 @@ int run_solve(sicp_context* h, const double* init_qt, double* out_qt, SolveResul
     hipGraph_t g = nullptr;
     HIPCHECK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
     hipError_t ce = hipSuccess;
-    for (int b = 0; b < batch && ce == hipSuccess; ++b) ce = sicp::launch_accumulate_lm(a, h->d_lm.p, h->stream);
+    for (int b = 0; b < batch && ce == hipSuccess; ++b)
+      ce = fused ? sicp::launch_accumulate_fused(a, h->stream) : sicp::launch_accumulate_lm(a, h->d_lm.p, h->stream);
     hipError_t ee = hipStreamEndCapture(h->stream, &g);
     HIPCHECK(ce);
     HIPCHECK(ee);
@@ -686,8 +700,8 @@ int sicp_default_params(int mode, sicp_params* p) {
   p->jacobi_scaling = 1;
   p->quirk_bool_probability = 1;
   p->quirk_float_products = 1;
-  p->nn_method = 1;  // exact box-tree search; 0 = LDS-tiled brute force (same results)
-  p->lm_on_device = 1;
+  p->nn_method = 1;  // exact box-tree search, packet walk; 2 = per-query walk; 0 = LDS-tiled brute force (same results)
+  p->lm_on_device = 2;
   p->lm_batch = 8;   // 16 kernel nodes per graph: longer graphs replay with a ~50 us bubble every 16 nodes
   if (mode == SICP_MODE_EM) {
     p->knn = 4; p->cauchy_a = 3.0; p->use_sqloss = 1;  // em_icp.hpp:60,111,115
@@ -750,7 +764,7 @@ int sicp_set_params(sicp_handle h, const sicp_params* p) {
   if (!h || !p) return SICP_ERR_INVALID_ARGUMENT;
   if (p->mode < SICP_MODE_GICP || p->mode > SICP_MODE_SEMANTIC) return SICP_ERR_INVALID_ARGUMENT;
   if (!sicp::nn_k_supported(p->knn) || !sicp::nn_k_supported(p->k_cov)) return SICP_ERR_INVALID_ARGUMENT;
-  if (!(p->epsilon > 0) || !(p->cauchy_a > 0) || p->nn_method < 0 || p->nn_method > 1) return SICP_ERR_INVALID_ARGUMENT;
+  if (!(p->epsilon > 0) || !(p->cauchy_a > 0) || p->nn_method < 0 || p->nn_method > 2) return SICP_ERR_INVALID_ARGUMENT;
   // engine knobs (profiling, batching) do not invalidate the correspondences held on the device
   sicp_params a = h->params, b = *p;
   a.profile = b.profile = 0; a.lm_batch = b.lm_batch = 0; a.lm_on_device = b.lm_on_device = 0;
@@ -833,7 +847,7 @@ int sicp_align(sicp_handle h, const double init_qt[7], double out_qt[7], int32_t
     const double t0 = now_ms();
     // the two clouds' feature kernels are independent and latency bound: run them side by side
     // (not with brute force, which shares one scratch buffer, nor while those kernels are timed)
-    const bool side_by_side = P.nn_method == 1 && !(P.profile & SICP_PROFILE_COV);
+    const bool side_by_side = P.nn_method >= 1 && !(P.profile & SICP_PROFILE_COV);
     if (!sem || !features_current(h, S, false)) SICPCHECK(compute_features(h, S, em));
     if (!sem || !features_current(h, T, false)) {
       SICPCHECK(compute_features(h, T, em, side_by_side ? h->stream2 : h->stream));

@@ -57,13 +57,13 @@ def oracle_params(mode, C=0, **kw):
     return p
 
 
-@pytest.fixture(params=[0, 1], ids=["bruteforce", "boxtree"])
+@pytest.fixture(params=[0, 1, 2], ids=["bruteforce", "boxtree", "boxtree_per_query"])
 def nn(request):
     """Both exact kNN engines (sicp_params.nn_method) must give bit-identical results."""
     return request.param
 
 
-@pytest.fixture(params=[0, 1], ids=["hostlm", "devicelm"])
+@pytest.fixture(params=[0, 1, 2], ids=["hostlm", "devicelm", "fusedlm"])
 def lm(request):
     """Host-loop and device-resident inner solve run the same LM machine (csrc/lm.hpp)."""
     return request.param
