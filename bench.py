@@ -56,6 +56,10 @@ def parse_args():
     ap.add_argument("--profile", type=int, default=0,
                     help="SICP_PROFILE_* mask applied inside the timed region (default 0: the roofline kernels are timed with "
                          "HIP events right after it, on the same data and streams)")
+    ap.add_argument("--concurrency", choices=["lockstep", "threads"], default="lockstep",
+                    help="how the pairs in flight share the GPU: one sicp_align_batch call (lock step, batched launches) or "
+                         "one host thread + stream per pair")
+    ap.add_argument("--timed-only", action="store_true", help="skip the single-pair / roofline / CPU legs (for tracing the timed region)")
     ap.add_argument("--dry-run", action="store_true", help="exercise the multi-process plumbing without a GPU")
     return ap.parse_args()
 
@@ -172,11 +176,15 @@ def main():
         def step():
             if S == 1:
                 return engine.align(ident)
-            # S independent registrations in flight: one host thread per handle (ctypes drops the GIL)
-            import concurrent.futures as cf
+            if args.concurrency == "lockstep":
+                # S independent registrations advanced in lock step by one call (batched launches)
+                res = sicp.align_batch(engines)
+            else:
+                # S independent registrations in flight: one host thread per handle (ctypes drops the GIL)
+                import concurrent.futures as cf
 
-            with cf.ThreadPoolExecutor(S) as ex:
-                res = list(ex.map(lambda e: e.align(ident), engines))
+                with cf.ThreadPoolExecutor(S) as ex:
+                    res = list(ex.map(lambda e: e.align(ident), engines))
             qt0, st0 = res[0]
             agg = dict(st0)
             for _, st in res[1:]:
@@ -207,7 +215,7 @@ def main():
     elapsed_max = dist.reduce(elapsed, "max")
     corr_all = dist.reduce(float(corr), "sum")
     single = None
-    if engine and dist.rank == 0:
+    if engine and dist.rank == 0 and not args.timed_only:
         # latency of one pair alone on the GPU (outside the timed region)
         reps = 3
         engine.align(ident)
@@ -255,7 +263,7 @@ def main():
             out["accumulate_kernel_us_per_launch"] = 1e3 * acc_ms / max(1, acc_launches)
         if single:
             out["single_pair"] = single
-        if not args.dry_run:
+        if not args.dry_run and not args.timed_only:
             # --- rooflines (SURVEY.md 8d per-unit bytes x units per launch / HIP-event duration) -------
             # accumulate: the path's HBM-model kernel (38 B per correspondence per pass); timed alone
             # with HIP events on the handle's stream, right after the timed region, on the
@@ -302,7 +310,7 @@ def main():
                         "FP32-VALU bound: 1e10 pair evaluations per launch",
                 "pair_evals_per_s_if_brute_force": float(n) * n / (avg_ms * 1e-3),
             }]
-        if not args.dry_run and not args.no_cpu_baseline:
+        if not args.dry_run and not args.no_cpu_baseline and not args.timed_only:
             base, oq = cpu_baseline(src, sl, tgt, tl, cm)
             from scipy.spatial.transform import Rotation
 

@@ -110,9 +110,10 @@ typedef struct sicp_params {
   int32_t lm_on_device;           /* 0 = host loop (one synchronisation per evaluation);
                                      1 = trust-region state lives on the GPU, accumulate
                                      kernel + one-wave step kernel per evaluation, the
-                                     host polls once per batch; 2 (default) = the same with
+                                     host polls once per batch (default); 2 = the same with
                                      the step fused into the accumulate kernel's last
-                                     block.  Same machine (csrc/lm.hpp), same iterates.  */
+                                     block (measured: no faster).  Same machine
+                                     (csrc/lm.hpp), same iterates.                       */
   int32_t lm_batch;               /* evaluations queued per host poll (lm_on_device)    */
 } sicp_params;
 
@@ -169,6 +170,13 @@ int sicp_set_confusion(sicp_handle h, int32_t C, const double* cm_rowmajor);
  * stats may be NULL. */
 int sicp_align(sicp_handle h, const double init_qt[7], double out_qt[7],
                int32_t* outer_iters, sicp_stats* stats);
+/* n independent align() calls -- one handle per scan pair, all on one device, same mode /
+ * knn / solver knobs -- advanced in lock step: every launch of the inner solve evaluates
+ * all pairs at once (what exec/kitti_eval.cc:124-249 does pair after pair).  Per pair the
+ * result is bit-identical to sicp_align on that handle.  init_qt, out_qt: n*7;
+ * outer_iters (nullable): n; stats (nullable): n.  No reference counterpart. */
+int sicp_align_batch(sicp_handle* handles, int32_t n, const double* init_qt, double* out_qt,
+                     int32_t* outer_iters, sicp_stats* stats);
 
 /* the final_cloud output of align (em_icp.hpp:192-198): source transformed by
  * float(matrix(qt)); ox/oy/oz are host buffers of n_source floats */
@@ -196,6 +204,10 @@ int sicp_correspondences(sicp_handle h, const double qt[7], int32_t* idx, float*
  * g = sum rho1 r J, cost = 1/2 sum rho0 (what ceres::Evaluator produces from
  * GICPCostFunction::Evaluate gicp_cost_function.h:27-73 through the losses). */
 int sicp_accumulate(sicp_handle h, const double qt[7], double out28[28]);
+/* the same sweep for n handles in ONE launch (the kernel sicp_align_batch runs): qt n*7,
+ * out28 n*28; kernel_ms (nullable) = HIP-event time of that launch on handles[0]'s stream */
+int sicp_accumulate_batch(sicp_handle* handles, int32_t n, const double* qt, double* out28,
+                          double* kernel_ms);
 /* the inner ceres::Solve (em_icp.hpp:162-177) on the current correspondences */
 int sicp_solve(sicp_handle h, const double init_qt[7], double out_qt[7], int32_t* lm_iters,
                int32_t* evals, double* final_cost);

@@ -146,6 +146,8 @@ def lib():
             "sicp_set_cloud_device": [C.c_void_p, C.c_int, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
             "sicp_set_confusion": [C.c_void_p, C.c_int32, _dp],
             "sicp_align": [C.c_void_p, _dp, _dp, _ip, C.POINTER(SicpStats)],
+            "sicp_align_batch": [C.POINTER(C.c_void_p), C.c_int32, _dp, _dp, _ip, C.POINTER(SicpStats)],
+            "sicp_accumulate_batch": [C.POINTER(C.c_void_p), C.c_int32, _dp, _dp, _dp],
             "sicp_transform_source": [C.c_void_p, _dp, _fp, _fp, _fp],
             "sicp_fused_labels": [C.c_void_p, _dp, _up],
             "sicp_covariances": [C.c_void_p, C.c_int, _dp, _dp, _bp, _ip],
@@ -317,3 +319,38 @@ class Engine:
 
     def synchronize(self):
         self._check(lib().sicp_synchronize(self._h), "sicp_synchronize")
+
+
+# ---- lock-step batch over several engines (one per scan pair) ---------------------------------
+def _handles(engines):
+    arr = (C.c_void_p * len(engines))(*[e._h for e in engines])
+    return arr
+
+
+def align_batch(engines, init_qts=None, want_stats: bool = True):
+    """sicp_align_batch: every engine registers its own pair, advanced in lock step.
+    Returns [(qt, stats)] in the order of `engines`; per pair identical to Engine.align."""
+    n = len(engines)
+    init = np.tile(np.array([0, 0, 0, 1, 0, 0, 0], dtype=np.float64), (n, 1)) if init_qts is None else \
+        np.ascontiguousarray(init_qts, dtype=np.float64).reshape(n, 7)
+    out = np.empty((n, 7))
+    its = np.zeros(n, dtype=np.int32)
+    sts = (SicpStats * n)()
+    rc = lib().sicp_align_batch(_handles(engines), n, _ptr(init, _dp), _ptr(out, _dp), _ptr(its, _ip), sts if want_stats else None)
+    if rc != 0:
+        msgs = "; ".join(m for m in (lib().sicp_last_error(e._h).decode() for e in engines) if m)
+        raise RuntimeError(f"sicp_align_batch failed: {_strerror(rc)} ({rc}) {msgs}")
+    return [(out[p].copy(), (sts[p].as_dict() if want_stats else {"outer_iters": int(its[p])})) for p in range(n)]
+
+
+def accumulate_batch(engines, qts):
+    """sicp_accumulate_batch: the 28 sums of every engine's current correspondences from one launch.
+    Returns (out28 [n, 28], kernel_ms)."""
+    n = len(engines)
+    qts = np.ascontiguousarray(qts, dtype=np.float64).reshape(n, 7)
+    out = np.empty((n, 28))
+    ms = C.c_double(0.0)
+    rc = lib().sicp_accumulate_batch(_handles(engines), n, _ptr(qts, _dp), _ptr(out, _dp), C.byref(ms))
+    if rc != 0:
+        raise RuntimeError(f"sicp_accumulate_batch failed: {_strerror(rc)} ({rc})")
+    return out, ms.value

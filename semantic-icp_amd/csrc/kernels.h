@@ -117,7 +117,15 @@ struct AccArgs {
   unsigned* ticket;     // block-arrival counter of the fused step (zero between launches)
   double one_m_eps;
   LossArgs loss;
-  double* partials;  // [accumulate_blocks][28]
+  double* partials;  // [28][accumulate_blocks]
+  const double* partials_in;  // chained solve: the previous launch's partials (fed in this launch's prologue)
+};
+
+// one pair of a lock-step batch (sicp_align_batch); an array of these lives in HBM
+struct BatchArgs {
+  AccArgs a;
+  int nb;    // accumulate blocks of this pair (its partials are [28][nb])
+  int pad_;
 };
 
 bool nn_k_supported(int K);
@@ -137,6 +145,10 @@ hipError_t launch_finalize(const AccArgs& a, double* out28, hipStream_t st);
 // one evaluation of the device-resident solve: accumulate at lm->pose, then feed the LM machine
 hipError_t launch_accumulate_lm(const AccArgs& a, LmState* lm, hipStream_t st);
 hipError_t launch_accumulate_fused(const AccArgs& a, hipStream_t st);
+hipError_t launch_accumulate_chain(const AccArgs& a, hipStream_t st);
+hipError_t launch_accumulate_batch(int K, const BatchArgs* batch, int n, int max_nb, hipStream_t st);
+hipError_t launch_lm_step_batch(const BatchArgs* batch, int n, hipStream_t st);
+hipError_t launch_finalize_batch(const BatchArgs* batch, int n, double* out28, hipStream_t st);
 hipError_t launch_count_active(const int* idx, int n, unsigned long long* out, hipStream_t st);
 hipError_t launch_transform_float(int n, const float* x, const float* y, const float* z, const Mat4f& M,
                                   float* ox, float* oy, float* oz, hipStream_t st);

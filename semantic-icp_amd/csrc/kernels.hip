@@ -563,11 +563,15 @@ __device__ __forceinline__ unsigned child_mask_packet(const float4* __restrict__
   return (unsigned)b & 15u;
 }
 
-template <int K>
-__global__ __launch_bounds__(64) void bvh_knn_packet_kernel(KnnArgs a) {
-  __shared__ u64 s_merge[16][4][K];
-  const int lane = threadIdx.x, sub = lane & 3, slot = lane >> 2;
-  const int bid = xcd_contiguous_block((int)blockIdx.x, (int)gridDim.x);
+// WPB waves (packets) per workgroup: one-wave workgroups are launched too slowly to fill the chip
+// (6250 of them at 100K queries: ~1.5 waves per SIMD resident on average)
+template <int K, int WPB>
+__global__ __launch_bounds__(64 * WPB) void bvh_knn_packet_kernel(KnnArgs a) {
+  __shared__ u64 s_merge_all[WPB][16][4][K];
+  u64 (&s_merge)[16][4][K] = s_merge_all[threadIdx.x >> 6];
+  const int lane = threadIdx.x & 63, sub = lane & 3, slot = lane >> 2;
+  const int bid = xcd_contiguous_block((int)blockIdx.x, (int)gridDim.x) * WPB + (int)(threadIdx.x >> 6);
+  if (bid * 16 >= a.q_count) return;  // a surplus wave of the last workgroup (no barrier below is block-wide)
   const int q_raw = bid * 16 + slot;
   const int q = min(q_raw, a.q_count - 1);  // a padding quad repeats the last query and is not emitted
   float px, py, pz;
@@ -659,7 +663,9 @@ __global__ __launch_bounds__(64) void bvh_knn_packet_kernel(KnnArgs a) {
   // --- merge the quad's four ascending lists (LDS), lane 0 of the quad emits
 #pragma unroll
   for (int k = 0; k < K; ++k) s_merge[slot][sub][k] = bk[k];
-  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the wave's own LDS writes, read below by its lanes 0 mod 4
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   if (sub == 0 && q_raw < a.q_count) {
     int p0 = 0, p1 = 0, p2 = 0, p3 = 0;
     const size_t o = (size_t)(a.q_begin + q) * K;
@@ -929,6 +935,74 @@ __device__ __forceinline__ double wave_sum(double v) {
   return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
 }
 
+#define SICP_GLOBAL __attribute__((address_space(1)))
+
+// the per-lane part of one evaluation: groups of 4 slots, loads first (see accumulate_kernel)
+template <int K, int BS>
+__device__ __forceinline__ void accumulate_groups(const AccArgs& a, const Pose& P, int block, int nb, double (&acc)[28]) {
+#pragma unroll
+  for (int k = 0; k < 28; ++k) acc[k] = 0.0;
+  // every array is HBM: typed as such, the loads are global_load even when the pointers themselves
+  // were fetched from memory (batch form), where the compiler would otherwise emit flat_load
+  const SICP_GLOBAL int* idx = (const SICP_GLOBAL int*)a.idx;
+  const SICP_GLOBAL double* wgt = (const SICP_GLOBAL double*)a.w;
+  const SICP_GLOBAL float *sx = (const SICP_GLOBAL float*)a.sx, *sy = (const SICP_GLOBAL float*)a.sy, *sz = (const SICP_GLOBAL float*)a.sz;
+  const SICP_GLOBAL float *tx = (const SICP_GLOBAL float*)a.tx, *ty = (const SICP_GLOBAL float*)a.ty, *tz = (const SICP_GLOBAL float*)a.tz;
+  const SICP_GLOBAL double *g_snx = (const SICP_GLOBAL double*)a.snx, *g_sny = (const SICP_GLOBAL double*)a.sny, *g_snz = (const SICP_GLOBAL double*)a.snz;
+  const SICP_GLOBAL double *g_tnx = (const SICP_GLOBAL double*)a.tnx, *g_tny = (const SICP_GLOBAL double*)a.tny, *g_tnz = (const SICP_GLOBAL double*)a.tnz;
+  const int total = a.n_s * K;
+  const int n_groups = (total + 3) >> 2;
+  for (int g = block * BS + threadIdx.x; g < n_groups; g += nb * BS) {
+    const int e0 = g << 2;
+    int j[4], i[4];
+    double w[4];
+    if (e0 + 3 < total) {
+      typedef int v4i __attribute__((ext_vector_type(4)));
+      const v4i jv = *(const SICP_GLOBAL v4i*)(idx + e0);
+      j[0] = jv.x; j[1] = jv.y; j[2] = jv.z; j[3] = jv.w;
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) j[c] = e0 + c < total ? idx[e0 + c] : -1;
+    }
+    float sxv[4], syv[4], szv[4], txv[4], tyv[4], tzv[4];
+    double snx[4], sny[4], snz[4], tnx[4], tny[4], tnz[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      i[c] = min((e0 + c) / K, a.n_s - 1);
+      const int jj = max(j[c], 0);
+      w[c] = wgt ? wgt[min(e0 + c, total - 1)] : 1.0;
+      if (K != 4 || c == 0) {
+        sxv[c] = sx[i[c]]; syv[c] = sy[i[c]]; szv[c] = sz[i[c]];
+        snx[c] = g_snx[i[c]]; sny[c] = g_sny[i[c]]; snz[c] = g_snz[i[c]];
+      } else {  // K == 4: the four slots of a group share one source point
+        sxv[c] = sxv[0]; syv[c] = syv[0]; szv[c] = szv[0];
+        snx[c] = snx[0]; sny[c] = sny[0]; snz[c] = snz[0];
+      }
+      txv[c] = tx[jj]; tyv[c] = ty[jj]; tzv[c] = tz[jj];
+      tnx[c] = g_tnx[jj]; tny[c] = g_tny[jj]; tnz[c] = g_tnz[jj];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma clang fp contract(fast)
+      if (j[c] < 0) continue;
+      Corr cr;
+      corr_eval<true>(P, a.one_m_eps, sxv[c], syv[c], szv[c], snx[c], sny[c], snz[c], txv[c], tyv[c], tzv[c], tnx[c],
+                      tny[c], tnz[c], cr);
+      double rho0, rho1;
+      loss_eval(a.loss, cr.r * cr.r, w[c], rho0, rho1);
+      int o = 0;
+#pragma unroll
+      for (int p = 0; p < 6; ++p) {
+        const double jp = rho1 * cr.J[p];
+#pragma unroll
+        for (int q = p; q < 6; ++q) acc[o++] += jp * cr.J[q];
+        acc[21 + p] += jp * cr.r;
+      }
+      acc[27] += 0.5 * rho0;
+    }
+  }
+}
+
 // One lane handles groups of 4 consecutive slots: all index / weight / point / normal loads of the
 // group are issued before the first residual is computed (4 independent gather chains in flight
 // per lane instead of one), then the 28 partial sums are combined across the block through an
@@ -952,58 +1026,7 @@ __global__ __launch_bounds__(BS) void accumulate_kernel(AccArgs a) {
     P = a.pose;
   }
   double acc[28];
-#pragma unroll
-  for (int k = 0; k < 28; ++k) acc[k] = 0.0;
-  const int total = a.n_s * K;
-  const int n_groups = (total + 3) >> 2;
-  for (int g = blockIdx.x * BS + threadIdx.x; g < n_groups; g += gridDim.x * BS) {
-    const int e0 = g << 2;
-    int j[4], i[4];
-    double w[4];
-    if (e0 + 3 < total) {
-      const int4 jv = *reinterpret_cast<const int4*>(a.idx + e0);
-      j[0] = jv.x; j[1] = jv.y; j[2] = jv.z; j[3] = jv.w;
-    } else {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) j[c] = e0 + c < total ? a.idx[e0 + c] : -1;
-    }
-    float sxv[4], syv[4], szv[4], txv[4], tyv[4], tzv[4];
-    double snx[4], sny[4], snz[4], tnx[4], tny[4], tnz[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      i[c] = min((e0 + c) / K, a.n_s - 1);
-      const int jj = max(j[c], 0);
-      w[c] = a.w ? a.w[min(e0 + c, total - 1)] : 1.0;
-      if (K != 4 || c == 0) {
-        sxv[c] = a.sx[i[c]]; syv[c] = a.sy[i[c]]; szv[c] = a.sz[i[c]];
-        snx[c] = a.snx[i[c]]; sny[c] = a.sny[i[c]]; snz[c] = a.snz[i[c]];
-      } else {  // K == 4: the four slots of a group share one source point
-        sxv[c] = sxv[0]; syv[c] = syv[0]; szv[c] = szv[0];
-        snx[c] = snx[0]; sny[c] = sny[0]; snz[c] = snz[0];
-      }
-      txv[c] = a.tx[jj]; tyv[c] = a.ty[jj]; tzv[c] = a.tz[jj];
-      tnx[c] = a.tnx[jj]; tny[c] = a.tny[jj]; tnz[c] = a.tnz[jj];
-    }
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-#pragma clang fp contract(fast)
-      if (j[c] < 0) continue;
-      Corr cr;
-      corr_eval<true>(P, a.one_m_eps, sxv[c], syv[c], szv[c], snx[c], sny[c], snz[c], txv[c], tyv[c], tzv[c], tnx[c],
-                      tny[c], tnz[c], cr);
-      double rho0, rho1;
-      loss_eval(a.loss, cr.r * cr.r, w[c], rho0, rho1);
-      int o = 0;
-#pragma unroll
-      for (int p = 0; p < 6; ++p) {
-        const double jp = rho1 * cr.J[p];
-#pragma unroll
-        for (int q = p; q < 6; ++q) acc[o++] += jp * cr.J[q];
-        acc[21 + p] += jp * cr.r;
-      }
-      acc[27] += 0.5 * rho0;
-    }
-  }
+  accumulate_groups<K, BS>(a, P, (int)blockIdx.x, (int)gridDim.x, acc);
   // block reduction: transpose through LDS, then wave w owns outputs w, w + BS/64, ...
 #pragma unroll
   for (int k = 0; k < 28; ++k) red[k][threadIdx.x] = acc[k];
@@ -1080,6 +1103,126 @@ __global__ __launch_bounds__(BS) void accumulate_kernel(AccArgs a) {
   }
 }
 
+// Chained device-resident solve: one kernel per LM evaluation and nothing in between.
+//
+// Launch n reads state[n & 1] and the partials of launch n-1, and EVERY block first finishes that
+// previous evaluation itself: it sums the partials (four waves, seven rows each, the fixed order of
+// reduce_partials) and runs lm_feed in its lane 0 -- all blocks compute the same bits, so all of
+// them know the next pose without a second kernel, a grid barrier or a fence ("combine in the next
+// kernel's prologue").  Then the block accumulates its share of the new evaluation into
+// partials[(n+1) & 1]; block 0 also publishes the advanced state as state[(n+1) & 1] (double
+// buffering: other blocks of this launch may still be reading state[n & 1]).  The loads of the
+// block's first slots do not depend on the pose and are in flight while lane 0 steps the solver.
+template <int K, int BS>
+__global__ __launch_bounds__(BS) void accumulate_chain_kernel(AccArgs a) {
+  __shared__ double red[28][BS];
+  constexpr int NSTATE = (int)(sizeof(LmState) / 8);
+  static_assert(sizeof(LmState) % 8 == 0, "LmState is copied as doubles");
+  __shared__ double s_state[NSTATE];
+  __shared__ double s_out[28];
+  constexpr int NW = BS / 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nb = (int)gridDim.x;
+  const double* __restrict__ g_in = reinterpret_cast<const double*>(a.lm);
+  for (int i = threadIdx.x; i < NSTATE; i += BS) s_state[i] = g_in[i];
+  // the previous launch's partials: issued before anybody looks at the state (one round trip
+  // for both); harmless when there is nothing pending
+  {
+    for (int k = wave; k < 28; k += NW) {
+      const double* __restrict__ row = a.partials_in + (size_t)k * nb;
+      double s = 0.0;
+      for (int b0 = lane; b0 < nb; b0 += 64 * 4) {
+        double v[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = b0 + 64 * t < nb ? row[b0 + 64 * t] : 0.0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          if (b0 + 64 * t < nb) s += v[t];
+      }
+      s = wave_sum(s);
+      if (lane == 0) s_out[k] = s;
+    }
+  }
+  __syncthreads();
+  LmState* S = reinterpret_cast<LmState*>(s_state);
+  if (S->status == LM_RUNNING && S->pending) {
+    if (threadIdx.x == 0) {
+      double o[28];
+#pragma unroll
+      for (int k = 0; k < 28; ++k) o[k] = s_out[k];
+      LmState st = *S;
+      lm_feed(st, o);
+      st.pending = 0;
+      *S = st;
+    }
+    __syncthreads();
+  }
+  double* g_out = reinterpret_cast<double*>(a.lm_step);
+  if (S->status != LM_RUNNING) {  // finished (now or earlier): hand the state on, nothing to evaluate
+    if (blockIdx.x == 0)
+      for (int i = threadIdx.x; i < NSTATE; i += BS) g_out[i] = s_state[i];
+    return;
+  }
+  Pose P;
+  se3::rotation(S->pose, P.R);
+  P.t[0] = S->pose[4]; P.t[1] = S->pose[5]; P.t[2] = S->pose[6];
+  double acc[28];
+  accumulate_groups<K, BS>(a, P, (int)blockIdx.x, nb, acc);
+#pragma unroll
+  for (int k = 0; k < 28; ++k) red[k][threadIdx.x] = acc[k];
+  __syncthreads();
+  for (int k = wave; k < 28; k += NW) {
+    double sum = 0.0;
+#pragma unroll
+    for (int t = 0; t < NW; ++t) sum += red[k][lane + 64 * t];
+    sum = wave_sum(sum);
+    if (lane == 0) a.partials[(size_t)k * nb + blockIdx.x] = sum;
+  }
+  if (blockIdx.x == 0) {
+    if (threadIdx.x == 0) S->pending = 1;
+    __syncthreads();
+    for (int i = threadIdx.x; i < NSTATE; i += BS) g_out[i] = s_state[i];
+  }
+}
+
+// Lock-step batch of independent pairs (sicp_align_batch): blockIdx.y selects the pair, whose
+// arguments live in HBM (one BatchArgs per pair, read through scalar loads).  One launch evaluates
+// the current LM pose of EVERY pair of the batch: P times fewer launches, launch boundaries and L2
+// invalidations than P pairs solving side by side on their own streams, and P x 15 MB of
+// algorithmic traffic behind one ~10 us launch floor.  Per pair the arithmetic, the block
+// decomposition and therefore the bits are those of accumulate_kernel.
+template <int K, int BS>
+__global__ __launch_bounds__(BS) void accumulate_batch_kernel(const BatchArgs* __restrict__ batch) {
+  __shared__ double red[28][BS];
+  const BatchArgs& B = batch[blockIdx.y];
+  const int nb = B.nb, block = (int)blockIdx.x;
+  if (block >= nb) return;
+  const AccArgs& a = B.a;
+  Pose P;
+  if (a.lm) {
+    if (a.lm->status != LM_RUNNING) return;
+    se3::rotation(a.lm->pose, P.R);
+    P.t[0] = a.lm->pose[4]; P.t[1] = a.lm->pose[5]; P.t[2] = a.lm->pose[6];
+  } else {
+    P = a.pose;
+  }
+  double acc[28];
+  accumulate_groups<K, BS>(a, P, block, nb, acc);
+#pragma unroll
+  for (int k = 0; k < 28; ++k) red[k][threadIdx.x] = acc[k];
+  __syncthreads();
+  constexpr int NW = BS / 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  SICP_GLOBAL double* partials = (SICP_GLOBAL double*)a.partials;
+  for (int k = wave; k < 28; k += NW) {
+    double sum = 0.0;
+#pragma unroll
+    for (int t = 0; t < NW; ++t) sum += red[k][lane + 64 * t];
+    sum = wave_sum(sum);
+    if (lane == 0) partials[(size_t)k * nb + block] = sum;
+  }
+}
+
 // fixed-order sum of the block partials (layout [28][n_blocks]) by one wave: every lane owns rows
 // lane, lane+64, ... ; the 28 loads of one trip are independent and coalesced
 __device__ __forceinline__ void reduce_partials(const double* __restrict__ partials, int n_blocks, int lane, double (&o)[28]) {
@@ -1130,6 +1273,33 @@ __global__ __launch_bounds__(64) void lm_step_kernel(LmState* lm, const double* 
     LmState st = *lm;
     lm_feed(st, o);
     *lm = st;
+  }
+}
+
+// batch forms: one block (one wave) per pair
+__global__ __launch_bounds__(64) void lm_step_batch_kernel(const BatchArgs* __restrict__ batch) {
+  const BatchArgs& B = batch[blockIdx.x];
+  LmState* lm = B.a.lm_step;
+  if (lm->status != LM_RUNNING) return;
+  const int lane = threadIdx.x;
+  double o[28];
+  reduce_partials(B.a.partials, B.nb, lane, o);
+  if (lane == 0) {
+    LmState st = *lm;
+    lm_feed(st, o);
+    *lm = st;
+  }
+}
+
+__global__ __launch_bounds__(64) void finalize_batch_kernel(const BatchArgs* __restrict__ batch, double* out28) {
+  const BatchArgs& B = batch[blockIdx.x];
+  double o[28];
+  reduce_partials(B.a.partials, B.nb, threadIdx.x, o);
+  if (threadIdx.x < 28) {
+    double v = 0.0;
+#pragma unroll
+    for (int k = 0; k < 28; ++k) v = threadIdx.x == k ? o[k] : v;
+    out28[28 * blockIdx.x + threadIdx.x] = v;
   }
 }
 
@@ -1245,13 +1415,18 @@ hipError_t launch_bvh_knn_quad(int K, const KnnArgs& a, hipStream_t st) {
 
 hipError_t launch_bvh_knn_packet(int K, const KnnArgs& a, hipStream_t st) {
   if (a.q_count <= 0) return hipSuccess;
-  dim3 grid((a.q_count + 15) / 16);
+  const int packets = (a.q_count + 15) / 16;
+  static const int wpb_small = [] { const char* e = getenv("SICP_KNN_WPB"); return e ? atoi(e) : 4; }();  // tuning aid
+  static const int wpb_big = [] { const char* e = getenv("SICP_KNN_WPB20"); return e ? atoi(e) : 2; }();
+  auto grid = [&](int wpb) { return dim3((packets + wpb - 1) / wpb); };
+#define SICP_PK(KK, W) hipLaunchKernelGGL((bvh_knn_packet_kernel<KK, W>), grid(W), dim3(64 * W), 0, st, a)
   switch (K) {
-    case 1: hipLaunchKernelGGL((bvh_knn_packet_kernel<1>), grid, dim3(64), 0, st, a); break;
-    case 4: hipLaunchKernelGGL((bvh_knn_packet_kernel<4>), grid, dim3(64), 0, st, a); break;
-    case 20: hipLaunchKernelGGL((bvh_knn_packet_kernel<20>), grid, dim3(64), 0, st, a); break;
+    case 1: if (wpb_small == 1) SICP_PK(1, 1); else if (wpb_small == 2) SICP_PK(1, 2); else SICP_PK(1, 4); break;
+    case 4: if (wpb_small == 1) SICP_PK(4, 1); else if (wpb_small == 2) SICP_PK(4, 2); else SICP_PK(4, 4); break;
+    case 20: if (wpb_big == 1) SICP_PK(20, 1); else if (wpb_big == 2) SICP_PK(20, 2); else SICP_PK(20, 4); break;
     default: return hipErrorInvalidValue;
   }
+#undef SICP_PK
   return hipGetLastError();
 }
 
@@ -1311,6 +1486,44 @@ static hipError_t launch_accumulate_only(const AccArgs& a, int nb, hipStream_t s
     case 1: hipLaunchKernelGGL((accumulate_kernel<1, 256, false>), dim3(nb), dim3(256), 0, st, a); break;
     case 4: hipLaunchKernelGGL((accumulate_kernel<4, 256, false>), dim3(nb), dim3(256), 0, st, a); break;
     case 20: hipLaunchKernelGGL((accumulate_kernel<20, 256, false>), dim3(nb), dim3(256), 0, st, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+// batched evaluation: `batch` holds n BatchArgs in HBM, max_nb = largest block count among them
+hipError_t launch_accumulate_batch(int K, const BatchArgs* batch, int n, int max_nb, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  const dim3 grid(max_nb, n);
+  switch (K) {
+    case 1: hipLaunchKernelGGL((accumulate_batch_kernel<1, 256>), grid, dim3(256), 0, st, batch); break;
+    case 4: hipLaunchKernelGGL((accumulate_batch_kernel<4, 256>), grid, dim3(256), 0, st, batch); break;
+    case 20: hipLaunchKernelGGL((accumulate_batch_kernel<20, 256>), grid, dim3(256), 0, st, batch); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_lm_step_batch(const BatchArgs* batch, int n, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(lm_step_batch_kernel, dim3(n), dim3(64), 0, st, batch);
+  return hipGetLastError();
+}
+
+hipError_t launch_finalize_batch(const BatchArgs* batch, int n, double* out28, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(finalize_batch_kernel, dim3(n), dim3(64), 0, st, batch, out28);
+  return hipGetLastError();
+}
+
+// chained solve: a.lm = state in, a.lm_step = state out, a.partials_in / a.partials = previous / this
+// evaluation's partials (same grid for every launch of a solve)
+hipError_t launch_accumulate_chain(const AccArgs& a, hipStream_t st) {
+  const int nb = accumulate_blocks(a.n_s * a.K);
+  switch (a.K) {
+    case 1: hipLaunchKernelGGL((accumulate_chain_kernel<1, 256>), dim3(nb), dim3(256), 0, st, a); break;
+    case 4: hipLaunchKernelGGL((accumulate_chain_kernel<4, 256>), dim3(nb), dim3(256), 0, st, a); break;
+    case 20: hipLaunchKernelGGL((accumulate_chain_kernel<20, 256>), dim3(nb), dim3(256), 0, st, a); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

@@ -63,6 +63,8 @@ struct LmState {
   int reuse_diagonal, invalid, iterations, evaluations;
   int phase;   // 0: pose == x (first evaluation), 1: pose is a candidate step
   int status;  // LM_*
+  int pending; // chained device solve: an evaluation at `pose` has been accumulated but not fed yet
+  int pad_;
 };
 
 namespace detail {
@@ -205,6 +207,7 @@ SICP_HD inline void lm_init(LmState& s, const LmOptions& opt, const double* x0) 
   s.reuse_diagonal = 0; s.invalid = 0; s.iterations = 0; s.evaluations = 0;
   s.phase = 0;
   s.status = LM_RUNNING;
+  s.pending = 0; s.pad_ = 0;
 }
 
 // out28 = [H upper 21 | g 6 | cost] evaluated at s.pose

@@ -124,12 +124,25 @@ struct sicp_context {
   // a single launch call per batch instead of 2 x lm_batch trips through the runtime's launch path
   hipGraphExec_t lm_graph = nullptr;
   sicp::AccArgs lm_graph_args;
+  int lm_graph_chain = 0;
   int lm_graph_batch = 0;
   sicp::LmState* h_lm = nullptr;  // pinned mirror of the device-resident LM state
   double* h_out28 = nullptr;      // pinned, 28 doubles
   long long* h_count = nullptr;   // pinned
   DevBuf<float> tmpx, tmpy, tmpz;
   DevBuf<uint32_t> tmpl;
+  // lock-step batch (sicp_align_batch), owned by the batch's first handle: one BatchArgs and one LM
+  // state per pair, pinned mirrors, and the captured [accumulate_batch, lm_step_batch] x lm_batch graph
+  DevBuf<sicp::BatchArgs> d_batch;
+  DevBuf<sicp::LmState> d_bstates;
+  DevBuf<double> d_bout28;
+  sicp::BatchArgs* h_batch = nullptr;
+  sicp::LmState* h_bstates = nullptr;
+  double* h_bout28 = nullptr;
+  int h_batch_cap = 0;
+  hipGraphExec_t b_graph = nullptr;
+  int b_graph_n = 0, b_graph_maxnb = 0, b_graph_K = 0, b_graph_len = 0;
+  const void* b_graph_ptr = nullptr;
   std::string last_error;
   sicp_stats st;
 };
@@ -585,18 +598,24 @@ int run_solve(sicp_context* h, const double* init_qt, double* out_qt, SolveResul
   // device-resident: the trust-region state stays in HBM; every evaluation is an accumulate kernel
   // followed by a one-block kernel that feeds the same LM machine; the host polls the status once
   // per batch.  Launches queued behind a finished solve exit at their first instruction.
+  // lm_on_device: 1 = accumulate kernel + one-wave step kernel; 2 = step fused into the last block
+  // of the accumulate kernel; 3 = chained (every launch finishes the previous evaluation in its
+  // prologue; state and partials double buffered, so a batch has an even number of launches).
+  // 2 and 3 keep the solver state in registers (one wave per SIMD): they are used while one round
+  // of blocks covers the launch, the two-kernel form beyond (the boundary is then noise).
   const int nb = sicp::accumulate_blocks(h->corr_n * h->corr_K);
-  HIPCHECK(h->partials.reserve((size_t)nb * 28));
-  HIPCHECK(h->d_lm.reserve(1));
+  const bool chain = P.lm_on_device >= 3 && nb <= 256;
+  const bool fused = P.lm_on_device == 2 && nb <= 256;
+  int batch = P.lm_batch > 0 ? P.lm_batch : 12;
+  if (chain) batch += batch & 1;
+  HIPCHECK(h->partials.reserve((size_t)nb * 28 * (chain ? 2 : 1)));
+  HIPCHECK(h->d_lm.reserve(chain ? 2 : 1));
   sicp::lm_init(*h->h_lm, lm_options(P), init_qt);
   HIPCHECK(hipMemcpyAsync(h->d_lm.p, h->h_lm, sizeof(sicp::LmState), hipMemcpyHostToDevice, h->stream));
   sicp::AccArgs a;
   std::memset(&a, 0, sizeof a);  // padding bytes take part in the graph-cache comparison
   fill_acc(h, a);
   a.lm = h->d_lm.p;
-  // the fused kernel keeps the solver state in registers (one wave per SIMD): use it while one
-  // round of blocks covers the launch, the two-kernel form beyond (the boundary is then noise)
-  const bool fused = P.lm_on_device >= 2 && nb <= 256;
   if (fused) {
     if (!h->d_ticket.p) {
       HIPCHECK(h->d_ticket.reserve(1));
@@ -605,15 +624,24 @@ int run_solve(sicp_context* h, const double* init_qt, double* out_qt, SolveResul
     a.lm_step = h->d_lm.p;
     a.ticket = h->d_ticket.p;
   }
-  const int batch = P.lm_batch > 0 ? P.lm_batch : 12;
-  if (!h->lm_graph || h->lm_graph_batch != batch || std::memcmp(&h->lm_graph_args, &a, sizeof a) != 0) {
+  if (!h->lm_graph || h->lm_graph_batch != batch || h->lm_graph_chain != (int)chain || std::memcmp(&h->lm_graph_args, &a, sizeof a) != 0) {
     // (re)capture: the arguments only change when a buffer was reallocated or the mode changed
     if (h->lm_graph) { (void)hipGraphExecDestroy(h->lm_graph); h->lm_graph = nullptr; }
     hipGraph_t g = nullptr;
     HIPCHECK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
     hipError_t ce = hipSuccess;
-    for (int b = 0; b < batch && ce == hipSuccess; ++b)
-      ce = fused ? sicp::launch_accumulate_fused(a, h->stream) : sicp::launch_accumulate_lm(a, h->d_lm.p, h->stream);
+    for (int b = 0; b < batch && ce == hipSuccess; ++b) {
+      if (chain) {
+        sicp::AccArgs c = a;
+        c.lm = h->d_lm.p + (b & 1);
+        c.lm_step = h->d_lm.p + ((b + 1) & 1);
+        c.partials_in = h->partials.p + (size_t)(b & 1) * nb * 28;
+        c.partials = h->partials.p + (size_t)((b + 1) & 1) * nb * 28;
+        ce = sicp::launch_accumulate_chain(c, h->stream);
+      } else {
+        ce = fused ? sicp::launch_accumulate_fused(a, h->stream) : sicp::launch_accumulate_lm(a, h->d_lm.p, h->stream);
+      }
+    }
     hipError_t ee = hipStreamEndCapture(h->stream, &g);
     HIPCHECK(ce);
     HIPCHECK(ee);
@@ -622,20 +650,187 @@ int run_solve(sicp_context* h, const double* init_qt, double* out_qt, SolveResul
     HIPCHECK(ie);
     std::memcpy(&h->lm_graph_args, &a, sizeof a);
     h->lm_graph_batch = batch;
+    h->lm_graph_chain = (int)chain;
   }
+  static const bool dbg_timing = std::getenv("SICP_DEBUG_TIMING") != nullptr;  // developer aid
+  double t_launch = 0, t_copy = 0, t_sync = 0; int n_batches = 0;
   for (;;) {
     KernelTimer kt(h, SICP_PROFILE_ACC);
+    const double ta = dbg_timing ? now_ms() : 0;
     HIPCHECK(hipGraphLaunch(h->lm_graph, h->stream));
+    const double tb = dbg_timing ? now_ms() : 0;
     h->st.acc_launches += batch;
     h->st.acc_kernel_ms += kt.stop();
     HIPCHECK(hipMemcpyAsync(h->h_lm, h->d_lm.p, sizeof(sicp::LmState), hipMemcpyDeviceToHost, h->stream));
+    const double tc = dbg_timing ? now_ms() : 0;
     HIPCHECK(hipStreamSynchronize(h->stream));
+    if (dbg_timing) { const double td = now_ms(); t_launch += tb - ta; t_copy += tc - tb; t_sync += td - tc; ++n_batches; }
     if (h->h_lm->status != sicp::LM_RUNNING) break;
   }
+  if (dbg_timing)
+    std::fprintf(stderr, "[sicp solve] batches %d: graph launch %.1f us, copy enqueue %.1f us, sync wait %.1f us (per batch)\n", n_batches,
+                 1e3 * t_launch / n_batches, 1e3 * t_copy / n_batches, 1e3 * t_sync / n_batches);
   const sicp::LmState& s = *h->h_lm;
   std::memcpy(out_qt, s.x, sizeof s.x);
   res->status = s.status; res->iterations = s.iterations; res->evaluations = s.evaluations; res->cost = s.cost;
   h->st.total_evals += s.evaluations;
+  return SICP_OK;
+}
+
+// ---- pieces of align() shared by the single-pair and the lock-step batch drivers ---------------
+struct OuterState {
+  double cur[7], est[7];
+  int outer = 0, count = 0;
+  bool converged = false;
+};
+
+// per-align preamble: counters, cloud layout, covariances / histograms (asynchronous)
+int align_begin(sicp_context* h, bool want_stats) {
+  const sicp_params& P = h->params;
+  const bool em = P.mode == SICP_MODE_EM, sem = P.mode == SICP_MODE_SEMANTIC;
+  std::memset(&h->st, 0, sizeof h->st);
+  Cloud &S = h->cloud[0], &T = h->cloud[1];
+  HIPCHECK(h->d_count.reserve(1));
+  if (want_stats) HIPCHECK(hipMemsetAsync(h->d_count.p, 0, sizeof(long long), h->stream));
+  SICPCHECK(prepare_cloud(h, S));
+  SICPCHECK(prepare_cloud(h, T));
+  // em_icp.hpp:28-29 / gicp.hpp:33-34 recompute the covariances on every align(); for
+  // SemanticICP they belong to cloud construction (semantic_point_cloud.hpp:25-84)
+  const double t0 = now_ms();
+  // the two clouds' feature kernels are independent and latency bound: run them side by side
+  // (not with brute force, which shares one scratch buffer, nor while those kernels are timed)
+  const bool side_by_side = P.nn_method >= 1 && !(P.profile & SICP_PROFILE_COV);
+  if (!sem || !features_current(h, S, false)) SICPCHECK(compute_features(h, S, em));
+  if (!sem || !features_current(h, T, false)) {
+    SICPCHECK(compute_features(h, T, em, side_by_side ? h->stream2 : h->stream));
+    if (side_by_side) {
+      HIPCHECK(hipEventRecord(h->ev_join, h->stream2));
+      HIPCHECK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
+    }
+  }
+  if (P.profile) HIPCHECK(hipStreamSynchronize(h->stream));
+  h->st.t_cov_ms = now_ms() - t0;
+  return SICP_OK;
+}
+
+// outer convergence test: em_icp.hpp:179-187 / gicp.hpp:153-161 / semantic_icp.hpp:151-158
+void outer_finish(const sicp_params& P, OuterState& o) {
+  double inv[7], rel[7], lg[6];
+  sicp::se3::inverse(o.cur, inv);
+  sicp::se3::mul(inv, o.est, rel);
+  sicp::se3::log(rel, lg);
+  double mse = 0;
+  for (int i = 0; i < 6; ++i) mse += lg[i] * lg[i];
+  if (P.mode == SICP_MODE_SEMANTIC) {
+    if (mse < P.outer_tol || o.count > P.max_outer) o.converged = true;
+    std::memcpy(o.cur, o.est, sizeof o.cur);
+  } else {
+    if (mse < P.outer_tol || o.outer > P.max_outer) o.converged = true;
+    std::memcpy(o.cur, o.est, sizeof o.cur);
+    o.outer++;
+  }
+}
+
+int align_end(sicp_context* h, const OuterState& o, double t_begin, int32_t* outer_iters, sicp_stats* stats) {
+  if (stats) {
+    HIPCHECK(hipMemcpyAsync(h->h_count, h->d_count.p, sizeof(long long), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    h->st.total_active = *h->h_count;
+  }
+  h->st.outer_iters = h->params.mode == SICP_MODE_SEMANTIC ? o.count : o.outer;
+  h->st.t_total_ms = now_ms() - t_begin;
+  if (outer_iters) *outer_iters = h->st.outer_iters;
+  if (stats) *stats = h->st;
+  return SICP_OK;
+}
+
+// ---- lock-step batch -----------------------------------------------------------------------------
+bool same_solver(const sicp_params& a, const sicp_params& b) {
+  return a.mode == b.mode && a.knn == b.knn && a.lm_batch == b.lm_batch && a.use_sqloss == b.use_sqloss;
+}
+
+int batch_reserve(sicp_context* h, int n) {
+  HIPCHECK(h->d_batch.reserve(n));
+  HIPCHECK(h->d_bstates.reserve(n));
+  HIPCHECK(h->d_bout28.reserve((size_t)28 * n));
+  if (h->h_batch_cap < n) {
+    if (h->h_batch) (void)hipHostFree(h->h_batch);
+    if (h->h_bstates) (void)hipHostFree(h->h_bstates);
+    if (h->h_bout28) (void)hipHostFree(h->h_bout28);
+    h->h_batch = nullptr; h->h_bstates = nullptr; h->h_bout28 = nullptr; h->h_batch_cap = 0;
+    HIPCHECK(hipHostMalloc((void**)&h->h_batch, sizeof(sicp::BatchArgs) * n, hipHostMallocDefault));
+    HIPCHECK(hipHostMalloc((void**)&h->h_bstates, sizeof(sicp::LmState) * n, hipHostMallocDefault));
+    HIPCHECK(hipHostMalloc((void**)&h->h_bout28, sizeof(double) * 28 * n, hipHostMallocDefault));
+    h->h_batch_cap = n;
+  }
+  return SICP_OK;
+}
+
+// The inner solves of all active pairs, in lock step: one accumulate launch evaluates every pair's
+// current LM pose, one step launch advances every pair's trust-region machine (csrc/lm.hpp, the
+// same code and the same bits as the single-pair solve).  A pair that has finished idles (its
+// blocks exit on the first instruction) until the slowest pair is done.
+int run_solve_batch(sicp_context* h, sicp_handle* hs, int n, const char* active, OuterState* o, SolveResult* res) {
+  const sicp_params& P = h->params;
+  SICPCHECK(batch_reserve(h, n));
+  int max_nb = 0;
+  for (int p = 0; p < n; ++p) {
+    sicp_context* g = hs[p];
+    sicp::BatchArgs& B = h->h_batch[p];
+    std::memset(&B, 0, sizeof B);
+    sicp::lm_init(h->h_bstates[p], lm_options(g->params), o[p].est);
+    if (!active[p]) { h->h_bstates[p].status = sicp::LM_CONVERGED; B.nb = 0; B.a.lm = B.a.lm_step = h->d_bstates.p + p; continue; }
+    const int nb = sicp::accumulate_blocks(g->corr_n * g->corr_K);
+    if (g->partials.reserve((size_t)nb * 28) != hipSuccess) return SICP_ERR_OUT_OF_MEMORY;
+    fill_acc(g, B.a);
+    B.a.lm = B.a.lm_step = h->d_bstates.p + p;
+    B.nb = nb;
+    max_nb = std::max(max_nb, nb);
+    // the batched kernels (leader stream) read what the pair's stream is still producing
+    if (g != h) {
+      HIPCHECK(hipEventRecord(g->ev_join, g->stream));
+      HIPCHECK(hipStreamWaitEvent(h->stream, g->ev_join, 0));
+    }
+  }
+  HIPCHECK(hipMemcpyAsync(h->d_batch.p, h->h_batch, sizeof(sicp::BatchArgs) * n, hipMemcpyHostToDevice, h->stream));
+  HIPCHECK(hipMemcpyAsync(h->d_bstates.p, h->h_bstates, sizeof(sicp::LmState) * n, hipMemcpyHostToDevice, h->stream));
+  const int len = P.lm_batch > 0 ? P.lm_batch : 12;
+  const int K = hs[0]->corr_K;
+  // the graph only depends on the grid and on the address of the argument array
+  if (!h->b_graph || h->b_graph_n != n || h->b_graph_maxnb != max_nb || h->b_graph_K != K || h->b_graph_len != len ||
+      h->b_graph_ptr != (const void*)h->d_batch.p) {
+    if (h->b_graph) { (void)hipGraphExecDestroy(h->b_graph); h->b_graph = nullptr; }
+    hipGraph_t g = nullptr;
+    HIPCHECK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    hipError_t ce = hipSuccess;
+    for (int b = 0; b < len && ce == hipSuccess; ++b) {
+      ce = sicp::launch_accumulate_batch(K, h->d_batch.p, n, max_nb, h->stream);
+      if (ce == hipSuccess) ce = sicp::launch_lm_step_batch(h->d_batch.p, n, h->stream);
+    }
+    hipError_t ee = hipStreamEndCapture(h->stream, &g);
+    HIPCHECK(ce);
+    HIPCHECK(ee);
+    hipError_t ie = hipGraphInstantiate(&h->b_graph, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    HIPCHECK(ie);
+    h->b_graph_n = n; h->b_graph_maxnb = max_nb; h->b_graph_K = K; h->b_graph_len = len; h->b_graph_ptr = h->d_batch.p;
+  }
+  for (;;) {
+    HIPCHECK(hipGraphLaunch(h->b_graph, h->stream));
+    for (int p = 0; p < n; ++p)
+      if (active[p]) hs[p]->st.acc_launches += len;
+    HIPCHECK(hipMemcpyAsync(h->h_bstates, h->d_bstates.p, sizeof(sicp::LmState) * n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    bool running = false;
+    for (int p = 0; p < n; ++p) running = running || h->h_bstates[p].status == sicp::LM_RUNNING;
+    if (!running) break;
+  }
+  for (int p = 0; p < n; ++p) {
+    if (!active[p]) continue;
+    const sicp::LmState& s = h->h_bstates[p];
+    std::memcpy(o[p].est, s.x, sizeof s.x);
+    res[p].status = s.status; res[p].iterations = s.iterations; res[p].evaluations = s.evaluations; res[p].cost = s.cost;
+  }
   return SICP_OK;
 }
 
@@ -701,7 +896,7 @@ int sicp_default_params(int mode, sicp_params* p) {
   p->quirk_bool_probability = 1;
   p->quirk_float_products = 1;
   p->nn_method = 1;  // exact box-tree search, packet walk; 2 = per-query walk; 0 = LDS-tiled brute force (same results)
-  p->lm_on_device = 2;
+  p->lm_on_device = 1;
   p->lm_batch = 8;   // 16 kernel nodes per graph: longer graphs replay with a ~50 us bubble every 16 nodes
   if (mode == SICP_MODE_EM) {
     p->knn = 4; p->cauchy_a = 3.0; p->use_sqloss = 1;  // em_icp.hpp:60,111,115
@@ -750,6 +945,10 @@ int sicp_destroy(sicp_handle h) {
   if (h->h_out28) (void)hipHostFree(h->h_out28);
   if (h->h_count) (void)hipHostFree(h->h_count);
   if (h->h_lm) (void)hipHostFree(h->h_lm);
+  if (h->h_batch) (void)hipHostFree(h->h_batch);
+  if (h->h_bstates) (void)hipHostFree(h->h_bstates);
+  if (h->h_bout28) (void)hipHostFree(h->h_bout28);
+  if (h->b_graph) (void)hipGraphExecDestroy(h->b_graph);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->lm_graph) (void)hipGraphExecDestroy(h->lm_graph);
@@ -833,75 +1032,124 @@ int sicp_align(sicp_handle h, const double init_qt[7], double out_qt[7], int32_t
   SICPCHECK(set_device(h));
   SICPCHECK(check_ready(h, false));
   const sicp_params& P = h->params;
-  const bool em = P.mode == SICP_MODE_EM, sem = P.mode == SICP_MODE_SEMANTIC;
-  std::memset(&h->st, 0, sizeof h->st);
   const double t_begin = now_ms();
-  Cloud &S = h->cloud[0], &T = h->cloud[1];
-  HIPCHECK(h->d_count.reserve(1));
-  if (stats) HIPCHECK(hipMemsetAsync(h->d_count.p, 0, sizeof(long long), h->stream));
-  SICPCHECK(prepare_cloud(h, S));
-  SICPCHECK(prepare_cloud(h, T));
-  {
-    // em_icp.hpp:28-29 / gicp.hpp:33-34 recompute the covariances on every align(); for
-    // SemanticICP they belong to cloud construction (semantic_point_cloud.hpp:25-84)
-    const double t0 = now_ms();
-    // the two clouds' feature kernels are independent and latency bound: run them side by side
-    // (not with brute force, which shares one scratch buffer, nor while those kernels are timed)
-    const bool side_by_side = P.nn_method >= 1 && !(P.profile & SICP_PROFILE_COV);
-    if (!sem || !features_current(h, S, false)) SICPCHECK(compute_features(h, S, em));
-    if (!sem || !features_current(h, T, false)) {
-      SICPCHECK(compute_features(h, T, em, side_by_side ? h->stream2 : h->stream));
-      if (side_by_side) {
-        HIPCHECK(hipEventRecord(h->ev_join, h->stream2));
-        HIPCHECK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
-      }
-    }
-    if (P.profile) HIPCHECK(hipStreamSynchronize(h->stream));
-    h->st.t_cov_ms = now_ms() - t0;
-  }
-  double cur[7], est[7];
-  std::memcpy(cur, init_qt, sizeof cur);
-  bool converged = false;
-  int outer = 0, count = 0;
-  while (!converged) {
-    std::memcpy(est, cur, sizeof est);
-    if (sem) count++;  // semantic_icp.hpp:47
-    SICPCHECK(run_correspondences(h, cur, P.knn, true));
+  SICPCHECK(align_begin(h, stats != nullptr));
+  OuterState o;
+  std::memcpy(o.cur, init_qt, sizeof o.cur);
+  while (!o.converged) {
+    std::memcpy(o.est, o.cur, sizeof o.est);
+    if (P.mode == SICP_MODE_SEMANTIC) o.count++;  // semantic_icp.hpp:47
+    SICPCHECK(run_correspondences(h, o.cur, P.knn, true));
     {
       const double t0 = now_ms();
       SolveResult r;
-      SICPCHECK(run_solve(h, est, est, &r));
+      SICPCHECK(run_solve(h, o.est, o.est, &r));
       h->st.total_lm_iters += r.iterations;
       h->st.final_cost = r.cost;
       h->st.t_solve_ms += now_ms() - t0;
     }
     if (stats) SICPCHECK(count_active(h));
-    // em_icp.hpp:179-187 / gicp.hpp:153-161 / semantic_icp.hpp:151-158
-    double inv[7], rel[7], lg[6];
-    sicp::se3::inverse(cur, inv);
-    sicp::se3::mul(inv, est, rel);
-    sicp::se3::log(rel, lg);
-    double mse = 0;
-    for (int i = 0; i < 6; ++i) mse += lg[i] * lg[i];
-    if (sem) {
-      if (mse < P.outer_tol || count > P.max_outer) converged = true;
-      std::memcpy(cur, est, sizeof cur);
-    } else {
-      if (mse < P.outer_tol || outer > P.max_outer) converged = true;
-      std::memcpy(cur, est, sizeof cur);
-      outer++;
+    outer_finish(P, o);
+  }
+  std::memcpy(out_qt, o.cur, sizeof o.cur);
+  SICPCHECK(align_end(h, o, t_begin, outer_iters, stats));
+  return SICP_OK;
+}
+
+int sicp_align_batch(sicp_handle* hs, int32_t n, const double* init_qt, double* out_qt, int32_t* outer_iters, sicp_stats* stats) {
+  if (!hs || n < 1 || !init_qt || !out_qt) return SICP_ERR_INVALID_ARGUMENT;
+  for (int p = 0; p < n; ++p)
+    if (!hs[p]) return SICP_ERR_INVALID_ARGUMENT;
+  sicp_context* L = hs[0];  // the leader owns the batch buffers and runs the batched kernels on its stream
+  {
+    sicp_context* h = L;
+    SICPCHECK(set_device(h));
+  }
+  for (int p = 0; p < n; ++p) {
+    sicp_context* h = hs[p];
+    for (int q = 0; q < p; ++q)
+      if (hs[q] == h) return SICP_ERR_INVALID_ARGUMENT;  // every pair needs its own handle
+    // one launch evaluates every pair: they must agree on what a launch does
+    if (h->device != L->device || !same_solver(h->params, L->params)) {
+      h->last_error = "sicp_align_batch: handles differ in device, mode, knn or solver parameters";
+      return SICP_ERR_INVALID_ARGUMENT;
+    }
+    SICPCHECK(check_ready(h, false));
+  }
+  const sicp_params& P = L->params;
+  const double t_begin = now_ms();
+  for (int p = 0; p < n; ++p) SICPCHECK(align_begin(hs[p], stats != nullptr));  // asynchronous: the pairs' feature kernels overlap
+  std::vector<OuterState> o(n);
+  for (int p = 0; p < n; ++p) std::memcpy(o[p].cur, init_qt + 7 * p, sizeof o[p].cur);
+  std::vector<SolveResult> res(n);
+  std::vector<char> active(n, 1);
+  for (;;) {
+    int n_active = 0;
+    for (int p = 0; p < n; ++p) {
+      active[p] = !o[p].converged;
+      if (!active[p]) continue;
+      ++n_active;
+      std::memcpy(o[p].est, o[p].cur, sizeof o[p].est);
+      if (P.mode == SICP_MODE_SEMANTIC) o[p].count++;
+      SICPCHECK(run_correspondences(hs[p], o[p].cur, P.knn, true));  // on the pair's own stream: the searches overlap
+    }
+    if (n_active == 0) break;
+    const double t0 = now_ms();
+    {
+      int rc = run_solve_batch(L, hs, n, active.data(), o.data(), res.data());
+      if (rc != SICP_OK) return rc;
+    }
+    const double dt = now_ms() - t0;
+    for (int p = 0; p < n; ++p) {
+      if (!active[p]) continue;
+      sicp_context* h = hs[p];
+      h->st.total_lm_iters += res[p].iterations;
+      h->st.final_cost = res[p].cost;
+      h->st.t_solve_ms += dt;
+      h->st.total_evals += res[p].evaluations;
+      if (stats) SICPCHECK(count_active(h));
+      outer_finish(P, o[p]);
     }
   }
-  std::memcpy(out_qt, cur, sizeof cur);
-  if (stats) {
-    HIPCHECK(hipMemcpyAsync(h->h_count, h->d_count.p, sizeof(long long), hipMemcpyDeviceToHost, h->stream));
-    HIPCHECK(hipStreamSynchronize(h->stream));
-    h->st.total_active = *h->h_count;
+  for (int p = 0; p < n; ++p) {
+    std::memcpy(out_qt + 7 * p, o[p].cur, sizeof o[p].cur);
+    SICPCHECK(align_end(hs[p], o[p], t_begin, outer_iters ? outer_iters + p : nullptr, stats ? stats + p : nullptr));
   }
-  h->st.outer_iters = sem ? count : outer;
-  h->st.t_total_ms = now_ms() - t_begin;
-  if (outer_iters) *outer_iters = h->st.outer_iters;
-  if (stats) *stats = h->st;
+  return SICP_OK;
+}
+
+int sicp_accumulate_batch(sicp_handle* hs, int32_t n, const double* qt, double* out28, double* kernel_ms) {
+  if (!hs || n < 1 || !qt || !out28) return SICP_ERR_INVALID_ARGUMENT;
+  for (int p = 0; p < n; ++p)
+    if (!hs[p] || !hs[p]->corr_valid || hs[p]->device != hs[0]->device || hs[p]->corr_K != hs[0]->corr_K) return SICP_ERR_NOT_READY;
+  sicp_context* h = hs[0];
+  SICPCHECK(set_device(h));
+  SICPCHECK(batch_reserve(h, n));
+  int max_nb = 0;
+  for (int p = 0; p < n; ++p) {
+    sicp_context* g = hs[p];
+    const int nb = sicp::accumulate_blocks(g->corr_n * g->corr_K);
+    if (g->partials.reserve((size_t)nb * 28) != hipSuccess) return SICP_ERR_OUT_OF_MEMORY;
+    std::memset(&h->h_batch[p], 0, sizeof(sicp::BatchArgs));
+    fill_acc(g, h->h_batch[p].a);
+    fill_pose(qt + 7 * p, h->h_batch[p].a.pose);
+    h->h_batch[p].nb = nb;
+    max_nb = std::max(max_nb, nb);
+    HIPCHECK(hipStreamSynchronize(g->stream));  // the pair's correspondences are complete
+  }
+  HIPCHECK(hipMemcpyAsync(h->d_batch.p, h->h_batch, sizeof(sicp::BatchArgs) * n, hipMemcpyHostToDevice, h->stream));
+  HIPCHECK(hipEventRecord(h->ev0, h->stream));
+  HIPCHECK(sicp::launch_accumulate_batch(h->corr_K, h->d_batch.p, n, max_nb, h->stream));
+  HIPCHECK(hipEventRecord(h->ev1, h->stream));
+  HIPCHECK(sicp::launch_finalize_batch(h->d_batch.p, n, h->d_bout28.p, h->stream));
+  HIPCHECK(hipMemcpyAsync(h->h_bout28, h->d_bout28.p, sizeof(double) * 28 * n, hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  std::memcpy(out28, h->h_bout28, sizeof(double) * 28 * n);
+  if (kernel_ms) {
+    float ms = 0.f;
+    HIPCHECK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    *kernel_ms = ms;
+  }
   return SICP_OK;
 }
 

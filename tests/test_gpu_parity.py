@@ -63,7 +63,7 @@ def nn(request):
     return request.param
 
 
-@pytest.fixture(params=[0, 1, 2], ids=["hostlm", "devicelm", "fusedlm"])
+@pytest.fixture(params=[0, 1, 2, 3], ids=["hostlm", "devicelm", "fusedlm", "chainlm"])
 def lm(request):
     """Host-loop and device-resident inner solve run the same LM machine (csrc/lm.hpp)."""
     return request.param
@@ -413,3 +413,77 @@ def test_metric_size_properties(lidar100k, nn, lm):
     qt2, st2 = e.align(qt)
     rot, tr = pose_delta(qt, qt2)
     assert st2["outer_iters"] == 1 and rot < 3.2e-3 and tr < 3.2e-3  # inside the outer stop radius sqrt(1e-5)
+
+
+# ------------------------------------------------------------------------------------------------
+# lock-step batch (sicp_align_batch): per pair bit-identical to sicp_align, and equal to the oracle
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["em", "gicp", "semantic"])
+def test_align_batch_equals_single_align(mode):
+    m = {"em": sicp.MODE_EM, "gicp": sicp.MODE_GICP, "semantic": sicp.MODE_SEMANTIC}[mode]
+    pairs = []
+    # pairs of different size and difficulty: they converge after different numbers of outer iterations
+    for seed, n in ((2, 6000), (3, 2500), (5, 9000)):
+        ps, ls, pt, lt, T, cm = synth.lidar_pair(seed=seed, n_points=n)
+        pairs.append((ps, ls, pt, lt, cm))
+    ident = np.array([0, 0, 0, 1, 0, 0, 0.0])
+    engines, singles = [], []
+    try:
+        for ps, ls, pt, lt, cm in pairs:
+            e, p = make_engine(m, 11 if mode == "em" else 0, cm if mode == "em" else None)
+            e.set_source(ps, ls if mode != "gicp" else None)
+            e.set_target(pt, lt if mode != "gicp" else None)
+            engines.append(e)
+            singles.append(e.align(ident))
+        res = sicp.align_batch(engines, np.tile(ident, (len(engines), 1)))
+        for (qb, sb), (q1, s1) in zip(res, singles):
+            assert np.array_equal(qb, q1)  # same kernels' arithmetic, same block decomposition: same bits
+            for key in ("outer_iters", "total_lm_iters", "total_evals", "total_corr", "total_active"):
+                assert sb[key] == s1[key], key
+        # and a second call on the same handles (graph and buffers reused) gives the same again
+        res2 = sicp.align_batch(engines, np.tile(ident, (len(engines), 1)))
+        for (qb, _), (q1, _) in zip(res2, singles):
+            assert np.array_equal(qb, q1)
+        # batch of one, and a sub-batch with another leader
+        (q0, _), = sicp.align_batch(engines[1:2])
+        assert np.array_equal(q0, singles[1][0])
+        r3 = sicp.align_batch(engines[1:])
+        assert np.array_equal(r3[0][0], singles[1][0]) and np.array_equal(r3[1][0], singles[2][0])
+    finally:
+        for e in engines:
+            e.close()
+
+
+def test_accumulate_batch_equals_accumulate():
+    ident = np.array([0, 0, 0, 1, 0, 0, 0.0])
+    engines, ref, qts = [], [], []
+    try:
+        for seed, n in ((2, 5000), (4, 12000)):
+            ps, ls, pt, lt, T, cm = synth.lidar_pair(seed=seed, n_points=n)
+            e, p = make_engine(sicp.MODE_EM, 11, cm)
+            e.set_source(ps, ls); e.set_target(pt, lt)
+            qt = mat_to_qt(T)
+            e.correspondences(ident)
+            engines.append(e); qts.append(qt); ref.append(e.accumulate(qt))
+        out, ms = sicp.accumulate_batch(engines, np.array(qts))
+        assert ms > 0
+        for p in range(len(engines)):
+            assert np.array_equal(out[p], ref[p])
+    finally:
+        for e in engines:
+            e.close()
+
+
+def test_align_batch_rejects_mismatched_handles():
+    ps, ls, pt, lt, T, cm = synth.lidar_pair(seed=2, n_points=2000)
+    e1, _ = make_engine(sicp.MODE_EM, 11, cm)
+    e2, _ = make_engine(sicp.MODE_GICP)
+    try:
+        for e in (e1, e2):
+            e.set_source(ps, ls); e.set_target(pt, lt)
+        with pytest.raises(RuntimeError):
+            sicp.align_batch([e1, e2])
+        with pytest.raises(RuntimeError):
+            sicp.align_batch([e1, e1])
+    finally:
+        e1.close(); e2.close()
