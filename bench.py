@@ -6,11 +6,13 @@ Metric (BASELINE.json): correspondences/sec (+ ms per outer ICP iteration) for E
 subsampled to exactly 100 000 x 100 000 points -- the metric point of configs[1].
 
 A "step" registers one batch of independent scan pairs on each GPU: `--pairs-in-flight` S pairs
-(default 4), each a complete align() (covariances of both clouds + every outer ICP iteration:
-transform -> kNN -> EM weights -> inner LM solve) on its own handle / stream / host thread, with
-all clouds already resident in HBM when the timed region starts.  Independent pairs are the
-reference's unit of work (exec/kitti_eval.cc loops over them) and the north star shards them
-across GPUs; several in flight per GPU keep the chip busy during each pair's serial LM chain.
+(default 16), each a complete align() (covariances of both clouds + every outer ICP iteration:
+transform -> kNN -> EM weights -> inner LM solve) on its own handle, with all clouds already
+resident in HBM when the timed region starts.  Independent pairs are the reference's unit of work
+(exec/kitti_eval.cc loops over them) and the north star shards them across GPUs.  By default the S
+pairs of a GPU advance in lock step through one sicp_align_batch call: every kernel launch of the
+path (searches, weights, LM evaluations, LM steps) covers all S pairs, per pair bit-identical to a
+lone align().  `--concurrency threads` runs them as S host threads + streams instead.
 Single-pair latency (S = 1) is measured after the timed region and reported in "single_pair".
 One correspondence = one (source, target) slot that went through kNN + weighting + accumulation
 in one outer iteration.
@@ -34,6 +36,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+PMC_TRAFFIC_BYTES = {}  # (points, pairs per launch) -> FETCH_SIZE + WRITE_SIZE bytes per launch, from profiles/
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 VALU_PAIR_PEAK = 9.8e12        # 78.6e12 FP32 lane-ops/s / 8 lane-ops per pair
 N_POINTS = 100_000
@@ -51,7 +54,7 @@ def parse_args():
     ap.add_argument("--nn-method", type=int, default=None, help="0 brute force, 1 box tree (default: library default)")
     ap.add_argument("--lm-on-device", type=int, default=None, help="0 host LM loop, 1 device-resident (default: library default)")
     ap.add_argument("--lm-batch", type=int, default=None)
-    ap.add_argument("--pairs-in-flight", type=int, default=4,
+    ap.add_argument("--pairs-in-flight", type=int, default=16,
                     help="independent scan pairs registered concurrently on each GPU (one handle + host thread each)")
     ap.add_argument("--profile", type=int, default=0,
                     help="SICP_PROFILE_* mask applied inside the timed region (default 0: the roofline kernels are timed with "
@@ -251,7 +254,9 @@ def main():
                             "(metric point of BASELINE configs[1]); one independent pair per GPU",
                 "points": n, "K": K_CORR, "classes": N_CLASSES, "parallelism": f"pairs-sharded x{dist.world}",
                 "pairs_in_flight_per_gpu": max(1, args.pairs_in_flight),
-                "step": f"{max(1, args.pairs_in_flight)} concurrent full align() calls per GPU (covariances of both clouds + all outer ICP iterations each)",
+                "concurrency": args.concurrency,
+                "step": f"{max(1, args.pairs_in_flight)} full align() calls per GPU (covariances of both clouds + all outer ICP iterations each), "
+                        + ("advanced in lock step by one sicp_align_batch call" if args.concurrency == "lockstep" else "one host thread + stream each"),
             },
             "ms_per_icp_iter": 1e3 * (elapsed * max(1, args.pairs_in_flight) - 1e-3 * cov_ms) / max(1, outer),
             "cov_ms_per_align": cov_ms / (steps * max(1, args.pairs_in_flight)),
@@ -277,36 +282,46 @@ def main():
             b1 = engine.stats()
             nn_ms = b1["nn_kernel_ms"] - b0["nn_kernel_ms"]
             nn_launches = b1["nn_launches"] - b0["nn_launches"]
-            pp.profile = 8  # SICP_PROFILE_ACC
+            pp.profile = 0
             engine.set_params(pp)
-            before = engine.stats()
-            n_acc = 200
-            for _ in range(n_acc):
-                engine.accumulate(qt)
-            after = engine.stats()
-            acc_us = 1e3 * (after["acc_kernel_ms"] - before["acc_kernel_ms"]) / max(1, after["acc_launches"] - before["acc_launches"])
-            acc_bytes = 24 * n + 32 * K_CORR * n            # 24*N_s + 32*K*N_s
+            # accumulate: the path's HBM-model kernel (38 B per correspondence per pass).  The timed
+            # region runs it as accumulate_batch_kernel, one launch per LM evaluation for all S pairs of
+            # the lock-step batch; here the same launch is timed alone with HIP events on its stream
+            # (sicp_accumulate_batch: 50 launches back to back between two events, 6 rounds)
+            for e in engines:
+                e.correspondences(qt)
+            qts = np.tile(qt, (S, 1))
+            acc_ms_l = []
+            for _ in range(8):
+                _, ms = sicp.accumulate_batch(engines, qts, repeat=50)
+                acc_ms_l.append(ms)
+            acc_us = 1e3 * float(np.mean(acc_ms_l[2:]))
+            n_acc = 50 * len(acc_ms_l[2:])
+            acc_bytes = S * (24 * n + 32 * K_CORR * n)      # pairs x (24*N_s + 32*K*N_s)
             acc_gbs = acc_bytes / (acc_us * 1e-6) / 1e9
             out["roofline"] = {
-                "kernel": "accumulate_kernel<K=4> (Mahalanobis residual + 6-DoF Jacobian -> 28 doubles; one launch per LM evaluation, "
-                          f"{evals / max(1, outer):.1f} per outer iteration)",
+                "kernel": f"accumulate_batch_kernel<K=4> (Mahalanobis residual + 6-DoF Jacobian -> 28 doubles per pair; one launch per LM "
+                          f"evaluation covers the {S} pairs of the batch, {evals / max(1, outer):.1f} launches per outer iteration)",
                 "bound": "hbm", "achieved": acc_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": acc_gbs / HBM_PEAK_GBS,
-                # PMC passes (profiles/r01_final_pmc_hbm_traffic.csv): FETCH_SIZE 6050 KB + WRITE_SIZE 272 KB per
-                # launch at 100Kx100K, raw (the guide's x2 FETCH correction is calibrated for 16-B streams only)
-                "traffic": (6050.0 + 272.0) * 1024 if (n == N_POINTS) else None,
+                # PMC passes (profiles/): FETCH_SIZE + WRITE_SIZE per launch, raw (the guide's x2 FETCH correction is
+                # calibrated for 16-B streams only); filled from the committed profile for the default configuration
+                "traffic": PMC_TRAFFIC_BYTES.get((n, S)),
                 "avg_launch_us": acc_us, "launches_timed": n_acc, "algorithmic_bytes_per_launch": acc_bytes,
-                "note": "100Kx100K working set (~15 MB) is L2/Infinity-Cache resident; the kernel is FP64-issue bound "
-                        "(~300 FP64 ops per correspondence), see DESIGN.md section 3",
+                "pairs_per_launch": S,
+                "note": "FP64-issue bound (~300 FP64 instructions per correspondence incl. log, sqrt, 3 divisions): "
+                        f"{S} pairs x 400K correspondences x 300 / (1024 SIMDs x 16 lanes x 2.4 GHz) = "
+                        f"{S * 4e5 * 300 / (1024 * 16 * 2.4e9) * 1e6:.0f} us of pure issue; see DESIGN.md section 3",
             }
             avg_ms = nn_ms / nn_launches
             alg_bytes = 12 * n + 12 * n + 8 * K_CORR * n     # src+tgt xyz once, idx+dist^2 out
             achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-            kname = {0: "nn_partial_kernel<K=4,Q=2> (LDS-tiled brute force)", 1: "bvh_knn_quad_kernel<K=4> (exact box-tree search, 4 lanes per query)"}[nn_method]
+            kname = {0: "nn_partial_kernel<K=4,Q=2> (LDS-tiled brute force)", 1: "bvh_knn_packet_kernel<K=4> (exact box-tree search, 16 queries per wave share one walk)",
+                     2: "bvh_knn_quad_kernel<K=4> (exact box-tree search, 4 lanes per query)"}[nn_method]
             out["other_kernels"] = [{
                 "kernel": kname + ", one launch per outer iteration; timed with HIP events right after the timed region",
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None, "avg_launch_ms": avg_ms, "launches": nn_launches, "algorithmic_bytes_per_launch": alg_bytes,
-                "note": "latency bound tree walk over an L2-resident cloud" if nn_method == 1 else
+                "note": "latency bound tree walk over an L2-resident cloud (one pair alone; the batch runs all pairs' searches in one launch)" if nn_method >= 1 else
                         "FP32-VALU bound: 1e10 pair evaluations per launch",
                 "pair_evals_per_s_if_brute_force": float(n) * n / (avg_ms * 1e-3),
             }]

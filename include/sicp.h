@@ -205,9 +205,10 @@ int sicp_correspondences(sicp_handle h, const double qt[7], int32_t* idx, float*
  * GICPCostFunction::Evaluate gicp_cost_function.h:27-73 through the losses). */
 int sicp_accumulate(sicp_handle h, const double qt[7], double out28[28]);
 /* the same sweep for n handles in ONE launch (the kernel sicp_align_batch runs): qt n*7,
- * out28 n*28; kernel_ms (nullable) = HIP-event time of that launch on handles[0]'s stream */
+ * out28 n*28.  The launch is issued `repeat` (>= 1) times back to back between two HIP
+ * events on handles[0]'s stream; kernel_ms (nullable) = event time / repeat. */
 int sicp_accumulate_batch(sicp_handle* handles, int32_t n, const double* qt, double* out28,
-                          double* kernel_ms);
+                          int32_t repeat, double* kernel_ms);
 /* the inner ceres::Solve (em_icp.hpp:162-177) on the current correspondences */
 int sicp_solve(sicp_handle h, const double init_qt[7], double out_qt[7], int32_t* lm_iters,
                int32_t* evals, double* final_cost);

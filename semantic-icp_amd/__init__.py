@@ -147,7 +147,7 @@ def lib():
             "sicp_set_confusion": [C.c_void_p, C.c_int32, _dp],
             "sicp_align": [C.c_void_p, _dp, _dp, _ip, C.POINTER(SicpStats)],
             "sicp_align_batch": [C.POINTER(C.c_void_p), C.c_int32, _dp, _dp, _ip, C.POINTER(SicpStats)],
-            "sicp_accumulate_batch": [C.POINTER(C.c_void_p), C.c_int32, _dp, _dp, _dp],
+            "sicp_accumulate_batch": [C.POINTER(C.c_void_p), C.c_int32, _dp, _dp, C.c_int32, _dp],
             "sicp_transform_source": [C.c_void_p, _dp, _fp, _fp, _fp],
             "sicp_fused_labels": [C.c_void_p, _dp, _up],
             "sicp_covariances": [C.c_void_p, C.c_int, _dp, _dp, _bp, _ip],
@@ -343,14 +343,14 @@ def align_batch(engines, init_qts=None, want_stats: bool = True):
     return [(out[p].copy(), (sts[p].as_dict() if want_stats else {"outer_iters": int(its[p])})) for p in range(n)]
 
 
-def accumulate_batch(engines, qts):
-    """sicp_accumulate_batch: the 28 sums of every engine's current correspondences from one launch.
-    Returns (out28 [n, 28], kernel_ms)."""
+def accumulate_batch(engines, qts, repeat: int = 1):
+    """sicp_accumulate_batch: the 28 sums of every engine's current correspondences from one launch
+    (issued `repeat` times back to back for timing).  Returns (out28 [n, 28], kernel_ms per launch)."""
     n = len(engines)
     qts = np.ascontiguousarray(qts, dtype=np.float64).reshape(n, 7)
     out = np.empty((n, 28))
     ms = C.c_double(0.0)
-    rc = lib().sicp_accumulate_batch(_handles(engines), n, _ptr(qts, _dp), _ptr(out, _dp), C.byref(ms))
+    rc = lib().sicp_accumulate_batch(_handles(engines), n, _ptr(qts, _dp), _ptr(out, _dp), repeat, C.byref(ms))
     if rc != 0:
         raise RuntimeError(f"sicp_accumulate_batch failed: {_strerror(rc)} ({rc})")
     return out, ms.value

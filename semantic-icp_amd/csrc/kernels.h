@@ -121,6 +121,16 @@ struct AccArgs {
   const double* partials_in;  // chained solve: the previous launch's partials (fed in this launch's prologue)
 };
 
+// job arrays passed by value to one launch (lock-step batch); sized to stay inside the 4 KB of
+// kernel arguments
+constexpr int kMaxKnnJobs = 8;
+constexpr int kMaxSmallJobs = 16;
+struct KnnJobs { KnnArgs job[kMaxKnnJobs]; };
+struct CovJobs { CovArgs job[kMaxSmallJobs]; };
+struct ProjJobs { ProjArgs job[kMaxSmallJobs]; };
+struct WeightJobs { WeightArgs job[kMaxKnnJobs]; };
+static_assert(sizeof(KnnJobs) <= 4000 && sizeof(WeightJobs) <= 4000 && sizeof(CovJobs) <= 4000, "kernel argument segment");
+
 // one pair of a lock-step batch (sicp_align_batch); an array of these lives in HBM
 struct BatchArgs {
   AccArgs a;
@@ -139,6 +149,10 @@ hipError_t launch_cov(const CovArgs& a, hipStream_t st);
 hipError_t launch_proj(const ProjArgs& a, hipStream_t st);
 hipError_t launch_em_weight(const WeightArgs& a, hipStream_t st);
 hipError_t launch_fused_labels(const WeightArgs& a, uint32_t* out, hipStream_t st);
+hipError_t launch_bvh_knn_packet_jobs(int K, const KnnArgs* jobs, int n, hipStream_t st);
+hipError_t launch_cov_jobs(const CovArgs* jobs, int n, hipStream_t st);
+hipError_t launch_proj_jobs(const ProjArgs* jobs, int n, hipStream_t st);
+hipError_t launch_em_weight_jobs(const WeightArgs* jobs, int n, hipStream_t st);
 int accumulate_blocks(int total);
 hipError_t launch_accumulate_kernel(const AccArgs& a, hipStream_t st);
 hipError_t launch_finalize(const AccArgs& a, double* out28, hipStream_t st);

@@ -566,11 +566,11 @@ __device__ __forceinline__ unsigned child_mask_packet(const float4* __restrict__
 // WPB waves (packets) per workgroup: one-wave workgroups are launched too slowly to fill the chip
 // (6250 of them at 100K queries: ~1.5 waves per SIMD resident on average)
 template <int K, int WPB>
-__global__ __launch_bounds__(64 * WPB) void bvh_knn_packet_kernel(KnnArgs a) {
+__device__ __forceinline__ void knn_packet_body(const KnnArgs& a, int wg, int n_wg) {
   __shared__ u64 s_merge_all[WPB][16][4][K];
   u64 (&s_merge)[16][4][K] = s_merge_all[threadIdx.x >> 6];
   const int lane = threadIdx.x & 63, sub = lane & 3, slot = lane >> 2;
-  const int bid = xcd_contiguous_block((int)blockIdx.x, (int)gridDim.x) * WPB + (int)(threadIdx.x >> 6);
+  const int bid = xcd_contiguous_block(wg, n_wg) * WPB + (int)(threadIdx.x >> 6);
   if (bid * 16 >= a.q_count) return;  // a surplus wave of the last workgroup (no barrier below is block-wide)
   const int q_raw = bid * 16 + slot;
   const int q = min(q_raw, a.q_count - 1);  // a padding quad repeats the last query and is not emitted
@@ -684,6 +684,22 @@ __global__ __launch_bounds__(64 * WPB) void bvh_knn_packet_kernel(KnnArgs a) {
   }
 }
 
+template <int K, int WPB>
+__global__ __launch_bounds__(64 * WPB) void bvh_knn_packet_kernel(KnnArgs a) {
+  knn_packet_body<K, WPB>(a, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Several searches in one launch (lock-step batch: all pairs' searches of a phase): blockIdx.y picks
+// the job from an array passed BY VALUE -- kernel arguments keep their pointers typed as HBM and
+// are read with scalar loads.  The jobs' long tails overlap inside the one launch.
+template <int K, int WPB>
+__global__ __launch_bounds__(64 * WPB) void bvh_knn_packet_jobs_kernel(KnnJobs jobs) {
+  const KnnArgs& a = jobs.job[blockIdx.y];
+  const int n_wg = ((a.q_count + 15) / 16 + WPB - 1) / WPB;
+  if ((int)blockIdx.x >= n_wg) return;
+  knn_packet_body<K, WPB>(a, (int)blockIdx.x, n_wg);
+}
+
 // ------------------------------------------------------------------------------------------
 // covariance / normal / label histogram from the k-neighbour lists   (em_icp.hpp:298-340)
 // ------------------------------------------------------------------------------------------
@@ -713,7 +729,7 @@ __device__ __forceinline__ void jacobi_rotate(double (&A)[3][3], double (&V)[3][
   }
 }
 
-__global__ __launch_bounds__(256) void cov_kernel(CovArgs a) {
+__device__ __forceinline__ void cov_body(const CovArgs& a) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.n) return;
   double mean0 = 0, mean1 = 0, mean2 = 0;
@@ -785,7 +801,10 @@ __global__ __launch_bounds__(256) void cov_kernel(CovArgs a) {
 //   proj[i][s] = dist_i^T * CM[:, s]   (the two factors of em_icp.hpp:86-87), dist = counts * 1/k
 // accumulated over r in ascending order exactly like the reference's dot product.  Computed once per
 // align() per cloud, so the per-correspondence weight is a C-term product-sum of two such rows.
-__global__ __launch_bounds__(256) void proj_kernel(ProjArgs a) {
+__global__ __launch_bounds__(256) void cov_kernel(CovArgs a) { cov_body(a); }
+__global__ __launch_bounds__(256) void cov_jobs_kernel(CovJobs jobs) { cov_body(jobs.job[blockIdx.y]); }
+
+__device__ __forceinline__ void proj_body(const ProjArgs& a) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= a.n * a.C) return;
   const int i = e / a.C, s = e - i * a.C;
@@ -881,7 +900,10 @@ __device__ __forceinline__ void loss_eval(const LossArgs& L, double s, double w,
 // ------------------------------------------------------------------------------------------
 // EM weight: label posterior from the confusion matrix x the (bool) geometric gate
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void em_weight_kernel(WeightArgs a) {
+__global__ __launch_bounds__(256) void proj_kernel(ProjArgs a) { proj_body(a); }
+__global__ __launch_bounds__(256) void proj_jobs_kernel(ProjJobs jobs) { proj_body(jobs.job[blockIdx.y]); }
+
+__device__ __forceinline__ void em_weight_body(const WeightArgs& a) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= a.n_s * a.K) return;
   const int i = e / a.K;
@@ -909,6 +931,9 @@ __global__ __launch_bounds__(256) void em_weight_kernel(WeightArgs a) {
   }
   a.w[e] = prob;
 }
+
+__global__ __launch_bounds__(256) void em_weight_kernel(WeightArgs a) { em_weight_body(a); }
+__global__ __launch_bounds__(256) void em_weight_jobs_kernel(WeightJobs jobs) { em_weight_body(jobs.job[blockIdx.y]); }
 
 // ------------------------------------------------------------------------------------------
 // accumulate: 28 doubles = [H upper 21 | g 6 | cost] over all correspondence slots
@@ -938,7 +963,19 @@ __device__ __forceinline__ double wave_sum(double v) {
 #define SICP_GLOBAL __attribute__((address_space(1)))
 
 // the per-lane part of one evaluation: groups of 4 slots, loads first (see accumulate_kernel)
-template <int K, int BS>
+// the pose is the same in every lane: held in scalar registers it costs no VGPRs (24 otherwise)
+__device__ __forceinline__ void pose_to_sgprs(Pose& P) {
+#pragma unroll
+  for (int k = 0; k < 9; ++k) P.R[k] = readlane_f64(P.R[k], 0);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) P.t[k] = readlane_f64(P.t[k], 0);
+}
+
+// PF = slots whose loads are in flight together inside a lane.  4 (the whole group: four
+// independent gather chains per lane) is right when a launch has fewer waves than the chip has
+// SIMDs (one pair alone); a batch launch has many waves per SIMD to hide latency with and prefers
+// the smaller register footprint of PF = 2 (three waves per SIMD instead of two).
+template <int K, int BS, int PF = 4>
 __device__ __forceinline__ void accumulate_groups(const AccArgs& a, const Pose& P, int block, int nb, double (&acc)[28]) {
 #pragma unroll
   for (int k = 0; k < 28; ++k) acc[k] = 0.0;
@@ -954,8 +991,7 @@ __device__ __forceinline__ void accumulate_groups(const AccArgs& a, const Pose& 
   const int n_groups = (total + 3) >> 2;
   for (int g = block * BS + threadIdx.x; g < n_groups; g += nb * BS) {
     const int e0 = g << 2;
-    int j[4], i[4];
-    double w[4];
+    int j[4];
     if (e0 + 3 < total) {
       typedef int v4i __attribute__((ext_vector_type(4)));
       const v4i jv = *(const SICP_GLOBAL v4i*)(idx + e0);
@@ -964,41 +1000,47 @@ __device__ __forceinline__ void accumulate_groups(const AccArgs& a, const Pose& 
 #pragma unroll
       for (int c = 0; c < 4; ++c) j[c] = e0 + c < total ? idx[e0 + c] : -1;
     }
-    float sxv[4], syv[4], szv[4], txv[4], tyv[4], tzv[4];
-    double snx[4], sny[4], snz[4], tnx[4], tny[4], tnz[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      i[c] = min((e0 + c) / K, a.n_s - 1);
-      const int jj = max(j[c], 0);
-      w[c] = wgt ? wgt[min(e0 + c, total - 1)] : 1.0;
-      if (K != 4 || c == 0) {
-        sxv[c] = sx[i[c]]; syv[c] = sy[i[c]]; szv[c] = sz[i[c]];
-        snx[c] = g_snx[i[c]]; sny[c] = g_sny[i[c]]; snz[c] = g_snz[i[c]];
-      } else {  // K == 4: the four slots of a group share one source point
-        sxv[c] = sxv[0]; syv[c] = syv[0]; szv[c] = szv[0];
-        snx[c] = snx[0]; sny[c] = sny[0]; snz[c] = snz[0];
+    for (int c0 = 0; c0 < 4; c0 += PF) {
+      int i[PF];
+      double w[PF];
+      float sxv[PF], syv[PF], szv[PF], txv[PF], tyv[PF], tzv[PF];
+      double snx[PF], sny[PF], snz[PF], tnx[PF], tny[PF], tnz[PF];
+#pragma unroll
+      for (int c = 0; c < PF; ++c) {
+        const int e = e0 + c0 + c;
+        i[c] = min(e / K, a.n_s - 1);
+        const int jj = max(j[c0 + c], 0);
+        w[c] = wgt ? wgt[min(e, total - 1)] : 1.0;
+        if (K != 4 || c == 0) {
+          sxv[c] = sx[i[c]]; syv[c] = sy[i[c]]; szv[c] = sz[i[c]];
+          snx[c] = g_snx[i[c]]; sny[c] = g_sny[i[c]]; snz[c] = g_snz[i[c]];
+        } else {  // K == 4: the four slots of a group share one source point
+          sxv[c] = sxv[0]; syv[c] = syv[0]; szv[c] = szv[0];
+          snx[c] = snx[0]; sny[c] = sny[0]; snz[c] = snz[0];
+        }
+        txv[c] = tx[jj]; tyv[c] = ty[jj]; tzv[c] = tz[jj];
+        tnx[c] = g_tnx[jj]; tny[c] = g_tny[jj]; tnz[c] = g_tnz[jj];
       }
-      txv[c] = tx[jj]; tyv[c] = ty[jj]; tzv[c] = tz[jj];
-      tnx[c] = g_tnx[jj]; tny[c] = g_tny[jj]; tnz[c] = g_tnz[jj];
-    }
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+      for (int c = 0; c < PF; ++c) {
 #pragma clang fp contract(fast)
-      if (j[c] < 0) continue;
-      Corr cr;
-      corr_eval<true>(P, a.one_m_eps, sxv[c], syv[c], szv[c], snx[c], sny[c], snz[c], txv[c], tyv[c], tzv[c], tnx[c],
-                      tny[c], tnz[c], cr);
-      double rho0, rho1;
-      loss_eval(a.loss, cr.r * cr.r, w[c], rho0, rho1);
-      int o = 0;
+        if (j[c0 + c] < 0) continue;
+        Corr cr;
+        corr_eval<true>(P, a.one_m_eps, sxv[c], syv[c], szv[c], snx[c], sny[c], snz[c], txv[c], tyv[c], tzv[c], tnx[c],
+                        tny[c], tnz[c], cr);
+        double rho0, rho1;
+        loss_eval(a.loss, cr.r * cr.r, w[c], rho0, rho1);
+        int o = 0;
 #pragma unroll
-      for (int p = 0; p < 6; ++p) {
-        const double jp = rho1 * cr.J[p];
+        for (int p = 0; p < 6; ++p) {
+          const double jp = rho1 * cr.J[p];
 #pragma unroll
-        for (int q = p; q < 6; ++q) acc[o++] += jp * cr.J[q];
-        acc[21 + p] += jp * cr.r;
+          for (int q = p; q < 6; ++q) acc[o++] += jp * cr.J[q];
+          acc[21 + p] += jp * cr.r;
+        }
+        acc[27] += 0.5 * rho0;
       }
-      acc[27] += 0.5 * rho0;
     }
   }
 }
@@ -1025,6 +1067,7 @@ __global__ __launch_bounds__(BS) void accumulate_kernel(AccArgs a) {
   } else {
     P = a.pose;
   }
+  pose_to_sgprs(P);
   double acc[28];
   accumulate_groups<K, BS>(a, P, (int)blockIdx.x, (int)gridDim.x, acc);
   // block reduction: transpose through LDS, then wave w owns outputs w, w + BS/64, ...
@@ -1166,6 +1209,7 @@ __global__ __launch_bounds__(BS) void accumulate_chain_kernel(AccArgs a) {
   Pose P;
   se3::rotation(S->pose, P.R);
   P.t[0] = S->pose[4]; P.t[1] = S->pose[5]; P.t[2] = S->pose[6];
+  pose_to_sgprs(P);
   double acc[28];
   accumulate_groups<K, BS>(a, P, (int)blockIdx.x, nb, acc);
 #pragma unroll
@@ -1191,7 +1235,7 @@ __global__ __launch_bounds__(BS) void accumulate_chain_kernel(AccArgs a) {
 // invalidations than P pairs solving side by side on their own streams, and P x 15 MB of
 // algorithmic traffic behind one ~10 us launch floor.  Per pair the arithmetic, the block
 // decomposition and therefore the bits are those of accumulate_kernel.
-template <int K, int BS>
+template <int K, int BS, int PF>
 __global__ __launch_bounds__(BS) void accumulate_batch_kernel(const BatchArgs* __restrict__ batch) {
   __shared__ double red[28][BS];
   const BatchArgs& B = batch[blockIdx.y];
@@ -1206,8 +1250,9 @@ __global__ __launch_bounds__(BS) void accumulate_batch_kernel(const BatchArgs* _
   } else {
     P = a.pose;
   }
+  pose_to_sgprs(P);
   double acc[28];
-  accumulate_groups<K, BS>(a, P, block, nb, acc);
+  accumulate_groups<K, BS, PF>(a, P, block, nb, acc);
 #pragma unroll
   for (int k = 0; k < 28; ++k) red[k][threadIdx.x] = acc[k];
   __syncthreads();
@@ -1464,6 +1509,63 @@ hipError_t launch_em_weight(const WeightArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 
+// job-array launches (lock-step batch): every job of one launch, grid.y = job
+hipError_t launch_bvh_knn_packet_jobs(int K, const KnnArgs* jobs, int n, hipStream_t st) {
+  for (int b = 0; b < n; b += kMaxKnnJobs) {
+    const int cnt = n - b < kMaxKnnJobs ? n - b : kMaxKnnJobs;
+    KnnJobs J;
+    int max_q = 0;
+    for (int i = 0; i < cnt; ++i) { J.job[i] = jobs[b + i]; max_q = jobs[b + i].q_count > max_q ? jobs[b + i].q_count : max_q; }
+    if (max_q <= 0) continue;
+    const int packets = (max_q + 15) / 16;
+#define SICP_PKJ(KK, W) hipLaunchKernelGGL((bvh_knn_packet_jobs_kernel<KK, W>), dim3((packets + W - 1) / W, cnt), dim3(64 * W), 0, st, J)
+    switch (K) {
+      case 1: SICP_PKJ(1, 4); break;
+      case 4: SICP_PKJ(4, 4); break;
+      case 20: SICP_PKJ(20, 2); break;
+      default: return hipErrorInvalidValue;
+    }
+#undef SICP_PKJ
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_cov_jobs(const CovArgs* jobs, int n, hipStream_t st) {
+  for (int b = 0; b < n; b += kMaxSmallJobs) {
+    const int cnt = n - b < kMaxSmallJobs ? n - b : kMaxSmallJobs;
+    CovJobs J;
+    int mx = 0;
+    for (int i = 0; i < cnt; ++i) { J.job[i] = jobs[b + i]; mx = jobs[b + i].n > mx ? jobs[b + i].n : mx; }
+    if (mx <= 0) continue;
+    hipLaunchKernelGGL(cov_jobs_kernel, dim3((mx + 255) / 256, cnt), dim3(256), 0, st, J);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_proj_jobs(const ProjArgs* jobs, int n, hipStream_t st) {
+  for (int b = 0; b < n; b += kMaxSmallJobs) {
+    const int cnt = n - b < kMaxSmallJobs ? n - b : kMaxSmallJobs;
+    ProjJobs J;
+    int mx = 0;
+    for (int i = 0; i < cnt; ++i) { J.job[i] = jobs[b + i]; const int t = jobs[b + i].n * jobs[b + i].C; mx = t > mx ? t : mx; }
+    if (mx <= 0) continue;
+    hipLaunchKernelGGL(proj_jobs_kernel, dim3((mx + 255) / 256, cnt), dim3(256), 0, st, J);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_em_weight_jobs(const WeightArgs* jobs, int n, hipStream_t st) {
+  for (int b = 0; b < n; b += kMaxKnnJobs) {
+    const int cnt = n - b < kMaxKnnJobs ? n - b : kMaxKnnJobs;
+    WeightJobs J;
+    int mx = 0;
+    for (int i = 0; i < cnt; ++i) { J.job[i] = jobs[b + i]; const int t = jobs[b + i].n_s * jobs[b + i].K; mx = t > mx ? t : mx; }
+    if (mx <= 0) continue;
+    hipLaunchKernelGGL(em_weight_jobs_kernel, dim3((mx + 255) / 256, cnt), dim3(256), 0, st, J);
+  }
+  return hipGetLastError();
+}
+
 hipError_t launch_fused_labels(const WeightArgs& a, uint32_t* out, hipStream_t st) {
   if (a.n_s <= 0) return hipSuccess;
   hipLaunchKernelGGL(fused_label_kernel, dim3((a.n_s + 255) / 256), dim3(256), 0, st, a, out);
@@ -1495,12 +1597,20 @@ static hipError_t launch_accumulate_only(const AccArgs& a, int nb, hipStream_t s
 hipError_t launch_accumulate_batch(int K, const BatchArgs* batch, int n, int max_nb, hipStream_t st) {
   if (n <= 0) return hipSuccess;
   const dim3 grid(max_nb, n);
+  static const int pf = [] { const char* e = getenv("SICP_ACC_BATCH_PF"); return e ? atoi(e) : 4; }();  // tuning aid
+#define SICP_AB(KK) \
+  do { \
+    if (pf == 1) hipLaunchKernelGGL((accumulate_batch_kernel<KK, 256, 1>), grid, dim3(256), 0, st, batch); \
+    else if (pf == 2) hipLaunchKernelGGL((accumulate_batch_kernel<KK, 256, 2>), grid, dim3(256), 0, st, batch); \
+    else hipLaunchKernelGGL((accumulate_batch_kernel<KK, 256, 4>), grid, dim3(256), 0, st, batch); \
+  } while (0)
   switch (K) {
-    case 1: hipLaunchKernelGGL((accumulate_batch_kernel<1, 256>), grid, dim3(256), 0, st, batch); break;
-    case 4: hipLaunchKernelGGL((accumulate_batch_kernel<4, 256>), grid, dim3(256), 0, st, batch); break;
-    case 20: hipLaunchKernelGGL((accumulate_batch_kernel<20, 256>), grid, dim3(256), 0, st, batch); break;
+    case 1: SICP_AB(1); break;
+    case 4: SICP_AB(4); break;
+    case 20: SICP_AB(20); break;
     default: return hipErrorInvalidValue;
   }
+#undef SICP_AB
   return hipGetLastError();
 }
 

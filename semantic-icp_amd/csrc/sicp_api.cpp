@@ -98,8 +98,19 @@ double now_ms() {
 
 }  // namespace
 
+// lock-step batch: instead of launching, the per-pair stages append their jobs here; the batch driver
+// launches each kind once for all pairs (kernels.h: *_jobs launchers), in dependency order
+struct JobCollector {
+  int knn_K = 0;
+  std::vector<sicp::KnnArgs> knn;
+  std::vector<sicp::CovArgs> cov;
+  std::vector<sicp::ProjArgs> proj;
+  std::vector<sicp::WeightArgs> weight;
+};
+
 struct sicp_context {
   int device = 0;
+  JobCollector* collect = nullptr;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;  // second cloud's feature kernels run beside the first's
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_join = nullptr;
@@ -314,6 +325,11 @@ int run_nn(sicp_context* h, int K, const Cloud& Qc, int q_begin, int q_count, co
     DevBuf<int> dbg;
     if (want_dbg) { HIPCHECK(dbg.reserve((size_t)2 * q_count)); a.dbg = dbg.p; }
     static const bool lane_per_query = std::getenv("SICP_KNN_LANE_PER_QUERY") != nullptr;  // A/B aid
+    if (h->collect) {  // lock-step batch (packet search, no profiling: checked by the driver)
+      h->collect->knn_K = K;
+      h->collect->knn.push_back(a);
+      return SICP_OK;
+    }
     KernelTimer kt(h, stream == h->stream ? timer_bit : 0);
     if (lane_per_query) HIPCHECK(sicp::launch_bvh_knn(K, a, stream));
     else if (h->params.nn_method == 2) HIPCHECK(sicp::launch_bvh_knn_quad(K, a, stream));
@@ -397,7 +413,8 @@ int ensure_proj(sicp_context* h, Cloud& c) {
   sicp::ProjArgs a;
   a.n = c.n; a.C = P.num_classes;
   a.hist = c.hist.p; a.cm = h->d_cm.p; a.hval = h->d_hval.p; a.proj = c.proj.p;
-  HIPCHECK(sicp::launch_proj(a, h->stream));
+  if (h->collect) h->collect->proj.push_back(a);
+  else HIPCHECK(sicp::launch_proj(a, h->stream));
   c.proj_valid = true;
   return SICP_OK;
 }
@@ -423,7 +440,8 @@ int compute_features(sicp_context* h, Cloud& c, bool with_hist, hipStream_t stre
   a.float_products = P.quirk_float_products;
   a.nx = c.nx.p; a.ny = c.ny.p; a.nz = c.nz.p;
   a.hist = with_hist ? c.hist.p : nullptr;
-  HIPCHECK(sicp::launch_cov(a, stream));
+  if (h->collect) h->collect->cov.push_back(a);
+  else HIPCHECK(sicp::launch_cov(a, stream));
   c.feat_valid = true;
   c.proj_valid = false;
   c.feat_k = k; c.feat_C = with_hist ? P.num_classes : 0;
@@ -509,7 +527,8 @@ int run_correspondences(sicp_context* h, const double* qt, int K, bool weights) 
     a.one_m_eps = 1.0 - P.epsilon;
     a.bool_probability = P.quirk_bool_probability;
     a.w = h->w.p;
-    HIPCHECK(sicp::launch_em_weight(a, h->stream));
+    if (h->collect) h->collect->weight.push_back(a);
+    else HIPCHECK(sicp::launch_em_weight(a, h->stream));
     h->st.weight_launches += 1;
     h->st.weight_kernel_ms += kt.stop();
     h->st.t_weight_ms += now_ms() - t0;
@@ -765,6 +784,31 @@ int batch_reserve(sicp_context* h, int n) {
   }
   return SICP_OK;
 }
+
+// launches what the pairs' stages collected: searches, then the kernels that consume them
+int flush_jobs(sicp_context* h, JobCollector& jc) {
+  if (!jc.knn.empty()) HIPCHECK(sicp::launch_bvh_knn_packet_jobs(jc.knn_K, jc.knn.data(), (int)jc.knn.size(), h->stream));
+  if (!jc.cov.empty()) HIPCHECK(sicp::launch_cov_jobs(jc.cov.data(), (int)jc.cov.size(), h->stream));
+  if (!jc.proj.empty()) HIPCHECK(sicp::launch_proj_jobs(jc.proj.data(), (int)jc.proj.size(), h->stream));
+  if (!jc.weight.empty()) HIPCHECK(sicp::launch_em_weight_jobs(jc.weight.data(), (int)jc.weight.size(), h->stream));
+  jc.knn.clear(); jc.cov.clear(); jc.proj.clear(); jc.weight.clear();
+  return SICP_OK;
+}
+
+// while a lock-step batch runs, all its handles work on the leader's stream and collect their jobs
+struct BatchGuard {
+  sicp_handle* hs; int n;
+  std::vector<hipStream_t> s1, s2;
+  BatchGuard(sicp_handle* handles, int count, JobCollector* jc, hipStream_t stream) : hs(handles), n(count), s1(count), s2(count) {
+    for (int p = 0; p < n; ++p) {
+      s1[p] = hs[p]->stream; s2[p] = hs[p]->stream2;
+      if (jc) { hs[p]->collect = jc; hs[p]->stream = stream; hs[p]->stream2 = stream; }
+    }
+  }
+  ~BatchGuard() {
+    for (int p = 0; p < n; ++p) { hs[p]->collect = nullptr; hs[p]->stream = s1[p]; hs[p]->stream2 = s2[p]; }
+  }
+};
 
 // The inner solves of all active pairs, in lock step: one accumulate launch evaluates every pair's
 // current LM pose, one step launch advances every pair's trust-region machine (csrc/lm.hpp, the
@@ -1078,7 +1122,19 @@ int sicp_align_batch(sicp_handle* hs, int32_t n, const double* init_qt, double* 
   }
   const sicp_params& P = L->params;
   const double t_begin = now_ms();
-  for (int p = 0; p < n; ++p) SICPCHECK(align_begin(hs[p], stats != nullptr));  // asynchronous: the pairs' feature kernels overlap
+  // One launch per kind of kernel for ALL pairs (searches, covariances, projections, weights):
+  // their long tails overlap inside the launch.  (With profiling on, or another search engine
+  // selected, every pair launches its own kernels on its own stream instead.)
+  bool one_launch = true;
+  for (int p = 0; p < n; ++p) {
+    one_launch = one_launch && hs[p]->params.profile == 0 && hs[p]->params.nn_method == 1;
+    sicp_context* h = hs[p];
+    HIPCHECK(hipStreamSynchronize(h->stream));  // earlier work of the handle on its own stream
+  }
+  JobCollector jc;
+  BatchGuard guard(hs, n, one_launch ? &jc : nullptr, L->stream);
+  for (int p = 0; p < n; ++p) SICPCHECK(align_begin(hs[p], stats != nullptr));
+  if (one_launch) SICPCHECK(flush_jobs(L, jc));
   std::vector<OuterState> o(n);
   for (int p = 0; p < n; ++p) std::memcpy(o[p].cur, init_qt + 7 * p, sizeof o[p].cur);
   std::vector<SolveResult> res(n);
@@ -1091,9 +1147,10 @@ int sicp_align_batch(sicp_handle* hs, int32_t n, const double* init_qt, double* 
       ++n_active;
       std::memcpy(o[p].est, o[p].cur, sizeof o[p].est);
       if (P.mode == SICP_MODE_SEMANTIC) o[p].count++;
-      SICPCHECK(run_correspondences(hs[p], o[p].cur, P.knn, true));  // on the pair's own stream: the searches overlap
+      SICPCHECK(run_correspondences(hs[p], o[p].cur, P.knn, true));
     }
     if (n_active == 0) break;
+    if (one_launch) SICPCHECK(flush_jobs(L, jc));
     const double t0 = now_ms();
     {
       int rc = run_solve_batch(L, hs, n, active.data(), o.data(), res.data());
@@ -1118,7 +1175,7 @@ int sicp_align_batch(sicp_handle* hs, int32_t n, const double* init_qt, double* 
   return SICP_OK;
 }
 
-int sicp_accumulate_batch(sicp_handle* hs, int32_t n, const double* qt, double* out28, double* kernel_ms) {
+int sicp_accumulate_batch(sicp_handle* hs, int32_t n, const double* qt, double* out28, int32_t repeat, double* kernel_ms) {
   if (!hs || n < 1 || !qt || !out28) return SICP_ERR_INVALID_ARGUMENT;
   for (int p = 0; p < n; ++p)
     if (!hs[p] || !hs[p]->corr_valid || hs[p]->device != hs[0]->device || hs[p]->corr_K != hs[0]->corr_K) return SICP_ERR_NOT_READY;
@@ -1138,8 +1195,9 @@ int sicp_accumulate_batch(sicp_handle* hs, int32_t n, const double* qt, double* 
     HIPCHECK(hipStreamSynchronize(g->stream));  // the pair's correspondences are complete
   }
   HIPCHECK(hipMemcpyAsync(h->d_batch.p, h->h_batch, sizeof(sicp::BatchArgs) * n, hipMemcpyHostToDevice, h->stream));
+  if (repeat < 1) repeat = 1;
   HIPCHECK(hipEventRecord(h->ev0, h->stream));
-  HIPCHECK(sicp::launch_accumulate_batch(h->corr_K, h->d_batch.p, n, max_nb, h->stream));
+  for (int r = 0; r < repeat; ++r) HIPCHECK(sicp::launch_accumulate_batch(h->corr_K, h->d_batch.p, n, max_nb, h->stream));
   HIPCHECK(hipEventRecord(h->ev1, h->stream));
   HIPCHECK(sicp::launch_finalize_batch(h->d_batch.p, n, h->d_bout28.p, h->stream));
   HIPCHECK(hipMemcpyAsync(h->h_bout28, h->d_bout28.p, sizeof(double) * 28 * n, hipMemcpyDeviceToHost, h->stream));
@@ -1148,7 +1206,7 @@ int sicp_accumulate_batch(sicp_handle* hs, int32_t n, const double* qt, double* 
   if (kernel_ms) {
     float ms = 0.f;
     HIPCHECK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
-    *kernel_ms = ms;
+    *kernel_ms = (double)ms / repeat;
   }
   return SICP_OK;
 }
