@@ -875,6 +875,111 @@ __device__ __forceinline__ void corr_eval(const Pose& P, double one_m_eps, doubl
   }
 }
 
+// The accumulate kernels' form of corr_eval<true>: everything that only depends on the SOURCE point
+// (shared by the K = 4 or 20 slots of one source point) is computed once per group of four slots.
+struct SrcTerms {
+  double qx, qy, qz;                      // R p_s + t
+  double mx, my, mz;                      // m = R n_s
+  double e00, e01, e02, e11, e12, e22;    // (1-eps) m m^T
+};
+
+__device__ __forceinline__ void src_terms(const Pose& P, double one_m_eps, double psx, double psy, double psz, double nsx,
+                                          double nsy, double nsz, SrcTerms& s) {
+#pragma clang fp contract(fast)
+  const double* R = P.R;
+  s.qx = R[0] * psx + R[1] * psy + R[2] * psz + P.t[0];
+  s.qy = R[3] * psx + R[4] * psy + R[5] * psz + P.t[1];
+  s.qz = R[6] * psx + R[7] * psy + R[8] * psz + P.t[2];
+  s.mx = R[0] * nsx + R[1] * nsy + R[2] * nsz;
+  s.my = R[3] * nsx + R[4] * nsy + R[5] * nsz;
+  s.mz = R[6] * nsx + R[7] * nsy + R[8] * nsz;
+  const double ex = one_m_eps * s.mx, ey = one_m_eps * s.my, ez = one_m_eps * s.mz;
+  s.e00 = ex * s.mx; s.e01 = ex * s.my; s.e02 = ex * s.mz;
+  s.e11 = ey * s.my; s.e12 = ey * s.mz; s.e22 = ez * s.mz;
+}
+
+__device__ __forceinline__ void corr_eval_src(const Pose& P, double one_m_eps, const SrcTerms& s, double psx, double psy,
+                                              double psz, double nsx, double nsy, double nsz, double ptx, double pty,
+                                              double ptz, double ntx, double nty, double ntz, Corr& o) {
+#pragma clang fp contract(fast)
+  const double* R = P.R;
+  // A = C_t + R C_s R^T = 2I - (1-eps) n_t n_t^T - (1-eps) m m^T
+  const double fx = one_m_eps * ntx, fy = one_m_eps * nty, fz = one_m_eps * ntz;
+  const double a00 = (2.0 - s.e00) - fx * ntx;
+  const double a01 = -s.e01 - fx * nty;
+  const double a02 = -s.e02 - fx * ntz;
+  const double a11 = (2.0 - s.e11) - fy * nty;
+  const double a12 = -s.e12 - fy * ntz;
+  const double a22 = (2.0 - s.e22) - fz * ntz;
+  const double rx = ptx - s.qx, ry = pty - s.qy, rz = ptz - s.qz;
+  // Eigen Matrix3d::inverse(): cofactors / determinant
+  const double k00 = a11 * a22 - a12 * a12;
+  const double k01 = a02 * a12 - a01 * a22;
+  const double k02 = a01 * a12 - a02 * a11;
+  const double k11 = a00 * a22 - a02 * a02;
+  const double k12 = a01 * a02 - a00 * a12;
+  const double k22 = a00 * a11 - a01 * a01;
+  const double det = a00 * k00 + a01 * k01 + a02 * k02;
+  const double inv = 1.0 / det;
+  const double ax = inv * (k00 * rx + k01 * ry + k02 * rz);
+  const double ay = inv * (k01 * rx + k11 * ry + k12 * rz);
+  const double az = inv * (k02 * rx + k12 * ry + k22 * rz);
+  o.r = rx * ax + ry * ay + rz * az;
+  o.detA = det;
+  const double bx = R[0] * ax + R[3] * ay + R[6] * az;  // b = R^T a
+  const double by = R[1] * ax + R[4] * ay + R[7] * az;
+  const double bz = R[2] * ax + R[5] * ay + R[8] * az;
+  const double nb = one_m_eps * (nsx * bx + nsy * by + nsz * bz);
+  const double cx = psx + bx - nb * nsx;  // c = p_s + C_s b
+  const double cy = psy + by - nb * nsy;
+  const double cz = psz + bz - nb * nsz;
+  o.J[0] = -2.0 * bx; o.J[1] = -2.0 * by; o.J[2] = -2.0 * bz;
+  o.J[3] = 2.0 * (by * cz - bz * cy);
+  o.J[4] = 2.0 * (bz * cx - bx * cz);
+  o.J[5] = 2.0 * (bx * cy - by * cx);
+}
+
+// log(x) for finite x >= 1 -- the only arguments the losses produce (1 + s/a^2 and 1 + sqrt(s)/a^2).
+// The classic argument-reduction + odd-polynomial scheme of fdlibm's e_log.c (x = 2^k m,
+// f = m - 1, s = f / (2 + f), log(1+f) = 2s + s R(s^2) ...), < 1 ulp, with the division replaced by
+// v_rcp_f64 + two Newton steps and none of the library routine's special cases: ~35 instructions
+// instead of ~80.  The logarithm was 40 % of the accumulate kernel's instructions.
+__device__ __forceinline__ double log_ge1(double x) {
+#pragma clang fp contract(fast)
+  double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
+  int k = __builtin_amdgcn_frexp_exp(x);
+  const bool low = m < 0.70710678118654752440;
+  m = low ? m + m : m;
+  k = low ? k - 1 : k;
+  const double f = m - 1.0, d = 2.0 + f, dk = (double)k;
+  double r = __builtin_amdgcn_rcp(d);
+  r = r + r * (1.0 - d * r);
+  r = r + r * (1.0 - d * r);
+  const double sq = f * r, z = sq * sq, w = z * z;
+  const double t1 = w * (3.999999999940941908e-01 + w * (2.222219843214978396e-01 + w * 1.531383769920937332e-01));
+  const double t2 = z * (6.666666666666735130e-01 + w * (2.857142874366239149e-01 + w * (1.818357216161805012e-01 + w * 1.479819860511658591e-01)));
+  const double R = t2 + t1, hfsq = 0.5 * f * f;
+  return dk * 6.93147180369123816490e-01 - ((hfsq - (sq * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
+}
+
+// loss_eval for the accumulate kernels: g0 = sqrt(v) and g1 = 1 / (2 g0) both come from one
+// reciprocal square root (a square root and a division less per correspondence; ~1 ulp)
+__device__ __forceinline__ void loss_eval_acc(const LossArgs& L, double b, double c, double s, double w, double& rho0, double& rho1) {
+#pragma clang fp contract(fast)
+  if (L.use_sqloss) {
+    const double v = s + 2.220446049250313e-16;  // std::numeric_limits<double>::epsilon()
+    const double y = rsqrt(v);
+    const double g0 = v * y, g1 = 0.5 * y;
+    const double sum = 1.0 + g0 * c, invs = 1.0 / sum;
+    rho0 = w * (b * log_ge1(sum));
+    rho1 = (w * fmax(2.2250738585072014e-308, invs)) * g1;
+  } else {
+    const double sum = 1.0 + s * c, invs = 1.0 / sum;
+    rho0 = b * log_ge1(sum);
+    rho1 = fmax(2.2250738585072014e-308, invs);
+  }
+}
+
 // rho0 / rho1 of the reference's loss stacks at s = r^2 (em_icp.hpp:109-117,
 // gicp.hpp:98-104, semantic_icp.hpp:96; Ceres CauchyLoss/ScaledLoss/ComposedLoss, sqloss.h).
 // rho2 < 0 for all of them, so Ceres' Corrector scales residual and Jacobian by sqrt(rho1).
@@ -989,6 +1094,7 @@ __device__ __forceinline__ void accumulate_groups(const AccArgs& a, const Pose& 
   const SICP_GLOBAL double *g_tnx = (const SICP_GLOBAL double*)a.tnx, *g_tny = (const SICP_GLOBAL double*)a.tny, *g_tnz = (const SICP_GLOBAL double*)a.tnz;
   const int total = a.n_s * K;
   const int n_groups = (total + 3) >> 2;
+  const double loss_b = a.loss.cauchy_a * a.loss.cauchy_a, loss_c = 1.0 / loss_b;
   for (int g = block * BS + threadIdx.x; g < n_groups; g += nb * BS) {
     const int e0 = g << 2;
     int j[4];
@@ -1000,6 +1106,7 @@ __device__ __forceinline__ void accumulate_groups(const AccArgs& a, const Pose& 
 #pragma unroll
       for (int c = 0; c < 4; ++c) j[c] = e0 + c < total ? idx[e0 + c] : -1;
     }
+    SrcTerms st;
 #pragma unroll
     for (int c0 = 0; c0 < 4; c0 += PF) {
       int i[PF];
@@ -1025,12 +1132,17 @@ __device__ __forceinline__ void accumulate_groups(const AccArgs& a, const Pose& 
 #pragma unroll
       for (int c = 0; c < PF; ++c) {
 #pragma clang fp contract(fast)
-        if (j[c0 + c] < 0) continue;
+        // the four slots of a group share their source point when K is a multiple of 4 (EM: K = 4)
+        if (K % 4 != 0 || c0 + c == 0) src_terms(P, a.one_m_eps, sxv[c], syv[c], szv[c], snx[c], sny[c], snz[c], st);
+        // A gated-out slot (index -1) is evaluated on target 0 and weighted by exactly zero instead of
+        // being branched around: x + (+-0 * finite) == x bit for bit, and a divergent skip makes the
+        // compiler copy all 28 accumulators at the join (10 % of the kernel's instructions).
         Corr cr;
-        corr_eval<true>(P, a.one_m_eps, sxv[c], syv[c], szv[c], snx[c], sny[c], snz[c], txv[c], tyv[c], tzv[c], tnx[c],
-                        tny[c], tnz[c], cr);
+        corr_eval_src(P, a.one_m_eps, st, sxv[c], syv[c], szv[c], snx[c], sny[c], snz[c], txv[c], tyv[c], tzv[c], tnx[c], tny[c],
+                      tnz[c], cr);
         double rho0, rho1;
-        loss_eval(a.loss, cr.r * cr.r, w[c], rho0, rho1);
+        loss_eval_acc(a.loss, loss_b, loss_c, cr.r * cr.r, w[c], rho0, rho1);
+        if (j[c0 + c] < 0) { rho0 = 0.0; rho1 = 0.0; }
         int o = 0;
 #pragma unroll
         for (int p = 0; p < 6; ++p) {
