@@ -875,6 +875,16 @@ __device__ __forceinline__ void corr_eval(const Pose& P, double one_m_eps, doubl
   }
 }
 
+// 1/d for a normal, finite d: v_rcp_f64 (2^-26) + two Newton steps (~1 ulp; 5 instructions, the
+// correctly rounded division sequence is 14)
+__device__ __forceinline__ double rcp_newton(double d) {
+#pragma clang fp contract(fast)
+  double r = __builtin_amdgcn_rcp(d);
+  r = r + r * (1.0 - d * r);
+  r = r + r * (1.0 - d * r);
+  return r;
+}
+
 // The accumulate kernels' form of corr_eval<true>: everything that only depends on the SOURCE point
 // (shared by the K = 4 or 20 slots of one source point) is computed once per group of four slots.
 struct SrcTerms {
@@ -920,7 +930,7 @@ __device__ __forceinline__ void corr_eval_src(const Pose& P, double one_m_eps, c
   const double k12 = a01 * a02 - a00 * a12;
   const double k22 = a00 * a11 - a01 * a01;
   const double det = a00 * k00 + a01 * k01 + a02 * k02;
-  const double inv = 1.0 / det;
+  const double inv = rcp_newton(det);  // det in [~eps^2, 8]
   const double ax = inv * (k00 * rx + k01 * ry + k02 * rz);
   const double ay = inv * (k01 * rx + k11 * ry + k12 * rz);
   const double az = inv * (k02 * rx + k12 * ry + k22 * rz);
@@ -952,9 +962,7 @@ __device__ __forceinline__ double log_ge1(double x) {
   m = low ? m + m : m;
   k = low ? k - 1 : k;
   const double f = m - 1.0, d = 2.0 + f, dk = (double)k;
-  double r = __builtin_amdgcn_rcp(d);
-  r = r + r * (1.0 - d * r);
-  r = r + r * (1.0 - d * r);
+  const double r = rcp_newton(d);
   const double sq = f * r, z = sq * sq, w = z * z;
   const double t1 = w * (3.999999999940941908e-01 + w * (2.222219843214978396e-01 + w * 1.531383769920937332e-01));
   const double t2 = z * (6.666666666666735130e-01 + w * (2.857142874366239149e-01 + w * (1.818357216161805012e-01 + w * 1.479819860511658591e-01)));
@@ -970,11 +978,11 @@ __device__ __forceinline__ void loss_eval_acc(const LossArgs& L, double b, doubl
     const double v = s + 2.220446049250313e-16;  // std::numeric_limits<double>::epsilon()
     const double y = rsqrt(v);
     const double g0 = v * y, g1 = 0.5 * y;
-    const double sum = 1.0 + g0 * c, invs = 1.0 / sum;
+    const double sum = 1.0 + g0 * c, invs = rcp_newton(sum);
     rho0 = w * (b * log_ge1(sum));
     rho1 = (w * fmax(2.2250738585072014e-308, invs)) * g1;
   } else {
-    const double sum = 1.0 + s * c, invs = 1.0 / sum;
+    const double sum = 1.0 + s * c, invs = rcp_newton(sum);
     rho0 = b * log_ge1(sum);
     rho1 = fmax(2.2250738585072014e-308, invs);
   }
