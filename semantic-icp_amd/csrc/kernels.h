@@ -73,13 +73,16 @@ struct KnnArgs {
   int* out_i;
   float* out_d;
   int* dbg;        // nullable: [q_count][2] = (boxes tested, leaves scanned), debugging only
+  int out_stride;  // 0: out_i / out_d are [query][K]; > 0: [K][out_stride] (packet kernel only: coalesced
+                   // for the covariance kernel, which reads one neighbour rank of 64 points at a time)
 };
 
 struct CovArgs {
   int n, k, C;
   const float *x, *y, *z;
   const uint32_t* label;  // nullable
-  const int* nn;          // [n][k] global indices
+  const int* nn;          // neighbour lists, device indices: [n][k], or [k][nn_stride] when nn_stride > 0
+  int nn_stride;
   int float_products;
   double *nx, *ny, *nz;
   uint8_t* hist;          // [n][C] or nullptr
@@ -129,6 +132,8 @@ struct KnnJobs { KnnArgs job[kMaxKnnJobs]; };
 struct CovJobs { CovArgs job[kMaxSmallJobs]; };
 struct ProjJobs { ProjArgs job[kMaxSmallJobs]; };
 struct WeightJobs { WeightArgs job[kMaxKnnJobs]; };
+struct CountJob { const int* idx; int n; unsigned long long* out; };
+struct CountJobs { CountJob job[kMaxSmallJobs]; };
 static_assert(sizeof(KnnJobs) <= 4000 && sizeof(WeightJobs) <= 4000 && sizeof(CovJobs) <= 4000, "kernel argument segment");
 
 // one pair of a lock-step batch (sicp_align_batch); an array of these lives in HBM
@@ -153,6 +158,7 @@ hipError_t launch_bvh_knn_packet_jobs(int K, const KnnArgs* jobs, int n, hipStre
 hipError_t launch_cov_jobs(const CovArgs* jobs, int n, hipStream_t st);
 hipError_t launch_proj_jobs(const ProjArgs* jobs, int n, hipStream_t st);
 hipError_t launch_em_weight_jobs(const WeightArgs* jobs, int n, hipStream_t st);
+hipError_t launch_count_active_jobs(const CountJob* jobs, int n, hipStream_t st);
 int accumulate_blocks(int total);
 hipError_t launch_accumulate_kernel(const AccArgs& a, hipStream_t st);
 hipError_t launch_finalize(const AccArgs& a, double* out28, hipStream_t st);

@@ -668,7 +668,9 @@ __device__ __forceinline__ void knn_packet_body(const KnnArgs& a, int wg, int n_
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   if (sub == 0 && q_raw < a.q_count) {
     int p0 = 0, p1 = 0, p2 = 0, p3 = 0;
-    const size_t o = (size_t)(a.q_begin + q) * K;
+    // [query][K], or [K][out_stride] (consecutive queries -> consecutive addresses)
+    const size_t o = a.out_stride > 0 ? (size_t)(a.q_begin + q) : (size_t)(a.q_begin + q) * K;
+    const size_t ks = a.out_stride > 0 ? (size_t)a.out_stride : 1;
     for (int k = 0; k < K; ++k) {
       const u64 h0 = p0 < K ? s_merge[slot][0][p0] : KEY_EMPTY, h1 = p1 < K ? s_merge[slot][1][p1] : KEY_EMPTY;
       const u64 h2 = p2 < K ? s_merge[slot][2][p2] : KEY_EMPTY, h3 = p3 < K ? s_merge[slot][3][p3] : KEY_EMPTY;
@@ -678,8 +680,8 @@ __device__ __forceinline__ void knn_packet_body(const KnnArgs& a, int wg, int n_
       const unsigned orig = (unsigned)best;
       const float d = best == KEY_EMPTY ? INFINITY : key_dist(best);
       const bool keep = orig != 0xffffffffu && d < a.gate_sq;  // strict <, float compare (em_icp.hpp:65)
-      a.out_i[o + k] = keep ? a.inv[orig] : -1;
-      if (a.out_d) a.out_d[o + k] = d;
+      a.out_i[o + k * ks] = keep ? a.inv[orig] : -1;
+      if (a.out_d) a.out_d[o + k * ks] = d;
     }
   }
 }
@@ -734,9 +736,10 @@ __device__ __forceinline__ void cov_body(const CovArgs& a) {
   if (i >= a.n) return;
   double mean0 = 0, mean1 = 0, mean2 = 0;
   double c00 = 0, c10 = 0, c11 = 0, c20 = 0, c21 = 0, c22 = 0;
-  const int* nn = a.nn + (size_t)i * a.k;
+  const int* nn = a.nn_stride > 0 ? a.nn + i : a.nn + (size_t)i * a.k;
+  const size_t js = a.nn_stride > 0 ? (size_t)a.nn_stride : 1;
   for (int j = 0; j < a.k; ++j) {
-    const int g = nn[j];
+    const int g = nn[j * js];
     if (g < 0) continue;
     const float x = a.x[g], y = a.y[g], z = a.z[g];
     mean0 += (double)x; mean1 += (double)y; mean2 += (double)z;
@@ -789,7 +792,7 @@ __device__ __forceinline__ void cov_body(const CovArgs& a) {
     uint8_t* h = a.hist + (size_t)i * a.C;  // this lane owns the row
     for (int c = 0; c < a.C; ++c) h[c] = 0;
     for (int j = 0; j < a.k; ++j) {
-      const int g = nn[j];
+      const int g = nn[j * js];
       if (g < 0) continue;
       const uint32_t l = a.label[g];
       if (l >= 1u && l <= (uint32_t)a.C) h[l - 1] = (uint8_t)(h[l - 1] + 1);
@@ -1785,6 +1788,28 @@ hipError_t launch_accumulate_lm(const AccArgs& a, LmState* lm, hipStream_t st) {
   hipError_t e = launch_accumulate_only(a, nb, st);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(lm_step_kernel, dim3(1), dim3(64), 0, st, lm, a.partials, nb);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void count_active_jobs_kernel(CountJobs jobs) {
+  const CountJob& J = jobs.job[blockIdx.y];
+  const int* idx = J.idx;
+  unsigned long long cnt = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < J.n; i += gridDim.x * blockDim.x) cnt += idx[i] >= 0;
+  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
+  if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(J.out, cnt);
+}
+
+hipError_t launch_count_active_jobs(const CountJob* jobs, int n, hipStream_t st) {
+  for (int b = 0; b < n; b += kMaxSmallJobs) {
+    const int cnt = n - b < kMaxSmallJobs ? n - b : kMaxSmallJobs;
+    CountJobs J;
+    int mx = 0;
+    for (int i = 0; i < cnt; ++i) { J.job[i] = jobs[b + i]; mx = jobs[b + i].n > mx ? jobs[b + i].n : mx; }
+    if (mx <= 0) continue;
+    const int gx = (mx + 255) / 256 < 256 ? (mx + 255) / 256 : 256;
+    hipLaunchKernelGGL(count_active_jobs_kernel, dim3(gx, cnt), dim3(256), 0, st, J);
+  }
   return hipGetLastError();
 }
 

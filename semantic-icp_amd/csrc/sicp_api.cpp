@@ -84,6 +84,7 @@ struct Cloud {
   DevBuf<double> proj;  // [n][C] label distribution x confusion matrix
   bool proj_valid = false;
   DevBuf<int> nn;
+  int nn_stride = 0;  // 0: [n][k]; > 0: [k][nn_stride]
   bool feat_valid = false;
   int feat_k = 0, feat_C = 0, feat_float_products = 0;
   bool feat_hist = false;
@@ -106,6 +107,7 @@ struct JobCollector {
   std::vector<sicp::CovArgs> cov;
   std::vector<sicp::ProjArgs> proj;
   std::vector<sicp::WeightArgs> weight;
+  std::vector<sicp::CountJob> count;
 };
 
 struct sicp_context {
@@ -299,7 +301,7 @@ int prepare_cloud(sicp_context* h, Cloud& c) {
 // queries: points [q_begin, q_begin+q_count) of cloud Q (device order), optionally transformed
 // by M34; targets: segment `tseg` of cloud T.  Writes device indices of T (or -1) and distances.
 int run_nn(sicp_context* h, int K, const Cloud& Qc, int q_begin, int q_count, const double* M34, const Cloud& Tc,
-           int tseg, bool self, float gate_sq, int* out_i, float* out_d, int timer_bit, hipStream_t stream) {
+           int tseg, bool self, float gate_sq, int* out_i, float* out_d, int timer_bit, hipStream_t stream, int out_stride = 0) {
   if (q_count <= 0) return SICP_OK;
   const Cloud::SegTree& tr = Tc.trees[tseg];
   auto account = [&](double ms) {
@@ -321,6 +323,7 @@ int run_nn(sicp_context* h, int K, const Cloud& Qc, int q_begin, int q_count, co
     a.inv = Tc.inv.p;
     a.out_i = out_i; a.out_d = out_d;
     a.dbg = nullptr;
+    a.out_stride = out_stride;
     static const bool want_dbg = std::getenv("SICP_KNN_STATS") != nullptr;  // developer aid, off by default
     DevBuf<int> dbg;
     if (want_dbg) { HIPCHECK(dbg.reserve((size_t)2 * q_count)); a.dbg = dbg.p; }
@@ -427,16 +430,22 @@ int compute_features(sicp_context* h, Cloud& c, bool with_hist, hipStream_t stre
   HIPCHECK(c.nx.reserve(m)); HIPCHECK(c.ny.reserve(m)); HIPCHECK(c.nz.reserve(m));
   HIPCHECK(c.nn.reserve(m * k));
   if (with_hist) HIPCHECK(c.hist.reserve(m * P.num_classes));
+  // the packet search writes the lists rank-major ([k][n]): coalesced stores there and coalesced
+  // loads in the covariance kernel; the other engines keep [n][k]
+  static const bool no_lane_per_query = std::getenv("SICP_KNN_LANE_PER_QUERY") == nullptr && std::getenv("SICP_KNN_STATS") == nullptr;
+  const int nn_stride = (P.nn_method == 1 && no_lane_per_query) ? (int)m : 0;
   for (int s = 0; s < c.n_seg(); ++s) {
     const int o = c.seg_off[s], cnt = c.seg_off[s + 1] - o;
     SICPCHECK(run_nn(h, k, c, o, cnt, nullptr, c, s, true, std::numeric_limits<float>::infinity(), c.nn.p, nullptr,
-                     SICP_PROFILE_COV, stream));
+                     SICP_PROFILE_COV, stream, nn_stride));
   }
+  c.nn_stride = nn_stride;
   sicp::CovArgs a;
   a.n = n; a.k = k; a.C = with_hist ? P.num_classes : 0;
   a.x = c.x.p; a.y = c.y.p; a.z = c.z.p;
   a.label = c.has_label ? c.label.p : nullptr;
   a.nn = c.nn.p;
+  a.nn_stride = nn_stride;
   a.float_products = P.quirk_float_products;
   a.nx = c.nx.p; a.ny = c.ny.p; a.nz = c.nz.p;
   a.hist = with_hist ? c.hist.p : nullptr;
@@ -791,7 +800,8 @@ int flush_jobs(sicp_context* h, JobCollector& jc) {
   if (!jc.cov.empty()) HIPCHECK(sicp::launch_cov_jobs(jc.cov.data(), (int)jc.cov.size(), h->stream));
   if (!jc.proj.empty()) HIPCHECK(sicp::launch_proj_jobs(jc.proj.data(), (int)jc.proj.size(), h->stream));
   if (!jc.weight.empty()) HIPCHECK(sicp::launch_em_weight_jobs(jc.weight.data(), (int)jc.weight.size(), h->stream));
-  jc.knn.clear(); jc.cov.clear(); jc.proj.clear(); jc.weight.clear();
+  if (!jc.count.empty()) HIPCHECK(sicp::launch_count_active_jobs(jc.count.data(), (int)jc.count.size(), h->stream));
+  jc.knn.clear(); jc.cov.clear(); jc.proj.clear(); jc.weight.clear(); jc.count.clear();
   return SICP_OK;
 }
 
@@ -880,6 +890,10 @@ int run_solve_batch(sicp_context* h, sicp_handle* hs, int n, const char* active,
 
 // statistics only: add the number of live slots of the current search to the device counter
 int count_active(sicp_context* h) {
+  if (h->collect) {
+    h->collect->count.push_back(sicp::CountJob{h->idx.p, h->corr_n * h->corr_K, (unsigned long long*)h->d_count.p});
+    return SICP_OK;
+  }
   HIPCHECK(sicp::launch_count_active(h->idx.p, h->corr_n * h->corr_K, (unsigned long long*)h->d_count.p, h->stream));
   return SICP_OK;
 }
@@ -1167,6 +1181,7 @@ int sicp_align_batch(sicp_handle* hs, int32_t n, const double* init_qt, double* 
       if (stats) SICPCHECK(count_active(h));
       outer_finish(P, o[p]);
     }
+    if (one_launch) SICPCHECK(flush_jobs(L, jc));  // the counts: before the next searches overwrite idx
   }
   for (int p = 0; p < n; ++p) {
     std::memcpy(out_qt + 7 * p, o[p].cur, sizeof o[p].cur);
@@ -1281,7 +1296,7 @@ int sicp_covariances(sicp_handle h, int which, double* cov9, double* normal3, ui
     if (hist) std::memcpy(hist + (size_t)i * P.num_classes, hh.data() + (size_t)d * P.num_classes, P.num_classes);
     if (nn_idx)
       for (int j = 0; j < k; ++j) {
-        const int g = nn[(size_t)d * k + j];
+        const int g = c.nn_stride > 0 ? nn[(size_t)j * c.nn_stride + d] : nn[(size_t)d * k + j];
         nn_idx[(size_t)i * k + j] = g < 0 ? -1 : c.caller_index(g);
       }
   }
