@@ -1360,7 +1360,8 @@ __global__ __launch_bounds__(BS) void accumulate_chain_kernel(AccArgs a) {
 // decomposition and therefore the bits are those of accumulate_kernel.
 template <int K, int BS, int PF>
 __global__ __launch_bounds__(BS) void accumulate_batch_kernel(const BatchArgs* __restrict__ batch) {
-  __shared__ double red[28][BS];
+  constexpr int RED_ROWS = 14;
+  __shared__ double red[RED_ROWS][BS];
   const BatchArgs& B = batch[blockIdx.y];
   const int nb = B.nb, block = (int)blockIdx.x;
   if (block >= nb) return;
@@ -1376,18 +1377,24 @@ __global__ __launch_bounds__(BS) void accumulate_batch_kernel(const BatchArgs* _
   pose_to_sgprs(P);
   double acc[28];
   accumulate_groups<K, BS, PF>(a, P, block, nb, acc);
-#pragma unroll
-  for (int k = 0; k < 28; ++k) red[k][threadIdx.x] = acc[k];
-  __syncthreads();
+  // the same transpose reduction as accumulate_kernel, RED_ROWS rows at a time (same additions in
+  // the same order, so the same bits): 28 rows at once are 56 KB of LDS, i.e. two workgroups per CU
   constexpr int NW = BS / 64;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   SICP_GLOBAL double* partials = (SICP_GLOBAL double*)a.partials;
-  for (int k = wave; k < 28; k += NW) {
-    double sum = 0.0;
 #pragma unroll
-    for (int t = 0; t < NW; ++t) sum += red[k][lane + 64 * t];
-    sum = wave_sum(sum);
-    if (lane == 0) partials[(size_t)k * nb + block] = sum;
+  for (int p0 = 0; p0 < 28; p0 += RED_ROWS) {
+    if (p0) __syncthreads();
+#pragma unroll
+    for (int k = 0; k < RED_ROWS; ++k) red[k][threadIdx.x] = acc[p0 + k];
+    __syncthreads();
+    for (int kk = wave; kk < RED_ROWS; kk += NW) {
+      double sum = 0.0;
+#pragma unroll
+      for (int t = 0; t < NW; ++t) sum += red[kk][lane + 64 * t];
+      sum = wave_sum(sum);
+      if (lane == 0) partials[(size_t)(p0 + kk) * nb + block] = sum;
+    }
   }
 }
 
