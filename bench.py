@@ -36,7 +36,9 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-PMC_TRAFFIC_BYTES = {}  # (points, pairs per launch) -> FETCH_SIZE + WRITE_SIZE bytes per launch, from profiles/
+# (points, pairs per launch) -> FETCH_SIZE + WRITE_SIZE bytes per accumulate_batch launch, raw counter values from
+# profiles/r01_final_pmc_hbm_traffic.csv (117805.8 KB + 2773.6 KB)
+PMC_TRAFFIC_BYTES = {(100_000, 16): (117805.8 + 2773.6) * 1024}
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 VALU_PAIR_PEAK = 9.8e12        # 78.6e12 FP32 lane-ops/s / 8 lane-ops per pair
 N_POINTS = 100_000
@@ -308,9 +310,9 @@ def main():
                 "traffic": PMC_TRAFFIC_BYTES.get((n, S)),
                 "avg_launch_us": acc_us, "launches_timed": n_acc, "algorithmic_bytes_per_launch": acc_bytes,
                 "pairs_per_launch": S,
-                "note": "FP64-issue bound (~300 FP64 instructions per correspondence incl. log, sqrt, 3 divisions): "
-                        f"{S} pairs x 400K correspondences x 300 / (1024 SIMDs x 16 lanes x 2.4 GHz) = "
-                        f"{S * 4e5 * 300 / (1024 * 16 * 2.4e9) * 1e6:.0f} us of pure issue; see DESIGN.md section 3",
+                "note": "two floors of similar size: HBM (what the launch really moves, f64 normals and weights included: ~12 MB per pair "
+                        f"-> {S * 12e6 / 6.3e12 * 1e6:.0f} us at the 6.3 TB/s achievable) and FP64 issue (~170 instructions per correspondence "
+                        f"-> {S * 4e5 * 170 / (1024 * 16 * 2.4e9) * 1e6:.0f} us); two waves per SIMD (180 VGPRs) hide latency poorly; DESIGN.md section 3",
             }
             avg_ms = nn_ms / nn_launches
             alg_bytes = 12 * n + 12 * n + 8 * K_CORR * n     # src+tgt xyz once, idx+dist^2 out
