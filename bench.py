@@ -253,7 +253,7 @@ def main():
             "data": "dry-run" if args.dry_run else "synthetic",
             "config": {
                 "workload": f"EM-ICP align() on a synthetic KITTI-like scan pair, {n}x{n} points, K={K_CORR}, C={N_CLASSES} "
-                            "(metric point of BASELINE configs[1]); one independent pair per GPU",
+                            "(metric point of BASELINE configs[1]); every pair of a GPU's batch is its own registration",
                 "points": n, "K": K_CORR, "classes": N_CLASSES, "parallelism": f"pairs-sharded x{dist.world}",
                 "pairs_in_flight_per_gpu": max(1, args.pairs_in_flight),
                 "concurrency": args.concurrency,

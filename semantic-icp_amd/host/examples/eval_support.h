@@ -114,6 +114,92 @@ class KittiMetrics {
   std::ostream* out_;
 };
 
+// exec/nyu_metrics.h:8-113: label agreement between a registered source cloud and the target.
+// For every source point the nearest target point (any label) is looked up; pairs closer than
+// sqrt(25) (strict <, float compare) are tallied.  The reference searches a pcl::KdTreeFLANN on the
+// host; here the lookup is one K = 1 correspondence search of the engine at the identity (the
+// source passed in is already transformed, as in the reference).
+class NYUMetrics {
+ public:
+  typedef pcl::PointXYZL PointT;
+  typedef pcl::PointCloud<PointT> PointCloud;
+  typedef PointCloud::Ptr PointCloudPtr;
+
+  NYUMetrics(const std::string& testFileName, std::string outName, size_t countStart = 0, size_t numClasses = 895)
+      : numClasses_(numClasses), count_(countStart), outName_(std::move(outName)) {
+    for (const auto& row : read_rows(testFileName)) {  // exec/nyu_metrics.h:25-31 (CSVIterator splits on ' ')
+      std::vector<size_t> data;
+      for (const std::string& cell : row) data.push_back((size_t)std::stoi(cell));
+      testPairs_.push_back(data);
+    }
+    confusion_.assign(numClasses_ * numClasses_, 0);
+    it_ = std::min(countStart, testPairs_.size());
+  }
+
+  double evaluate(PointCloudPtr source, PointCloudPtr target, const std::string& label) {
+    const int num = std::stoi(label);
+    std::ostringstream oss;
+    oss << "Label" << num << "-";
+    count_++;
+    std::ofstream out(dir_of(outName_) + oss.str() + base_of(outName_));
+    const int ns = (int)source->size(), nt = (int)target->size();
+    std::vector<int32_t> idx(ns > 0 ? ns : 1);
+    std::vector<float> d2(ns > 0 ? ns : 1);
+    {
+      sicp_handle h = engine_.get();
+      sicp_params p;
+      semanticicp::detail::check(sicp_default_params(SICP_MODE_GICP, &p), h, "sicp_default_params");
+      p.knn = 1;
+      p.gate_sq = 25.0;  // nyu_metrics.h:57
+      semanticicp::detail::check(sicp_set_params(h, &p), h, "sicp_set_params");
+      semanticicp::detail::FlatCloud s = semanticicp::detail::flatten(*source), t = semanticicp::detail::flatten(*target);
+      semanticicp::detail::check(sicp_set_cloud(h, SICP_SOURCE, ns, s.x.data(), s.y.data(), s.z.data(), nullptr), h, "sicp_set_cloud");
+      semanticicp::detail::check(sicp_set_cloud(h, SICP_TARGET, nt, t.x.data(), t.y.data(), t.z.data(), nullptr), h, "sicp_set_cloud");
+      const double ident[7] = {0, 0, 0, 1, 0, 0, 0};
+      semanticicp::detail::check(sicp_correspondences(h, ident, idx.data(), d2.data(), nullptr), h, "sicp_correspondences");
+    }
+    double inlier = 0, total = 0, dist = 0;
+    for (int i = 0; i < ns; ++i) {
+      if (idx[i] < 0) continue;  // gated out: nn_dist_sq >= 25
+      const uint32_t labelSource = (*source)[i].label, labelTarget = (*target)[idx[i]].label;
+      if (labelSource < numClasses_ && labelTarget < numClasses_) confusion_[labelSource * numClasses_ + labelTarget]++;
+      out << labelSource << ", " << labelTarget << std::endl;
+      total++;
+      dist += std::sqrt(d2[i]);
+      if (labelSource == labelTarget) inlier++;
+    }
+    out.close();
+    std::ofstream matrixOut(dir_of(outName_) + "Matrix" + base_of(outName_));  // Eigen's operator<<: rows, space separated
+    for (size_t r = 0; r < numClasses_; ++r) {
+      for (size_t c = 0; c < numClasses_; ++c) matrixOut << (c ? " " : "") << confusion_[r * numClasses_ + c];
+      matrixOut << "\n";
+    }
+    matrixOut.close();
+    std::ofstream sumOut(outName_, std::ios_base::app | std::ios_base::out);
+    sumOut << num << ", " << inlier / total << ", " << dist / total << ", " << total << std::endl;
+    return inlier / total;
+  }
+
+  std::vector<size_t> getPairs() {
+    std::vector<size_t> out;
+    if (it_ < testPairs_.size()) out = testPairs_[it_++];
+    return out;
+  }
+  bool morePairs() const { return it_ < testPairs_.size(); }
+  const std::vector<int>& getConfusionMatrix() const { return confusion_; }
+
+ private:
+  static std::string dir_of(const std::string& p) { const size_t k = p.find_last_of('/'); return k == std::string::npos ? "" : p.substr(0, k + 1); }
+  static std::string base_of(const std::string& p) { const size_t k = p.find_last_of('/'); return k == std::string::npos ? p : p.substr(k + 1); }
+  std::vector<std::vector<size_t>> testPairs_;
+  size_t it_ = 0;
+  std::vector<int> confusion_;
+  size_t numClasses_;
+  size_t count_;
+  std::string outName_;
+  semanticicp::detail::Engine engine_;
+};
+
 inline const char* arg(int argc, char** argv, const char* flag) {
   for (int i = 1; i + 1 < argc; ++i)
     if (!std::strcmp(argv[i], flag)) return argv[i + 1];

@@ -218,3 +218,69 @@ def test_scenenet_eval_headless_rows_and_fused_labels(tmp_path):
                 assert np.allclose(fp, ps, atol=1e-5)
                 olab = O.fused_labels(p, ps, ls, pt, lt, cm, oq)
                 assert np.mean(fl == olab) > 0.999
+
+
+# ------------------------------------------------------------------------------------------------
+# f2: headless nyu_eval (exec/nyu_eval.cc:45-222 + exec/nyu_metrics.h)
+# ------------------------------------------------------------------------------------------------
+def test_nyu_eval_compiles_and_fails_loudly_without_gpu(tmp_path):
+    if os.path.exists("/dev/kfd"):
+        pytest.skip("a GPU is present")
+    exe = build_example(tmp_path, "nyu_eval_headless")
+    frames, poses, cm = synth.rgbd_sequence(seed=6, n_frames=2, stride=16)
+    d = tmp_path / "seq"
+    d.mkdir()
+    for k, (p, l) in enumerate(frames):
+        write_pcd(str(d / f"{k:04d}.pcd"), p, l)
+    (tmp_path / "pairs.txt").write_text("0 1\n")
+    r = subprocess.run([exe, "-s", str(d), "-t", str(tmp_path / "pairs.txt"), "-o", str(tmp_path / "o_")], capture_output=True, text=True)
+    assert r.returncode == 2 and "no usable HIP device" in r.stderr
+
+
+@pytest.mark.gpu
+def test_nyu_eval_headless_poses_and_label_agreement(tmp_path):
+    from scipy.spatial import cKDTree
+
+    exe = build_example(tmp_path, "nyu_eval_headless")
+    frames, poses, cm = synth.rgbd_sequence(seed=6, n_frames=3, stride=4)
+    d = tmp_path / "seq"
+    d.mkdir()
+    for k, (p, l) in enumerate(frames):
+        write_pcd(str(d / f"{k:04d}.pcd"), p, l, binary=True)
+    (tmp_path / "pairs.txt").write_text("1 0\n2 1 0\n")  # rows of indices; consecutive entries are (source, target)
+    prefix = str(tmp_path / "o_")
+    r = subprocess.run([exe, "-s", str(d), "-t", str(tmp_path / "pairs.txt"), "-o", prefix, "-c", "16"], capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr
+    lines = [l.split() for l in r.stdout.splitlines() if l.startswith("pair ")]
+    assert [(l[1], l[2]) for l in lines] == [("1->0", "SICP"), ("1->0", "se3GICP"), ("2->1", "SICP"), ("2->1", "se3GICP"),
+                                             ("1->0", "SICP"), ("1->0", "se3GICP")]
+    ident = np.array([0, 0, 0, 1, 0, 0, 0.0])
+    summary = {name: [[float(v) for v in row.split(",")] for row in open(prefix + name) if row.strip()]
+               for name in ("SICPnyu.csv", "se3GICPnyu.csv")}
+    counters = {"SICP": 0, "se3GICP": 0}
+    for l in lines:
+        s_i, t_i = (int(v) for v in l[1].split("->"))
+        which = l[2]
+        qt = np.array([float(v) for v in l[4:11]])
+        (ps, ls), (pt, lt) = frames[s_i], frames[t_i]
+        p = O.default_params(O.MODE_SEMANTIC)
+        zero = np.zeros(len(ps), np.uint32), np.zeros(len(pt), np.uint32)
+        oq, _ = O.align(p, ps, ls if which == "SICP" else zero[0], pt, lt if which == "SICP" else zero[1], None, ident)
+        D = np.linalg.inv(O.se3_matrix(oq)) @ O.se3_matrix(qt)
+        assert np.linalg.norm(Rotation.from_matrix(D[:3, :3]).as_rotvec()) < 1e-4 and np.linalg.norm(D[:3, 3]) < 1e-3
+        # the metric (exec/nyu_metrics.h:36-84) recomputed from the driver's pose
+        M = O.se3_matrix(qt).astype(np.float32)
+        moved = (ps @ M[:3, :3].T + M[:3, 3]).astype(np.float32)
+        dist, nn = cKDTree(pt).query(moved)
+        keep = dist.astype(np.float32) ** 2 < 25.0
+        ratio, mean_d, total = np.mean(ls[keep] == lt[nn[keep]]), dist[keep].mean(), keep.sum()
+        row = summary[which + "nyu.csv"][counters[which]]
+        counters[which] += 1
+        assert int(row[0]) == s_i and abs(row[3] - total) <= 2
+        assert abs(row[1] - ratio) < 2e-3 and abs(row[2] - mean_d) < 1e-4 and abs(float(l[12]) - row[1]) < 1e-5
+    # per-pair label files and the accumulated confusion matrix
+    lab = np.loadtxt(f"{tmp_path}/Label1-o_SICPnyu.csv", delimiter=",")
+    assert lab.shape[1] == 2 and len(lab) == int(summary["SICPnyu.csv"][-1][3])
+    mat = np.loadtxt(f"{tmp_path}/Matrixo_SICPnyu.csv")
+    assert mat.shape == (16, 16) and mat.sum() == sum(r_[3] for r_ in summary["SICPnyu.csv"])
