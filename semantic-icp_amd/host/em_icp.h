@@ -72,6 +72,33 @@ class EmIterativeClosestPoint {
   Sophus::SE3d getFinalTransFormation() { return final_transformation_; }
   int getOuterIter() { return outer_iter; }
 
+  // Engine extension (no reference counterpart): align() of several objects -- one per scan pair,
+  // clouds and confusion matrices already set -- advanced in lock step by sicp_align_batch.  Every
+  // object ends up exactly as if its own align() had been called.  finalClouds may hold nullptrs.
+  static void alignBatch(const std::vector<EmIterativeClosestPoint*>& objs, const std::vector<PointCloudPtr>& finalClouds,
+                         const std::vector<Sophus::SE3d>& initTransforms) {
+    const size_t n = objs.size();
+    if (n == 0) return;
+    if (finalClouds.size() != n || initTransforms.size() != n) throw std::runtime_error("alignBatch: argument sizes differ");
+    std::vector<sicp_handle> hs(n);
+    std::vector<double> init(7 * n), out(7 * n);
+    std::vector<int32_t> iters(n, 0);
+    for (size_t p = 0; p < n; ++p) {
+      hs[p] = objs[p]->engine_.get();
+      objs[p]->configure(hs[p]);
+      for (int i = 0; i < 7; ++i) init[7 * p + i] = initTransforms[p].data()[i];
+    }
+    detail::check(sicp_align_batch(hs.data(), (int32_t)n, init.data(), out.data(), iters.data(), nullptr), hs[0], "sicp_align_batch");
+    for (size_t p = 0; p < n; ++p) {
+      objs[p]->final_transformation_ = detail::to_se3(&out[7 * p]);
+      objs[p]->outer_iter = iters[p];
+      if (finalClouds[p] != nullptr) {
+        Eigen::Matrix4f mat = (objs[p]->final_transformation_.matrix()).template cast<float>();
+        pcl::transformPointCloud(*objs[p]->source_cloud_, *finalClouds[p], mat);
+      }
+    }
+  }
+
  protected:
   void configure(sicp_handle h) {
     sicp_params p;

@@ -6,11 +6,17 @@
 // Not reproduced: the pcl::GeneralizedIterativeClosestPoint comparison (third-party algorithm), the
 // disabled FPFH bootstrap, and quirk Q7 (the reference hands SE3-GICP the kd-tree of another scan,
 // exec/kitti_eval.cc:213; here every align() sees its own clouds).
+// -b <pairs>: register that many pairs at a time in lock step (alignBatch, sicp_align_batch) instead
+// of one after the other; the rows are the same, the run is several times faster.
 #include <chrono>
 #include <cstdio>
 #include <fstream>
+#include <algorithm>
+#include <cstdlib>
 #include <iostream>
+#include <memory>
 #include <string>
+#include <vector>
 
 #include <em_icp.h>
 #include <gicp.h>
@@ -20,6 +26,8 @@
 int main(int argc, char** argv) {
   using namespace evalsupport;
   const char *dir = arg(argc, argv, "-s"), *gt = arg(argc, argv, "-t"), *cmf = arg(argc, argv, "-m"), *prefix = arg(argc, argv, "-o");
+  const char* barg = arg(argc, argv, "-b");
+  const size_t batch = barg ? (size_t)std::max(1, std::atoi(barg)) : 1;
   if (!dir) { std::cout << "Need source directory (-s)\n"; return -1; }
   if (!gt) { std::cout << "Need ground truth file (-t)\n"; return -1; }
   if (!cmf) { std::cout << "Need ground confusion matrix file (-m)\n"; return -1; }
@@ -29,40 +37,61 @@ int main(int argc, char** argv) {
   std::ofstream foutSICP(pre + "EMICPkitti.csv"), foutse3GICP(pre + "se3GICPkitti.csv");
   const std::string gtFile = gt;
   KittiMetrics semanticICPMetrics(gtFile, &foutSICP), se3GICPMetrics(gtFile, &foutse3GICP);
+  typedef semanticicp::EmIterativeClosestPoint<11> Em;
+  typedef semanticicp::GICP<pcl::PointXYZ> Gicp;
   try {
-    // one engine per method for the whole run: device buffers and the captured solver graph are reused
-    semanticicp::EmIterativeClosestPoint<11> emicp;
-    semanticicp::GICP<pcl::PointXYZ> gicpse3;
-    emicp.setConfusionMatrix(cm);
-    for (size_t n = 0; n + 3 < pcd_fns.size(); n += 3) {  // exec/kitti_eval.cc:124-129
-      const size_t indxTarget = n, indxSource = n + 3;
-      pcl::PointCloud<pcl::PointXYZL>::Ptr cloudA(new pcl::PointCloud<pcl::PointXYZL>), cloudB(new pcl::PointCloud<pcl::PointXYZL>);
-      if (pcl::io::loadPCDFile<pcl::PointXYZL>(pcd_fns[indxSource], *cloudA) == -1) { std::cerr << "Couldn't read source file\n"; return -1; }
-      if (pcl::io::loadPCDFile<pcl::PointXYZL>(pcd_fns[indxTarget], *cloudB) == -1) { std::cerr << "Couldn't read target file\n"; return -1; }
-      filterRange(cloudA, 40.0);  // :138
-      filterRange(cloudB, 40.0);  // :159
-      Sophus::SE3d initTransform;  // identity (:172-176)
-
-      pcl::PointCloud<pcl::PointXYZL>::Ptr finalCloudem(new pcl::PointCloud<pcl::PointXYZL>);
+    // one engine per method and batch slot for the whole run: device buffers and the captured solver
+    // graphs are reused
+    std::vector<std::unique_ptr<Em>> em(batch);
+    std::vector<std::unique_ptr<Gicp>> gi(batch);
+    for (size_t b = 0; b < batch; ++b) {
+      em[b].reset(new Em());
+      gi[b].reset(new Gicp());
+      em[b]->setConfusionMatrix(cm);
+    }
+    std::vector<size_t> starts;
+    for (size_t n = 0; n + 3 < pcd_fns.size(); n += 3) starts.push_back(n);  // exec/kitti_eval.cc:124-129
+    for (size_t g0 = 0; g0 < starts.size(); g0 += batch) {
+      const size_t cnt = std::min(batch, starts.size() - g0);
+      std::vector<Em*> eo(cnt);
+      std::vector<Gicp*> go(cnt);
+      std::vector<pcl::PointCloud<pcl::PointXYZL>::Ptr> finalEm(cnt);
+      std::vector<pcl::PointCloud<pcl::PointXYZ>::Ptr> finalGi(cnt);
+      std::vector<Sophus::SE3d> inits(cnt);  // identity (:172-176)
+      for (size_t b = 0; b < cnt; ++b) {
+        const size_t indxTarget = starts[g0 + b], indxSource = indxTarget + 3;
+        pcl::PointCloud<pcl::PointXYZL>::Ptr cloudA(new pcl::PointCloud<pcl::PointXYZL>), cloudB(new pcl::PointCloud<pcl::PointXYZL>);
+        if (pcl::io::loadPCDFile<pcl::PointXYZL>(pcd_fns[indxSource], *cloudA) == -1) { std::cerr << "Couldn't read source file\n"; return -1; }
+        if (pcl::io::loadPCDFile<pcl::PointXYZL>(pcd_fns[indxTarget], *cloudB) == -1) { std::cerr << "Couldn't read target file\n"; return -1; }
+        filterRange(cloudA, 40.0);  // :138
+        filterRange(cloudB, 40.0);  // :159
+        eo[b] = em[b].get();
+        eo[b]->setSourceCloud(cloudA);
+        eo[b]->setTargetCloud(cloudB);
+        finalEm[b].reset(new pcl::PointCloud<pcl::PointXYZL>);
+        // the reference re-loads the files as PointXYZ (:201-204): same points, no labels, no range filter
+        pcl::PointCloud<pcl::PointXYZ>::Ptr cloudAnoL(new pcl::PointCloud<pcl::PointXYZ>), cloudBnoL(new pcl::PointCloud<pcl::PointXYZ>);
+        pcl::io::loadPCDFile<pcl::PointXYZ>(pcd_fns[indxSource], *cloudAnoL);
+        pcl::io::loadPCDFile<pcl::PointXYZ>(pcd_fns[indxTarget], *cloudBnoL);
+        go[b] = gi[b].get();
+        go[b]->setSourceCloud(cloudAnoL);
+        go[b]->setTargetCloud(cloudBnoL);
+        finalGi[b].reset(new pcl::PointCloud<pcl::PointXYZ>);
+      }
       auto begin = std::chrono::steady_clock::now();
-      emicp.setSourceCloud(cloudA);
-      emicp.setTargetCloud(cloudB);
-      emicp.align(finalCloudem, initTransform);
-      double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - begin).count();
-      const double e1 = semanticICPMetrics.evaluate(emicp.getFinalTransFormation(), indxTarget, indxSource, secs, emicp.getOuterIter());
-
-      // the reference re-loads the files as PointXYZ (:201-204): same points, no labels, no range filter
-      pcl::PointCloud<pcl::PointXYZ>::Ptr cloudAnoL(new pcl::PointCloud<pcl::PointXYZ>), cloudBnoL(new pcl::PointCloud<pcl::PointXYZ>);
-      pcl::io::loadPCDFile<pcl::PointXYZ>(pcd_fns[indxSource], *cloudAnoL);
-      pcl::io::loadPCDFile<pcl::PointXYZ>(pcd_fns[indxTarget], *cloudBnoL);
-      pcl::PointCloud<pcl::PointXYZ>::Ptr finalCloudse3(new pcl::PointCloud<pcl::PointXYZ>);
+      if (batch == 1) eo[0]->align(finalEm[0], inits[0]);
+      else Em::alignBatch(eo, finalEm, inits);
+      const double secsEm = std::chrono::duration<double>(std::chrono::steady_clock::now() - begin).count() / double(cnt);
       begin = std::chrono::steady_clock::now();
-      gicpse3.setSourceCloud(cloudAnoL);
-      gicpse3.setTargetCloud(cloudBnoL);
-      gicpse3.align(finalCloudse3);
-      secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - begin).count();
-      const double e2 = se3GICPMetrics.evaluate(gicpse3.getFinalTransFormation(), indxTarget, indxSource, secs, gicpse3.getOuterIter());
-      std::printf("pair %zu<-%zu  SICP MSE %.3e  se3GICP MSE %.3e\n", indxTarget, indxSource, e1, e2);
+      if (batch == 1) go[0]->align(finalGi[0]);
+      else Gicp::alignBatch(go, finalGi, inits);
+      const double secsGi = std::chrono::duration<double>(std::chrono::steady_clock::now() - begin).count() / double(cnt);
+      for (size_t b = 0; b < cnt; ++b) {
+        const size_t indxTarget = starts[g0 + b], indxSource = indxTarget + 3;
+        const double e1 = semanticICPMetrics.evaluate(eo[b]->getFinalTransFormation(), indxTarget, indxSource, secsEm, eo[b]->getOuterIter());
+        const double e2 = se3GICPMetrics.evaluate(go[b]->getFinalTransFormation(), indxTarget, indxSource, secsGi, go[b]->getOuterIter());
+        std::printf("pair %zu<-%zu  SICP MSE %.3e  se3GICP MSE %.3e\n", indxTarget, indxSource, e1, e2);
+      }
     }
   } catch (const std::exception& e) {
     std::cerr << "error: " << e.what() << "\n";

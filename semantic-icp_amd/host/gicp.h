@@ -83,6 +83,46 @@ class GICP {
   Sophus::SE3d getFinalTransFormation() { return finalTransformation_; }
   int getOuterIter() { return outer_iter; }
 
+  // Engine extension (no reference counterpart): align() of several objects, one per scan pair with
+  // its clouds set, advanced in lock step by sicp_align_batch; every object ends up as after its own
+  // align().  finalClouds may hold nullptrs.
+  static void alignBatch(const std::vector<GICP*>& objs, const std::vector<PointCloudPtr>& finalClouds,
+                         const std::vector<Sophus::SE3d>& initTransforms) {
+    const size_t n = objs.size();
+    if (n == 0) return;
+    if (finalClouds.size() != n || initTransforms.size() != n) throw std::runtime_error("alignBatch: argument sizes differ");
+    std::vector<sicp_handle> hs(n);
+    std::vector<double> init(7 * n), out(7 * n);
+    std::vector<int32_t> iters(n, 0);
+    std::vector<int> ns(n), nt(n);
+    for (size_t q = 0; q < n; ++q) {
+      GICP& o = *objs[q];
+      sicp_handle h = hs[q] = o.engine_.get();
+      sicp_params p;
+      detail::check(sicp_default_params(SICP_MODE_GICP, &p), h, "sicp_default_params");
+      p.k_cov = o.kCorrespondences_;
+      p.epsilon = o.epsilon_;
+      detail::check(sicp_set_params(h, &p), h, "sicp_set_params");
+      detail::FlatCloud s = detail::flatten(*o.sourceCloud_), t = detail::flatten(*o.targetCloud_);
+      ns[q] = s.size(); nt[q] = t.size();
+      detail::check(sicp_set_cloud(h, SICP_SOURCE, s.size(), s.x.data(), s.y.data(), s.z.data(), nullptr), h, "sicp_set_cloud");
+      detail::check(sicp_set_cloud(h, SICP_TARGET, t.size(), t.x.data(), t.y.data(), t.z.data(), nullptr), h, "sicp_set_cloud");
+      for (int i = 0; i < 7; ++i) init[7 * q + i] = initTransforms[q].data()[i];
+    }
+    detail::check(sicp_align_batch(hs.data(), (int32_t)n, init.data(), out.data(), iters.data(), nullptr), hs[0], "sicp_align_batch");
+    for (size_t q = 0; q < n; ++q) {
+      GICP& o = *objs[q];
+      o.finalTransformation_ = detail::to_se3(&out[7 * q]);
+      o.outer_iter = iters[q];
+      o.fill_covariances(hs[q], SICP_SOURCE, ns[q], o.sourceCovariances_);
+      o.fill_covariances(hs[q], SICP_TARGET, nt[q], o.targetCovariances_);
+      if (finalClouds[q] != nullptr) {
+        Eigen::Matrix4f mat = (o.finalTransformation_.matrix()).template cast<float>();
+        pcl::transformPointCloud(*o.sourceCloud_, *finalClouds[q], mat);
+      }
+    }
+  }
+
  protected:
   void fill_covariances(sicp_handle h, int which, int n, MatricesVectorPtr& out) {
     if (!out) out = MatricesVectorPtr(new MatricesVector());

@@ -166,6 +166,16 @@ def test_kitti_eval_headless_rows_match_oracle(tmp_path):
             D = np.linalg.inv(O.se3_matrix(oq)) @ T_est
             assert np.linalg.norm(Rotation.from_matrix(D[:3, :3]).as_rotvec()) < 1e-7 and np.linalg.norm(D[:3, 3]) < 1e-7
             assert int(row[38]) == ost["outer_iters"]
+    # -b 2: the same pairs registered two at a time in lock step (alignBatch / sicp_align_batch)
+    prefix2 = str(tmp_path / "batch_")
+    r2 = subprocess.run([exe, "-s", d, "-t", gt, "-m", cmf, "-o", prefix2, "-b", "2"], capture_output=True, text=True, timeout=900)
+    assert r2.returncode == 0, r2.stderr
+    for fname in ("EMICPkitti.csv", "se3GICPkitti.csv"):
+        one = [line.split(",") for line in open(prefix + fname) if line.strip()]
+        two = [line.split(",") for line in open(prefix2 + fname) if line.strip()]
+        assert len(one) == len(two)
+        for ra, rb in zip(one, two):  # every column but the wall time (5) is identical text
+            assert ra[:5] == rb[:5] and ra[6:] == rb[6:]
 
 
 # ------------------------------------------------------------------------------------------------
