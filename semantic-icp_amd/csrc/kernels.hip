@@ -1445,9 +1445,9 @@ __global__ __launch_bounds__(64) void lm_step_kernel(LmState* lm, const double* 
   double o[28];
   reduce_partials(partials, n_blocks, lane, o);
   if (lane == 0) {
-    LmState st = *lm;
-    lm_feed(st, o);
-    *lm = st;
+    LmCore st = *lm;  // the options stay in memory: uniform, read with scalar loads
+    lm_feed(st, lm->opt, o);
+    *static_cast<LmCore*>(lm) = st;
   }
 }
 
@@ -1460,9 +1460,9 @@ __global__ __launch_bounds__(64) void lm_step_batch_kernel(const BatchArgs* __re
   double o[28];
   reduce_partials(B.a.partials, B.nb, lane, o);
   if (lane == 0) {
-    LmState st = *lm;
-    lm_feed(st, o);
-    *lm = st;
+    LmCore st = *lm;
+    lm_feed(st, lm->opt, o);
+    *static_cast<LmCore*>(lm) = st;
   }
 }
 

@@ -53,8 +53,8 @@ struct LmOptions {
 
 enum { LM_RUNNING = -1, LM_CONVERGED = 0, LM_ITERATION_CAP = 1, LM_INVALID_STEPS = 2, LM_EVAL_FAILED = 3 };
 
-struct LmState {
-  LmOptions opt;
+// the part of the state that changes (what the GPU step keeps in registers) ...
+struct LmCore {
   double pose[7];  // the point whose evaluation lm_feed expects next
   double x[7];     // last accepted iterate (the answer when status != LM_RUNNING)
   double H[36], g[6], cost, x_norm;
@@ -67,12 +67,20 @@ struct LmState {
   int pad_;
 };
 
+// ... and the whole state: the options stay in memory (uniform: scalar loads on the GPU)
+struct LmState : LmCore {
+  LmOptions opt;
+};
+
 namespace detail {
 
 // Solves A y = b by Cholesky, IN PLACE: only the lower triangle of A is read, and it is overwritten
 // by L (so the caller's 6x6 costs 21 live values, not 36 + 36: on the GPU this routine runs in one
-// lane and its register footprint sets the allocation of the whole kernel).
+// lane and its register footprint sets the allocation of the whole kernel).  The six reciprocals
+// of the diagonal are formed once and multiplied (6 divisions instead of 27: a correctly rounded
+// FP64 division is a 14-instruction sequence, and this lane runs alone).
 SICP_HD inline bool chol6_solve(double* A, const double* b, double* y) {
+  double inv[6];
   SICP_UNROLL
   for (int i = 0; i < 6; ++i)
     SICP_UNROLL
@@ -83,8 +91,9 @@ SICP_HD inline bool chol6_solve(double* A, const double* b, double* y) {
       if (i == j) {
         if (!(s > 0)) return false;
         A[6 * i + i] = sqrt(s);
+        inv[i] = 1.0 / A[6 * i + i];
       } else {
-        A[6 * i + j] = s / A[6 * j + j];
+        A[6 * i + j] = s * inv[j];
       }
     }
   double z[6];
@@ -93,14 +102,14 @@ SICP_HD inline bool chol6_solve(double* A, const double* b, double* y) {
     double s = b[i];
     SICP_UNROLL
     for (int k = 0; k < i; ++k) s -= A[6 * i + k] * z[k];
-    z[i] = s / A[6 * i + i];
+    z[i] = s * inv[i];
   }
   SICP_UNROLL
   for (int i = 5; i >= 0; --i) {
     double s = z[i];
     SICP_UNROLL
     for (int k = i + 1; k < 6; ++k) s -= A[6 * k + i] * y[k];
-    y[i] = s / A[6 * i + i];
+    y[i] = s * inv[i];
   }
   return true;
 }
@@ -131,8 +140,7 @@ SICP_HD inline double gradient_max_norm(const double* x, const double* g) {
 // candidate in s.pose.  The retry loop (an invalid step halves the radius and tries again without a
 // new evaluation) only contains the 6x6 solve: x and g do not change inside it, so the gradient
 // test is done once, before it -- same decisions in the same order as testing it every time.
-SICP_HD inline void lm_propose(LmState& s) {
-  const LmOptions& opt = s.opt;
+SICP_HD inline void lm_propose(LmCore& s, const LmOptions& opt) {
   if (s.iterations >= opt.max_iterations) { s.status = LM_ITERATION_CAP; return; }
   if (gradient_max_norm(s.x, s.g) <= opt.gradient_tolerance) { s.status = LM_CONVERGED; return; }
   double step[6], model_change;
@@ -211,10 +219,9 @@ SICP_HD inline void lm_init(LmState& s, const LmOptions& opt, const double* x0) 
 }
 
 // out28 = [H upper 21 | g 6 | cost] evaluated at s.pose
-SICP_HD inline void lm_feed(LmState& s, const double* o) {
+SICP_HD inline void lm_feed(LmCore& s, const LmOptions& opt, const double* o) {
   using namespace detail;
   if (s.status != LM_RUNNING) return;
-  const LmOptions& opt = s.opt;
   s.evaluations++;
   if (s.phase == 0) {
     unpack28(o, s.H, s.g, &s.cost);
@@ -245,8 +252,10 @@ SICP_HD inline void lm_feed(LmState& s, const double* o) {
       s.reuse_diagonal = 1;
     }
   }
-  lm_propose(s);
+  lm_propose(s, opt);
 }
+
+SICP_HD inline void lm_feed(LmState& s, const double* o) { lm_feed(s, s.opt, o); }
 
 }  // namespace sicp
 #endif
