@@ -310,9 +310,10 @@ def main():
                 "traffic": PMC_TRAFFIC_BYTES.get((n, S)),
                 "avg_launch_us": acc_us, "launches_timed": n_acc, "algorithmic_bytes_per_launch": acc_bytes,
                 "pairs_per_launch": S,
-                "note": "two floors of similar size: HBM (what the launch really moves, f64 normals and weights included: ~12 MB per pair "
-                        f"-> {S * 12e6 / 6.3e12 * 1e6:.0f} us at the 6.3 TB/s achievable) and FP64 issue (~170 instructions per correspondence "
-                        f"-> {S * 4e5 * 170 / (1024 * 16 * 2.4e9) * 1e6:.0f} us); two waves per SIMD (180 VGPRs) hide latency poorly; DESIGN.md section 3",
+                "note": "FP64 issue first (PMC: 245 VALU instructions per correspondence incl. reductions "
+                        f"-> {S * 4e5 * 245 / (1024 * 16 * 2.4e9) * 1e6:.0f} us on 1024 SIMDs), HBM second (what the launch really moves, f64 normals and "
+                        f"weights included: ~12 MB per pair -> {S * 12e6 / 6.3e12 * 1e6:.0f} us at the 6.3 TB/s achievable); two waves per SIMD "
+                        "(180 VGPRs); DESIGN.md section 3",
             }
             avg_ms = nn_ms / nn_launches
             alg_bytes = 12 * n + 12 * n + 8 * K_CORR * n     # src+tgt xyz once, idx+dist^2 out

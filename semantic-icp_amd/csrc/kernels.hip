@@ -1087,10 +1087,19 @@ __device__ __forceinline__ void pose_to_sgprs(Pose& P) {
   for (int k = 0; k < 3; ++k) P.t[k] = readlane_f64(P.t[k], 0);
 }
 
-// PF = slots whose loads are in flight together inside a lane.  4 (the whole group: four
-// independent gather chains per lane) is right when a launch has fewer waves than the chip has
-// SIMDs (one pair alone); a batch launch has many waves per SIMD to hide latency with and prefers
-// the smaller register footprint of PF = 2 (three waves per SIMD instead of two).
+// One group = 4 consecutive slots.  A lane issues the loads of TWO groups (its grid-stride
+// neighbours) before it computes the first: the kernel runs at two waves per SIMD with ~70 spare
+// VGPRs, and an index -> gather chain from HBM is ~2 us, about the time one group takes to compute.
+// PF (prefetch depth inside a group) is kept for the chained kernel experiments; the slots are always
+// accumulated in ascending order, so every variant produces the same bits.
+template <int K>
+struct SlotGroup {
+  int j[4];
+  double w[4];
+  float sx[4], sy[4], sz[4], tx[4], ty[4], tz[4];
+  double snx[4], sny[4], snz[4], tnx[4], tny[4], tnz[4];
+};
+
 template <int K, int BS, int PF = 4>
 __device__ __forceinline__ void accumulate_groups(const AccArgs& a, const Pose& P, int block, int nb, double (&acc)[28]) {
 #pragma unroll
@@ -1106,64 +1115,74 @@ __device__ __forceinline__ void accumulate_groups(const AccArgs& a, const Pose& 
   const int total = a.n_s * K;
   const int n_groups = (total + 3) >> 2;
   const double loss_b = a.loss.cauchy_a * a.loss.cauchy_a, loss_c = 1.0 / loss_b;
-  for (int g = block * BS + threadIdx.x; g < n_groups; g += nb * BS) {
+
+  auto load = [&](int g, SlotGroup<K>& G) {
     const int e0 = g << 2;
-    int j[4];
     if (e0 + 3 < total) {
       typedef int v4i __attribute__((ext_vector_type(4)));
       const v4i jv = *(const SICP_GLOBAL v4i*)(idx + e0);
-      j[0] = jv.x; j[1] = jv.y; j[2] = jv.z; j[3] = jv.w;
+      G.j[0] = jv.x; G.j[1] = jv.y; G.j[2] = jv.z; G.j[3] = jv.w;
     } else {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) j[c] = e0 + c < total ? idx[e0 + c] : -1;
+      for (int c = 0; c < 4; ++c) G.j[c] = e0 + c < total ? idx[e0 + c] : -1;
     }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int e = e0 + c;
+      const int i = min(e / K, a.n_s - 1);
+      const int jj = max(G.j[c], 0);
+      G.w[c] = wgt ? wgt[min(e, total - 1)] : 1.0;
+      if (K % 4 != 0 || c == 0) {
+        G.sx[c] = sx[i]; G.sy[c] = sy[i]; G.sz[c] = sz[i];
+        G.snx[c] = g_snx[i]; G.sny[c] = g_sny[i]; G.snz[c] = g_snz[i];
+      } else {  // K a multiple of 4: the four slots of a group share one source point
+        G.sx[c] = G.sx[0]; G.sy[c] = G.sy[0]; G.sz[c] = G.sz[0];
+        G.snx[c] = G.snx[0]; G.sny[c] = G.sny[0]; G.snz[c] = G.snz[0];
+      }
+      G.tx[c] = tx[jj]; G.ty[c] = ty[jj]; G.tz[c] = tz[jj];
+      G.tnx[c] = g_tnx[jj]; G.tny[c] = g_tny[jj]; G.tnz[c] = g_tnz[jj];
+    }
+  };
+  auto compute = [&](const SlotGroup<K>& G) {
     SrcTerms st;
 #pragma unroll
-    for (int c0 = 0; c0 < 4; c0 += PF) {
-      int i[PF];
-      double w[PF];
-      float sxv[PF], syv[PF], szv[PF], txv[PF], tyv[PF], tzv[PF];
-      double snx[PF], sny[PF], snz[PF], tnx[PF], tny[PF], tnz[PF];
-#pragma unroll
-      for (int c = 0; c < PF; ++c) {
-        const int e = e0 + c0 + c;
-        i[c] = min(e / K, a.n_s - 1);
-        const int jj = max(j[c0 + c], 0);
-        w[c] = wgt ? wgt[min(e, total - 1)] : 1.0;
-        if (K != 4 || c == 0) {
-          sxv[c] = sx[i[c]]; syv[c] = sy[i[c]]; szv[c] = sz[i[c]];
-          snx[c] = g_snx[i[c]]; sny[c] = g_sny[i[c]]; snz[c] = g_snz[i[c]];
-        } else {  // K == 4: the four slots of a group share one source point
-          sxv[c] = sxv[0]; syv[c] = syv[0]; szv[c] = szv[0];
-          snx[c] = snx[0]; sny[c] = sny[0]; snz[c] = snz[0];
-        }
-        txv[c] = tx[jj]; tyv[c] = ty[jj]; tzv[c] = tz[jj];
-        tnx[c] = g_tnx[jj]; tny[c] = g_tny[jj]; tnz[c] = g_tnz[jj];
-      }
-#pragma unroll
-      for (int c = 0; c < PF; ++c) {
+    for (int c = 0; c < 4; ++c) {
 #pragma clang fp contract(fast)
-        // the four slots of a group share their source point when K is a multiple of 4 (EM: K = 4)
-        if (K % 4 != 0 || c0 + c == 0) src_terms(P, a.one_m_eps, sxv[c], syv[c], szv[c], snx[c], sny[c], snz[c], st);
-        // A gated-out slot (index -1) is evaluated on target 0 and weighted by exactly zero instead of
-        // being branched around: x + (+-0 * finite) == x bit for bit, and a divergent skip makes the
-        // compiler copy all 28 accumulators at the join (10 % of the kernel's instructions).
-        Corr cr;
-        corr_eval_src(P, a.one_m_eps, st, sxv[c], syv[c], szv[c], snx[c], sny[c], snz[c], txv[c], tyv[c], tzv[c], tnx[c], tny[c],
-                      tnz[c], cr);
-        double rho0, rho1;
-        loss_eval_acc(a.loss, loss_b, loss_c, cr.r * cr.r, w[c], rho0, rho1);
-        if (j[c0 + c] < 0) { rho0 = 0.0; rho1 = 0.0; }
-        int o = 0;
+      if (K % 4 != 0 || c == 0) src_terms(P, a.one_m_eps, G.sx[c], G.sy[c], G.sz[c], G.snx[c], G.sny[c], G.snz[c], st);
+      // A gated-out slot (index -1) is evaluated on target 0 and weighted by exactly zero instead of
+      // being branched around: x + (+-0 * finite) == x bit for bit, and a divergent skip makes the
+      // compiler copy all 28 accumulators at the join (10 % of the kernel's instructions).
+      Corr cr;
+      corr_eval_src(P, a.one_m_eps, st, G.sx[c], G.sy[c], G.sz[c], G.snx[c], G.sny[c], G.snz[c], G.tx[c], G.ty[c], G.tz[c], G.tnx[c],
+                    G.tny[c], G.tnz[c], cr);
+      double rho0, rho1;
+      loss_eval_acc(a.loss, loss_b, loss_c, cr.r * cr.r, G.w[c], rho0, rho1);
+      if (G.j[c] < 0) { rho0 = 0.0; rho1 = 0.0; }
+      int o = 0;
 #pragma unroll
-        for (int p = 0; p < 6; ++p) {
-          const double jp = rho1 * cr.J[p];
+      for (int p = 0; p < 6; ++p) {
+        const double jp = rho1 * cr.J[p];
 #pragma unroll
-          for (int q = p; q < 6; ++q) acc[o++] += jp * cr.J[q];
-          acc[21 + p] += jp * cr.r;
-        }
-        acc[27] += 0.5 * rho0;
+        for (int q = p; q < 6; ++q) acc[o++] += jp * cr.J[q];
+        acc[21 + p] += jp * cr.r;
       }
+      acc[27] += 0.5 * rho0;
+    }
+  };
+
+  const int stride = nb * BS;
+  for (int g = block * BS + threadIdx.x; g < n_groups; g += (PF == 8 ? 2 : 1) * stride) {
+    SlotGroup<K> A;
+    load(g, A);
+    if (PF == 8) {
+      SlotGroup<K> B;
+      const bool two = g + stride < n_groups;
+      load(two ? g + stride : g, B);  // a lane without a second group re-reads its first, with zero weight:
+      if (!two) { B.j[0] = -1; B.j[1] = -1; B.j[2] = -1; B.j[3] = -1; }  // no branch around loads or sums
+      compute(A);
+      compute(B);
+    } else {
+      compute(A);
     }
   }
 }
@@ -1730,8 +1749,7 @@ hipError_t launch_accumulate_batch(int K, const BatchArgs* batch, int n, int max
   static const int pf = [] { const char* e = getenv("SICP_ACC_BATCH_PF"); return e ? atoi(e) : 4; }();  // tuning aid
 #define SICP_AB(KK) \
   do { \
-    if (pf == 1) hipLaunchKernelGGL((accumulate_batch_kernel<KK, 256, 1>), grid, dim3(256), 0, st, batch); \
-    else if (pf == 2) hipLaunchKernelGGL((accumulate_batch_kernel<KK, 256, 2>), grid, dim3(256), 0, st, batch); \
+    if (pf == 8) hipLaunchKernelGGL((accumulate_batch_kernel<KK, 256, 8>), grid, dim3(256), 0, st, batch); \
     else hipLaunchKernelGGL((accumulate_batch_kernel<KK, 256, 4>), grid, dim3(256), 0, st, batch); \
   } while (0)
   switch (K) {
