@@ -487,3 +487,22 @@ def test_align_batch_rejects_mismatched_handles():
             sicp.align_batch([e1, e1])
     finally:
         e1.close(); e2.close()
+
+
+def test_align_batch_more_pairs_than_one_job_launch():
+    """10 pairs: 20 covariance jobs and 10 search jobs per phase exceed one job-array launch (16 / 8)."""
+    ident = np.array([0, 0, 0, 1, 0, 0, 0.0])
+    engines, singles = [], []
+    try:
+        for k in range(10):
+            ps, ls, pt, lt, T, cm = synth.lidar_pair(seed=10 + k, n_points=1500 + 100 * k)
+            e, p = make_engine(sicp.MODE_EM, 11, cm)
+            e.set_source(ps, ls); e.set_target(pt, lt)
+            engines.append(e)
+            singles.append(e.align(ident))
+        res = sicp.align_batch(engines)
+        for (qb, sb), (q1, s1) in zip(res, singles):
+            assert np.array_equal(qb, q1) and sb["outer_iters"] == s1["outer_iters"] and sb["total_active"] == s1["total_active"]
+    finally:
+        for e in engines:
+            e.close()
