@@ -75,6 +75,39 @@ SICP_HD inline uint64_t curve_code(float x, float y, float z, float lox, float l
   return hilbert63_cells(quant21_cell(x, lox, scale), quant21_cell(y, loy, scale), quant21_cell(z, loz, scale));
 }
 
+// The curve index at BITS bits per axis, aligned with the 63-bit indices: the Hilbert index is
+// hierarchical (the index of the coarse cell is a prefix of the index of every fine cell inside it),
+// so this is the first 63-bit index of the coarse cell -- all a seed search needs, at BITS/21 of the
+// cost (the unrolled 21-bit transform is ~900 instructions).
+template <int BITS>
+SICP_HD inline uint64_t curve_code_coarse(float x, float y, float z, float lox, float loy, float loz, float scale) {
+  uint32_t X[3] = {quant21_cell(x, lox, scale) >> (21 - BITS), quant21_cell(y, loy, scale) >> (21 - BITS),
+                   quant21_cell(z, loz, scale) >> (21 - BITS)};
+  const uint32_t M = 1u << (BITS - 1);
+  for (uint32_t Q = M; Q > 1; Q >>= 1) {
+    const uint32_t P = Q - 1;
+    for (int i = 0; i < 3; ++i) {
+      if (X[i] & Q) {
+        X[0] ^= P;
+      } else {
+        const uint32_t t = (X[0] ^ X[i]) & P;
+        X[0] ^= t;
+        X[i] ^= t;
+      }
+    }
+  }
+  X[1] ^= X[0];
+  X[2] ^= X[1];
+  uint32_t t = 0;
+  for (uint32_t Q = M; Q > 1; Q >>= 1)
+    if (X[2] & Q) t ^= Q - 1;
+  X[0] ^= t; X[1] ^= t; X[2] ^= t;
+  uint64_t h = 0;
+  for (int b = BITS - 1; b >= 0; --b)
+    h = (h << 3) | (uint64_t)((((X[0] >> b) & 1u) << 2) | (((X[1] >> b) & 1u) << 1) | ((X[2] >> b) & 1u));
+  return h << (3 * (21 - BITS));
+}
+
 // levels of the implicit tree over n points (node counts only depend on n)
 inline TreeLevels make_levels(int n) {
   TreeLevels lv;

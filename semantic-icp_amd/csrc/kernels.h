@@ -73,6 +73,9 @@ struct KnnArgs {
   int* out_i;
   float* out_d;
   int* dbg;        // nullable: [q_count][2] = (boxes tested, leaves scanned), debugging only
+  const int* seed_hint;  // nullable, packet kernel: [query][hint_K] device indices found by the previous search of
+                         // the same queries (the seed of the walk; any valid target index is a legal hint)
+  int hint_K, t_begin;   // t_begin = device index of the target segment's first point
   int out_stride;  // 0: out_i / out_d are [query][K]; > 0: [K][out_stride] (packet kernel only: coalesced
                    // for the covariance kernel, which reads one neighbour rank of 64 points at a time)
 };

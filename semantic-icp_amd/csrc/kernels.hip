@@ -591,23 +591,40 @@ __device__ __forceinline__ void knn_packet_body(const KnnArgs& a, int wg, int n_
     if (a.self) {
       seed = bid / kFan;  // the 16 queries ARE leaf `bid`
     } else {
-      // 64-ary search of the middle query's curve index in the leaves' first indices: lane i
-      // probes position lo + (i+1)*step, the ballot's population count is the sub-range
-      const u64 qc_lane = curve_code(px, py, pz, a.tree.lo[0], a.tree.lo[1], a.tree.lo[2], a.tree.scale);
-      const u64 qc = ((u64)(unsigned)__builtin_amdgcn_readlane((int)(qc_lane >> 32), 32) << 32) |
-                     (unsigned)__builtin_amdgcn_readlane((int)qc_lane, 32);
-      const u64* __restrict__ codes = a.tree.leaf_code + a.tree.code_begin;
-      int lo_i = 0, len = n_leaf;  // the answer (last leaf whose first index is <= qc, else 0) is in [lo_i, lo_i+len)
-      while (len > 1) {
-        const int step = (len + 63) >> 6;
-        const int idx = lo_i + (lane + 1) * step;
-        const bool ok = idx < lo_i + len && codes[idx] <= qc;  // sorted: true for a prefix of the lanes
-        const int cnt = __popcll(__ballot(ok));
-        const int nlo = lo_i + cnt * step;
-        len = min(step, lo_i + len - nlo);
-        lo_i = nlo;
+      // (1) the previous search of these queries, when there is one: the leaf of a previous nearest
+      // neighbour (outer iterations move the pose little) -- one load instead of a curve transform
+      int hint_leaf = -1;
+      if (a.seed_hint) {
+        const int prev = a.seed_hint[(size_t)(a.q_begin + q) * a.hint_K];
+        const bool ok = prev >= a.t_begin && prev < a.t_begin + a.tree.n;
+        const u64 m = __ballot(ok);
+        if (m) {
+          const u64 upper = m >> 32;  // prefer a query from the middle of the packet
+          const int src = upper ? 32 + __ffsll((unsigned long long)upper) - 1 : __ffsll((unsigned long long)m) - 1;
+          hint_leaf = (__builtin_amdgcn_readlane(prev, src) - a.t_begin) / kLeaf;
+        }
       }
-      seed = lo_i / kFan;
+      if (hint_leaf >= 0) {
+        seed = hint_leaf / kFan;
+      } else {
+        // (2) 64-ary search of the middle query's (10 bits per axis) curve index in the leaves' first
+        // indices: lane i probes position lo + (i+1)*step, the ballot's population count is the sub-range
+        const u64 qc_lane = curve_code_coarse<10>(px, py, pz, a.tree.lo[0], a.tree.lo[1], a.tree.lo[2], a.tree.scale);
+        const u64 qc = ((u64)(unsigned)__builtin_amdgcn_readlane((int)(qc_lane >> 32), 32) << 32) |
+                       (unsigned)__builtin_amdgcn_readlane((int)qc_lane, 32);
+        const u64* __restrict__ codes = a.tree.leaf_code + a.tree.code_begin;
+        int lo_i = 0, len = n_leaf;  // the answer (last leaf whose first index is <= qc, else 0) is in [lo_i, lo_i+len)
+        while (len > 1) {
+          const int step = (len + 63) >> 6;
+          const int idx = lo_i + (lane + 1) * step;
+          const bool ok = idx < lo_i + len && codes[idx] <= qc;  // sorted: true for a prefix of the lanes
+          const int cnt = __popcll(__ballot(ok));
+          const int nlo = lo_i + cnt * step;
+          len = min(step, lo_i + len - nlo);
+          lo_i = nlo;
+        }
+        seed = lo_i / kFan;
+      }
     }
     seed = __builtin_amdgcn_readfirstlane(seed);
   }

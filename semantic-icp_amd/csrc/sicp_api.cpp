@@ -128,6 +128,7 @@ struct sicp_context {
   DevBuf<double> w;
   int corr_n = 0, corr_K = 0;
   bool corr_valid = false, corr_weighted = false;
+  bool hint_ok = false;  // idx holds this align()'s previous search: usable as the next search's seed hint
   DevBuf<unsigned long long> part;
   DevBuf<double> partials, out28;
   DevBuf<long long> d_count;
@@ -295,6 +296,7 @@ int prepare_cloud(sicp_context* h, Cloud& c) {
   c.layout = want;
   c.feat_valid = false;
   h->corr_valid = false;
+  h->hint_ok = false;
   return SICP_OK;
 }
 
@@ -324,6 +326,10 @@ int run_nn(sicp_context* h, int K, const Cloud& Qc, int q_begin, int q_count, co
     a.out_i = out_i; a.out_d = out_d;
     a.dbg = nullptr;
     a.out_stride = out_stride;
+    // seed hint: what the previous search of the same queries found (same clouds, same K, this align)
+    a.seed_hint = (!self && h->hint_ok && out_i == h->idx.p && h->corr_K == K && h->corr_n == Qc.n) ? h->idx.p : nullptr;
+    a.hint_K = K;
+    a.t_begin = Tc.seg_off.empty() ? 0 : Tc.seg_off[tseg];
     static const bool want_dbg = std::getenv("SICP_KNN_STATS") != nullptr;  // developer aid, off by default
     DevBuf<int> dbg;
     if (want_dbg) { HIPCHECK(dbg.reserve((size_t)2 * q_count)); a.dbg = dbg.p; }
@@ -546,6 +552,7 @@ int run_correspondences(sicp_context* h, const double* qt, int K, bool weights) 
   h->corr_n = S.n;
   h->corr_K = K;
   h->corr_valid = true;
+  h->hint_ok = true;
   return SICP_OK;
 }
 
@@ -717,6 +724,7 @@ int align_begin(sicp_context* h, bool want_stats) {
   const sicp_params& P = h->params;
   const bool em = P.mode == SICP_MODE_EM, sem = P.mode == SICP_MODE_SEMANTIC;
   std::memset(&h->st, 0, sizeof h->st);
+  h->hint_ok = false;  // every align() starts its first search from the curve position, like a first call would
   Cloud &S = h->cloud[0], &T = h->cloud[1];
   HIPCHECK(h->d_count.reserve(1));
   if (want_stats) HIPCHECK(hipMemsetAsync(h->d_count.p, 0, sizeof(long long), h->stream));
@@ -1025,7 +1033,7 @@ int sicp_set_params(sicp_handle h, const sicp_params* p) {
   // engine knobs (profiling, batching) do not invalidate the correspondences held on the device
   sicp_params a = h->params, b = *p;
   a.profile = b.profile = 0; a.lm_batch = b.lm_batch = 0; a.lm_on_device = b.lm_on_device = 0;
-  if (std::memcmp(&a, &b, sizeof a) != 0) h->corr_valid = false;
+  if (std::memcmp(&a, &b, sizeof a) != 0) { h->corr_valid = false; h->hint_ok = false; }
   h->params = *p;
   return SICP_OK;
 }
@@ -1050,6 +1058,7 @@ int sicp_set_cloud(sicp_handle h, int which, int32_t n, const float* x, const fl
   c.layout = -1;
   c.feat_valid = false;
   h->corr_valid = false;
+  h->hint_ok = false;
   // upload now for the current mode, so that align() starts with the cloud resident in HBM;
   // a later mode change re-lays it out lazily
   if (h->params.mode != SICP_MODE_SEMANTIC || c.has_label) return prepare_cloud(h, c);
@@ -1374,6 +1383,7 @@ int sicp_fused_labels(sicp_handle h, const double qt[7], uint32_t* out_labels) {
   if (!features_current(h, T, true)) SICPCHECK(compute_features(h, T, true));
   SICPCHECK(run_correspondences(h, qt, 4, false));  // K = 4 is a literal here (em_icp.hpp:221)
   h->corr_valid = false;                            // K may differ from params.knn
+  h->hint_ok = false;
   sicp::WeightArgs a;
   a.n_s = S.n; a.K = 4; a.C = P.num_classes;
   a.idx = h->idx.p;
