@@ -910,7 +910,7 @@ __device__ __forceinline__ double rcp_newton(double d) {
 struct SrcTerms {
   double qx, qy, qz;                      // R p_s + t
   double mx, my, mz;                      // m = R n_s
-  double e00, e01, e02, e11, e12, e22;    // (1-eps) m m^T
+  double d00, d11, d22, n01, n02, n12;    // 2I - (1-eps) m m^T: diagonal, and the (negative) off-diagonal entries
 };
 
 __device__ __forceinline__ void src_terms(const Pose& P, double one_m_eps, double psx, double psy, double psz, double nsx,
@@ -924,8 +924,8 @@ __device__ __forceinline__ void src_terms(const Pose& P, double one_m_eps, doubl
   s.my = R[3] * nsx + R[4] * nsy + R[5] * nsz;
   s.mz = R[6] * nsx + R[7] * nsy + R[8] * nsz;
   const double ex = one_m_eps * s.mx, ey = one_m_eps * s.my, ez = one_m_eps * s.mz;
-  s.e00 = ex * s.mx; s.e01 = ex * s.my; s.e02 = ex * s.mz;
-  s.e11 = ey * s.my; s.e12 = ey * s.mz; s.e22 = ez * s.mz;
+  s.d00 = 2.0 - ex * s.mx; s.n01 = -(ex * s.my); s.n02 = -(ex * s.mz);
+  s.d11 = 2.0 - ey * s.my; s.n12 = -(ey * s.mz); s.d22 = 2.0 - ez * s.mz;
 }
 
 __device__ __forceinline__ void corr_eval_src(const Pose& P, double one_m_eps, const SrcTerms& s, double psx, double psy,
@@ -935,12 +935,12 @@ __device__ __forceinline__ void corr_eval_src(const Pose& P, double one_m_eps, c
   const double* R = P.R;
   // A = C_t + R C_s R^T = 2I - (1-eps) n_t n_t^T - (1-eps) m m^T
   const double fx = one_m_eps * ntx, fy = one_m_eps * nty, fz = one_m_eps * ntz;
-  const double a00 = (2.0 - s.e00) - fx * ntx;
-  const double a01 = -s.e01 - fx * nty;
-  const double a02 = -s.e02 - fx * ntz;
-  const double a11 = (2.0 - s.e11) - fy * nty;
-  const double a12 = -s.e12 - fy * ntz;
-  const double a22 = (2.0 - s.e22) - fz * ntz;
+  const double a00 = s.d00 - fx * ntx;
+  const double a01 = s.n01 - fx * nty;
+  const double a02 = s.n02 - fx * ntz;
+  const double a11 = s.d11 - fy * nty;
+  const double a12 = s.n12 - fy * ntz;
+  const double a22 = s.d22 - fz * ntz;
   const double rx = ptx - s.qx, ry = pty - s.qy, rz = ptz - s.qz;
   // Eigen Matrix3d::inverse(): cofactors / determinant
   const double k00 = a11 * a22 - a12 * a12;
@@ -963,10 +963,12 @@ __device__ __forceinline__ void corr_eval_src(const Pose& P, double one_m_eps, c
   const double cx = psx + bx - nb * nsx;  // c = p_s + C_s b
   const double cy = psy + by - nb * nsy;
   const double cz = psz + bz - nb * nsz;
-  o.J[0] = -2.0 * bx; o.J[1] = -2.0 * by; o.J[2] = -2.0 * bz;
-  o.J[3] = 2.0 * (by * cz - bz * cy);
-  o.J[4] = 2.0 * (bz * cx - bx * cz);
-  o.J[5] = 2.0 * (bx * cy - by * cx);
+  // HALF the Jacobian: J = 2 [-b; b x c].  The caller folds the powers of two into its weight
+  // (scaling by 2 and 4 is exact, so the sums keep their bits) and saves six multiplications.
+  o.J[0] = -bx; o.J[1] = -by; o.J[2] = -bz;
+  o.J[3] = by * cz - bz * cy;
+  o.J[4] = bz * cx - bx * cz;
+  o.J[5] = bx * cy - by * cx;
 }
 
 // log(x) for finite x >= 1 -- the only arguments the losses produce (1 + s/a^2 and 1 + sqrt(s)/a^2).
@@ -1175,13 +1177,15 @@ __device__ __forceinline__ void accumulate_groups(const AccArgs& a, const Pose& 
       double rho0, rho1;
       loss_eval_acc(a.loss, loss_b, loss_c, cr.r * cr.r, G.w[c], rho0, rho1);
       if (G.j[c] < 0) { rho0 = 0.0; rho1 = 0.0; }
+      // cr.J is J/2:  rho1 J J^T = (4 rho1) (J/2)(J/2)^T,  rho1 r J = (4 rho1) (J/2) (r/2)
+      const double rho4 = 4.0 * rho1, rh = 0.5 * cr.r;
       int o = 0;
 #pragma unroll
       for (int p = 0; p < 6; ++p) {
-        const double jp = rho1 * cr.J[p];
+        const double jp = rho4 * cr.J[p];
 #pragma unroll
         for (int q = p; q < 6; ++q) acc[o++] += jp * cr.J[q];
-        acc[21 + p] += jp * cr.r;
+        acc[21 + p] += jp * rh;
       }
       acc[27] += 0.5 * rho0;
     }
