@@ -125,6 +125,22 @@ SICP_HD inline void unpack28(const double* o, double* H, double* g, double* cost
   *cost = o[27];
 }
 
+// Rigorous lower bounds of gradient_max_norm that cost far less than the SE(3) exp it contains.
+// With u = g[0..2], w = g[3..5], t = |w|:
+//  * the translation rows of x - Plus(x, -g) are R V(w) u; R is orthonormal (to rounding) and V is
+//    normal with singular values 1 and 2|sin(t/2)|/t >= 2/pi for t <= pi, so
+//    max-norm >= |V u|_2 / sqrt(3) >= 0.3676 |u|_2;
+//  * the quaternion rows are q_x (1 - e) with e = exp's unit quaternion (angle t/2), and quaternion
+//    norms multiply: |q_x (1 - e)|_2 = |q_x| 2 |sin(t/4)|, so max-norm >= |q_x| |sin(t/4)|.
+// Each is used with a factor 2 of slack for rounding and |q_x| != 1.  When either is clearly above
+// the tolerance -- every iteration but the last few of a solve -- the exact evaluation is skipped;
+// the decisions are the same.
+SICP_HD inline bool gradient_clearly_above(const double* g, double tol) {
+  const double u2 = g[0] * g[0] + g[1] * g[1] + g[2] * g[2], w2 = g[3] * g[3] + g[4] * g[4] + g[5] * g[5];
+  if (w2 <= 9.0 && 0.18 * 0.18 * u2 > tol * tol) return true;
+  return 0.5 * fabs(sin(0.25 * sqrt(w2))) > tol;
+}
+
 // Ceres: ||x - Plus(x, -g)||_inf  (ambient coordinates)
 SICP_HD inline double gradient_max_norm(const double* x, const double* g) {
   double ng[6], xp[7], m = 0;
@@ -142,7 +158,10 @@ SICP_HD inline double gradient_max_norm(const double* x, const double* g) {
 // test is done once, before it -- same decisions in the same order as testing it every time.
 SICP_HD inline void lm_propose(LmCore& s, const LmOptions& opt) {
   if (s.iterations >= opt.max_iterations) { s.status = LM_ITERATION_CAP; return; }
-  if (gradient_max_norm(s.x, s.g) <= opt.gradient_tolerance) { s.status = LM_CONVERGED; return; }
+  if (!gradient_clearly_above(s.g, opt.gradient_tolerance) && gradient_max_norm(s.x, s.g) <= opt.gradient_tolerance) {
+    s.status = LM_CONVERGED;
+    return;
+  }
   double step[6], model_change;
   for (;;) {
 #if defined(__HIP_DEVICE_COMPILE__)
