@@ -593,10 +593,18 @@ __device__ __forceinline__ void knn_packet_body(const KnnArgs& a, int wg, int n_
     } else {
       // (1) the previous search of these queries, when there is one: the leaf of a previous nearest
       // neighbour (outer iterations move the pose little) -- one load instead of a curve transform
+      // The hint is only trusted while it is still close: the query's distance to its previous
+      // nearest neighbour must not have grown beyond twice what it was (after the first solve of an
+      // align() the pose jumps, and a stale hint is a worse seed than the curve position).
       int hint_leaf = -1;
       if (a.seed_hint) {
-        const int prev = a.seed_hint[(size_t)(a.q_begin + q) * a.hint_K];
-        const bool ok = prev >= a.t_begin && prev < a.t_begin + a.tree.n;
+        const size_t hq = (size_t)(a.q_begin + q) * a.hint_K;
+        const int prev = a.seed_hint[hq];
+        bool ok = prev >= a.t_begin && prev < a.t_begin + a.tree.n;
+        if (ok && a.out_d) {
+          const float4 hp = a.tree.pts4[a.tree.pt_begin + (prev - a.t_begin)];
+          ok = l2_simple(px, py, pz, hp.x, hp.y, hp.z) <= 4.0f * a.out_d[hq] + 1e-12f;
+        }
         const u64 m = __ballot(ok);
         if (m) {
           const u64 upper = m >> 32;  // prefer a query from the middle of the packet
@@ -607,21 +615,18 @@ __device__ __forceinline__ void knn_packet_body(const KnnArgs& a, int wg, int n_
       if (hint_leaf >= 0) {
         seed = hint_leaf / kFan;
       } else {
-        // (2) 64-ary search of the middle query's (10 bits per axis) curve index in the leaves' first
-        // indices: lane i probes position lo + (i+1)*step, the ballot's population count is the sub-range
+        // (2) binary search of the middle query's (10 bits per axis) curve index in the leaves' first
+        // indices, on the scalar unit (uniform addresses: ~13 dependent scalar loads).  A 64-ary
+        // ballot search is three rounds instead of thirteen but every round is 64 scattered vector
+        // loads per wave: in a batch launch those were +60 % memory transactions and +67 % time.
         const u64 qc_lane = curve_code_coarse<10>(px, py, pz, a.tree.lo[0], a.tree.lo[1], a.tree.lo[2], a.tree.scale);
         const u64 qc = ((u64)(unsigned)__builtin_amdgcn_readlane((int)(qc_lane >> 32), 32) << 32) |
                        (unsigned)__builtin_amdgcn_readlane((int)qc_lane, 32);
         const u64* __restrict__ codes = a.tree.leaf_code + a.tree.code_begin;
-        int lo_i = 0, len = n_leaf;  // the answer (last leaf whose first index is <= qc, else 0) is in [lo_i, lo_i+len)
-        while (len > 1) {
-          const int step = (len + 63) >> 6;
-          const int idx = lo_i + (lane + 1) * step;
-          const bool ok = idx < lo_i + len && codes[idx] <= qc;  // sorted: true for a prefix of the lanes
-          const int cnt = __popcll(__ballot(ok));
-          const int nlo = lo_i + cnt * step;
-          len = min(step, lo_i + len - nlo);
-          lo_i = nlo;
+        int lo_i = 0, hi_i = n_leaf - 1;  // last leaf whose first index is <= qc, else 0
+        while (lo_i < hi_i) {
+          const int mid = (lo_i + hi_i + 1) >> 1;
+          if (codes[mid] <= qc) lo_i = mid; else hi_i = mid - 1;
         }
         seed = lo_i / kFan;
       }
