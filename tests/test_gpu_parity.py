@@ -506,3 +506,22 @@ def test_align_batch_more_pairs_than_one_job_launch():
     finally:
         for e in engines:
             e.close()
+
+
+@pytest.mark.parametrize("knob", [dict(nn_method=2), dict(nn_method=0), dict(profile=1)])
+def test_align_batch_per_pair_launch_path(knob):
+    """With another search engine or with profiling on, a batch keeps the pairs' own searches and
+    feature kernels on their own streams (only the inner solves are batched): same results."""
+    engines, singles = [], []
+    try:
+        for seed, n in ((2, 3000), (7, 4500)):
+            ps, ls, pt, lt, T, cm = synth.lidar_pair(seed=seed, n_points=n)
+            e, p = make_engine(sicp.MODE_EM, 11, cm, **knob)
+            e.set_source(ps, ls); e.set_target(pt, lt)
+            engines.append(e)
+            singles.append(e.align())
+        for (qb, sb), (q1, s1) in zip(sicp.align_batch(engines), singles):
+            assert np.array_equal(qb, q1) and sb["outer_iters"] == s1["outer_iters"] and sb["total_lm_iters"] == s1["total_lm_iters"]
+    finally:
+        for e in engines:
+            e.close()
