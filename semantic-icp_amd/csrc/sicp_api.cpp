@@ -155,7 +155,9 @@ struct sicp_context {
   double* h_bout28 = nullptr;
   int h_batch_cap = 0;
   hipGraphExec_t b_graph = nullptr;
-  int b_graph_n = 0, b_graph_maxnb = 0, b_graph_K = 0, b_graph_len = 0;
+  int b_graph_n = 0, b_graph_maxnb = 0, b_graph_K = 0, b_graph_len = 0, b_graph_chains = 0;
+  hipStream_t stream_fork = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_fork_done = nullptr;
   const void* b_graph_ptr = nullptr;
   std::string last_error;
   sicp_stats st;
@@ -858,17 +860,35 @@ int run_solve_batch(sicp_context* h, sicp_handle* hs, int n, const char* active,
   HIPCHECK(hipMemcpyAsync(h->d_bstates.p, h->h_bstates, sizeof(sicp::LmState) * n, hipMemcpyHostToDevice, h->stream));
   const int len = P.lm_batch > 0 ? P.lm_batch : 12;
   const int K = hs[0]->corr_K;
-  // the graph only depends on the grid and on the address of the argument array
+  // The graph only depends on the grid and on the address of the argument array.  With four or more
+  // pairs it has two independent chains (the halves of the batch), so that one half's one-wave-per-
+  // pair LM step overlaps the other half's accumulate launch (+3 %; SICP_BATCH_CHAINS=1: one chain).
+  static const int chains_wanted = [] { const char* e = std::getenv("SICP_BATCH_CHAINS"); return e ? std::atoi(e) : 2; }();
+  const int chains = (chains_wanted >= 2 && n >= 4) ? 2 : 1;
+  if (chains == 2 && !h->stream_fork) {
+    HIPCHECK(hipStreamCreateWithFlags(&h->stream_fork, hipStreamNonBlocking));
+    HIPCHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    HIPCHECK(hipEventCreateWithFlags(&h->ev_fork_done, hipEventDisableTiming));
+  }
   if (!h->b_graph || h->b_graph_n != n || h->b_graph_maxnb != max_nb || h->b_graph_K != K || h->b_graph_len != len ||
-      h->b_graph_ptr != (const void*)h->d_batch.p) {
+      h->b_graph_ptr != (const void*)h->d_batch.p || h->b_graph_chains != chains) {
     if (h->b_graph) { (void)hipGraphExecDestroy(h->b_graph); h->b_graph = nullptr; }
     hipGraph_t g = nullptr;
+    const int n0 = chains == 2 ? n / 2 : n, n1 = n - n0;
     HIPCHECK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
     hipError_t ce = hipSuccess;
-    for (int b = 0; b < len && ce == hipSuccess; ++b) {
-      ce = sicp::launch_accumulate_batch(K, h->d_batch.p, n, max_nb, h->stream);
-      if (ce == hipSuccess) ce = sicp::launch_lm_step_batch(h->d_batch.p, n, h->stream);
+    if (chains == 2) {
+      ce = hipEventRecord(h->ev_fork, h->stream);
+      if (ce == hipSuccess) ce = hipStreamWaitEvent(h->stream_fork, h->ev_fork, 0);
     }
+    for (int b = 0; b < len && ce == hipSuccess; ++b) {
+      ce = sicp::launch_accumulate_batch(K, h->d_batch.p, n0, max_nb, h->stream);
+      if (ce == hipSuccess) ce = sicp::launch_lm_step_batch(h->d_batch.p, n0, h->stream);
+      if (chains == 2 && ce == hipSuccess) ce = sicp::launch_accumulate_batch(K, h->d_batch.p + n0, n1, max_nb, h->stream_fork);
+      if (chains == 2 && ce == hipSuccess) ce = sicp::launch_lm_step_batch(h->d_batch.p + n0, n1, h->stream_fork);
+    }
+    if (chains == 2 && ce == hipSuccess) ce = hipEventRecord(h->ev_fork_done, h->stream_fork);
+    if (chains == 2 && ce == hipSuccess) ce = hipStreamWaitEvent(h->stream, h->ev_fork_done, 0);
     hipError_t ee = hipStreamEndCapture(h->stream, &g);
     HIPCHECK(ce);
     HIPCHECK(ee);
@@ -876,6 +896,7 @@ int run_solve_batch(sicp_context* h, sicp_handle* hs, int n, const char* active,
     (void)hipGraphDestroy(g);
     HIPCHECK(ie);
     h->b_graph_n = n; h->b_graph_maxnb = max_nb; h->b_graph_K = K; h->b_graph_len = len; h->b_graph_ptr = h->d_batch.p;
+    h->b_graph_chains = chains;
   }
   for (;;) {
     HIPCHECK(hipGraphLaunch(h->b_graph, h->stream));
@@ -1019,6 +1040,9 @@ int sicp_destroy(sicp_handle h) {
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->lm_graph) (void)hipGraphExecDestroy(h->lm_graph);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->ev_fork_done) (void)hipEventDestroy(h->ev_fork_done);
+  if (h->stream_fork) (void)hipStreamDestroy(h->stream_fork);
   if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
