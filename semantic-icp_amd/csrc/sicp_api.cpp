@@ -103,11 +103,12 @@ double now_ms() {
 // launches each kind once for all pairs (kernels.h: *_jobs launchers), in dependency order
 struct JobCollector {
   int knn_K = 0;
-  std::vector<sicp::KnnArgs> knn;
-  std::vector<sicp::CovArgs> cov;
-  std::vector<sicp::ProjArgs> proj;
-  std::vector<sicp::WeightArgs> weight;
-  std::vector<sicp::CountJob> count;
+  int half = 0;  // which half of the batch the pair whose stage is running belongs to (set by the driver)
+  std::vector<sicp::KnnArgs> knn[2];
+  std::vector<sicp::CovArgs> cov[2];
+  std::vector<sicp::ProjArgs> proj[2];
+  std::vector<sicp::WeightArgs> weight[2];
+  std::vector<sicp::CountJob> count[2];
 };
 
 struct sicp_context {
@@ -338,7 +339,7 @@ int run_nn(sicp_context* h, int K, const Cloud& Qc, int q_begin, int q_count, co
     static const bool lane_per_query = std::getenv("SICP_KNN_LANE_PER_QUERY") != nullptr;  // A/B aid
     if (h->collect) {  // lock-step batch (packet search, no profiling: checked by the driver)
       h->collect->knn_K = K;
-      h->collect->knn.push_back(a);
+      h->collect->knn[h->collect->half].push_back(a);
       return SICP_OK;
     }
     KernelTimer kt(h, stream == h->stream ? timer_bit : 0);
@@ -424,7 +425,7 @@ int ensure_proj(sicp_context* h, Cloud& c) {
   sicp::ProjArgs a;
   a.n = c.n; a.C = P.num_classes;
   a.hist = c.hist.p; a.cm = h->d_cm.p; a.hval = h->d_hval.p; a.proj = c.proj.p;
-  if (h->collect) h->collect->proj.push_back(a);
+  if (h->collect) h->collect->proj[h->collect->half].push_back(a);
   else HIPCHECK(sicp::launch_proj(a, h->stream));
   c.proj_valid = true;
   return SICP_OK;
@@ -457,7 +458,7 @@ int compute_features(sicp_context* h, Cloud& c, bool with_hist, hipStream_t stre
   a.float_products = P.quirk_float_products;
   a.nx = c.nx.p; a.ny = c.ny.p; a.nz = c.nz.p;
   a.hist = with_hist ? c.hist.p : nullptr;
-  if (h->collect) h->collect->cov.push_back(a);
+  if (h->collect) h->collect->cov[h->collect->half].push_back(a);
   else HIPCHECK(sicp::launch_cov(a, stream));
   c.feat_valid = true;
   c.proj_valid = false;
@@ -544,7 +545,7 @@ int run_correspondences(sicp_context* h, const double* qt, int K, bool weights) 
     a.one_m_eps = 1.0 - P.epsilon;
     a.bool_probability = P.quirk_bool_probability;
     a.w = h->w.p;
-    if (h->collect) h->collect->weight.push_back(a);
+    if (h->collect) h->collect->weight[h->collect->half].push_back(a);
     else HIPCHECK(sicp::launch_em_weight(a, h->stream));
     h->st.weight_launches += 1;
     h->st.weight_kernel_ms += kt.stop();
@@ -806,12 +807,32 @@ int batch_reserve(sicp_context* h, int n) {
 
 // launches what the pairs' stages collected: searches, then the kernels that consume them
 int flush_jobs(sicp_context* h, JobCollector& jc) {
-  if (!jc.knn.empty()) HIPCHECK(sicp::launch_bvh_knn_packet_jobs(jc.knn_K, jc.knn.data(), (int)jc.knn.size(), h->stream));
-  if (!jc.cov.empty()) HIPCHECK(sicp::launch_cov_jobs(jc.cov.data(), (int)jc.cov.size(), h->stream));
-  if (!jc.proj.empty()) HIPCHECK(sicp::launch_proj_jobs(jc.proj.data(), (int)jc.proj.size(), h->stream));
-  if (!jc.weight.empty()) HIPCHECK(sicp::launch_em_weight_jobs(jc.weight.data(), (int)jc.weight.size(), h->stream));
-  if (!jc.count.empty()) HIPCHECK(sicp::launch_count_active_jobs(jc.count.data(), (int)jc.count.size(), h->stream));
-  jc.knn.clear(); jc.cov.clear(); jc.proj.clear(); jc.weight.clear(); jc.count.clear();
+  // The two halves of the batch run their stage sequences (searches -> covariances -> projections ->
+  // weights -> counts) on two streams: the small kernels and the search tails of one half overlap
+  // the searches of the other (+4 %).
+  const bool two = !jc.knn[1].empty() || !jc.cov[1].empty() || !jc.proj[1].empty() || !jc.weight[1].empty() || !jc.count[1].empty();
+  if (two && !h->stream_fork) {
+    HIPCHECK(hipStreamCreateWithFlags(&h->stream_fork, hipStreamNonBlocking));
+    HIPCHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    HIPCHECK(hipEventCreateWithFlags(&h->ev_fork_done, hipEventDisableTiming));
+  }
+  if (two) {
+    HIPCHECK(hipEventRecord(h->ev_fork, h->stream));
+    HIPCHECK(hipStreamWaitEvent(h->stream_fork, h->ev_fork, 0));
+  }
+  for (int half = 0; half < 2; ++half) {
+    hipStream_t st = half ? h->stream_fork : h->stream;
+    if (!jc.knn[half].empty()) HIPCHECK(sicp::launch_bvh_knn_packet_jobs(jc.knn_K, jc.knn[half].data(), (int)jc.knn[half].size(), st));
+    if (!jc.cov[half].empty()) HIPCHECK(sicp::launch_cov_jobs(jc.cov[half].data(), (int)jc.cov[half].size(), st));
+    if (!jc.proj[half].empty()) HIPCHECK(sicp::launch_proj_jobs(jc.proj[half].data(), (int)jc.proj[half].size(), st));
+    if (!jc.weight[half].empty()) HIPCHECK(sicp::launch_em_weight_jobs(jc.weight[half].data(), (int)jc.weight[half].size(), st));
+    if (!jc.count[half].empty()) HIPCHECK(sicp::launch_count_active_jobs(jc.count[half].data(), (int)jc.count[half].size(), st));
+    jc.knn[half].clear(); jc.cov[half].clear(); jc.proj[half].clear(); jc.weight[half].clear(); jc.count[half].clear();
+  }
+  if (two) {
+    HIPCHECK(hipEventRecord(h->ev_fork_done, h->stream_fork));
+    HIPCHECK(hipStreamWaitEvent(h->stream, h->ev_fork_done, 0));
+  }
   return SICP_OK;
 }
 
@@ -920,7 +941,7 @@ int run_solve_batch(sicp_context* h, sicp_handle* hs, int n, const char* active,
 // statistics only: add the number of live slots of the current search to the device counter
 int count_active(sicp_context* h) {
   if (h->collect) {
-    h->collect->count.push_back(sicp::CountJob{h->idx.p, h->corr_n * h->corr_K, (unsigned long long*)h->d_count.p});
+    h->collect->count[h->collect->half].push_back(sicp::CountJob{h->idx.p, h->corr_n * h->corr_K, (unsigned long long*)h->d_count.p});
     return SICP_OK;
   }
   HIPCHECK(sicp::launch_count_active(h->idx.p, h->corr_n * h->corr_K, (unsigned long long*)h->d_count.p, h->stream));
@@ -1180,7 +1201,10 @@ int sicp_align_batch(sicp_handle* hs, int32_t n, const double* init_qt, double* 
   }
   JobCollector jc;
   BatchGuard guard(hs, n, one_launch ? &jc : nullptr, L->stream);
-  for (int p = 0; p < n; ++p) SICPCHECK(align_begin(hs[p], stats != nullptr));
+  for (int p = 0; p < n; ++p) {
+    jc.half = (n >= 4 && p >= n / 2) ? 1 : 0;
+    SICPCHECK(align_begin(hs[p], stats != nullptr));
+  }
   if (one_launch) SICPCHECK(flush_jobs(L, jc));
   std::vector<OuterState> o(n);
   for (int p = 0; p < n; ++p) std::memcpy(o[p].cur, init_qt + 7 * p, sizeof o[p].cur);
@@ -1194,6 +1218,7 @@ int sicp_align_batch(sicp_handle* hs, int32_t n, const double* init_qt, double* 
       ++n_active;
       std::memcpy(o[p].est, o[p].cur, sizeof o[p].est);
       if (P.mode == SICP_MODE_SEMANTIC) o[p].count++;
+      jc.half = (n >= 4 && p >= n / 2) ? 1 : 0;
       SICPCHECK(run_correspondences(hs[p], o[p].cur, P.knn, true));
     }
     if (n_active == 0) break;
@@ -1211,6 +1236,7 @@ int sicp_align_batch(sicp_handle* hs, int32_t n, const double* init_qt, double* 
       h->st.final_cost = res[p].cost;
       h->st.t_solve_ms += dt;
       h->st.total_evals += res[p].evaluations;
+      jc.half = (n >= 4 && p >= n / 2) ? 1 : 0;
       if (stats) SICPCHECK(count_active(h));
       outer_finish(P, o[p]);
     }
