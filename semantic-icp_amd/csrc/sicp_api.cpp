@@ -101,14 +101,16 @@ double now_ms() {
 
 // lock-step batch: instead of launching, the per-pair stages append their jobs here; the batch driver
 // launches each kind once for all pairs (kernels.h: *_jobs launchers), in dependency order
+constexpr int kParts = 4;  // slices of a batch whose stage sequences run on their own streams
+
 struct JobCollector {
   int knn_K = 0;
   int half = 0;  // which half of the batch the pair whose stage is running belongs to (set by the driver)
-  std::vector<sicp::KnnArgs> knn[2];
-  std::vector<sicp::CovArgs> cov[2];
-  std::vector<sicp::ProjArgs> proj[2];
-  std::vector<sicp::WeightArgs> weight[2];
-  std::vector<sicp::CountJob> count[2];
+  std::vector<sicp::KnnArgs> knn[kParts];
+  std::vector<sicp::CovArgs> cov[kParts];
+  std::vector<sicp::ProjArgs> proj[kParts];
+  std::vector<sicp::WeightArgs> weight[kParts];
+  std::vector<sicp::CountJob> count[kParts];
 };
 
 struct sicp_context {
@@ -159,6 +161,8 @@ struct sicp_context {
   int b_graph_n = 0, b_graph_maxnb = 0, b_graph_K = 0, b_graph_len = 0, b_graph_chains = 0;
   hipStream_t stream_fork = nullptr;
   hipEvent_t ev_fork = nullptr, ev_fork_done = nullptr;
+  hipStream_t part_stream[kParts] = {};
+  hipEvent_t part_fork = nullptr, part_done[kParts] = {};
   const void* b_graph_ptr = nullptr;
   std::string last_error;
   sicp_stats st;
@@ -806,32 +810,47 @@ int batch_reserve(sicp_context* h, int n) {
 }
 
 // launches what the pairs' stages collected: searches, then the kernels that consume them
+// slice of the batch a pair belongs to: SICP_BATCH_PARTS (default 4) contiguous slices of >= 2 pairs
+int batch_slice(int p, int n) {
+  static const int want = [] { const char* e = std::getenv("SICP_BATCH_PARTS"); return e ? std::atoi(e) : 4; }();
+  const int parts = std::max(1, std::min(std::min(want, kParts), n / 2));
+  return (int)((long long)p * parts / n);
+}
+
 int flush_jobs(sicp_context* h, JobCollector& jc) {
-  // The two halves of the batch run their stage sequences (searches -> covariances -> projections ->
-  // weights -> counts) on two streams: the small kernels and the search tails of one half overlap
-  // the searches of the other (+4 %).
-  const bool two = !jc.knn[1].empty() || !jc.cov[1].empty() || !jc.proj[1].empty() || !jc.weight[1].empty() || !jc.count[1].empty();
-  if (two && !h->stream_fork) {
-    HIPCHECK(hipStreamCreateWithFlags(&h->stream_fork, hipStreamNonBlocking));
-    HIPCHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-    HIPCHECK(hipEventCreateWithFlags(&h->ev_fork_done, hipEventDisableTiming));
+  // The slices of the batch run their stage sequences (searches -> covariances -> projections ->
+  // weights -> counts) on their own streams: the small kernels and the search tails of one slice
+  // overlap the searches of the others.
+  bool used[kParts];
+  int n_used = 0;
+  for (int s = 0; s < kParts; ++s) {
+    used[s] = !jc.knn[s].empty() || !jc.cov[s].empty() || !jc.proj[s].empty() || !jc.weight[s].empty() || !jc.count[s].empty();
+    n_used += used[s];
   }
-  if (two) {
-    HIPCHECK(hipEventRecord(h->ev_fork, h->stream));
-    HIPCHECK(hipStreamWaitEvent(h->stream_fork, h->ev_fork, 0));
+  const bool fork = n_used > 1 || (n_used == 1 && !used[0]);
+  if (fork) {
+    for (int s = 1; s < kParts; ++s)
+      if (used[s] && !h->part_stream[s]) {
+        HIPCHECK(hipStreamCreateWithFlags(&h->part_stream[s], hipStreamNonBlocking));
+        HIPCHECK(hipEventCreateWithFlags(&h->part_done[s], hipEventDisableTiming));
+      }
+    if (!h->part_fork) HIPCHECK(hipEventCreateWithFlags(&h->part_fork, hipEventDisableTiming));
+    HIPCHECK(hipEventRecord(h->part_fork, h->stream));
   }
-  for (int half = 0; half < 2; ++half) {
-    hipStream_t st = half ? h->stream_fork : h->stream;
-    if (!jc.knn[half].empty()) HIPCHECK(sicp::launch_bvh_knn_packet_jobs(jc.knn_K, jc.knn[half].data(), (int)jc.knn[half].size(), st));
-    if (!jc.cov[half].empty()) HIPCHECK(sicp::launch_cov_jobs(jc.cov[half].data(), (int)jc.cov[half].size(), st));
-    if (!jc.proj[half].empty()) HIPCHECK(sicp::launch_proj_jobs(jc.proj[half].data(), (int)jc.proj[half].size(), st));
-    if (!jc.weight[half].empty()) HIPCHECK(sicp::launch_em_weight_jobs(jc.weight[half].data(), (int)jc.weight[half].size(), st));
-    if (!jc.count[half].empty()) HIPCHECK(sicp::launch_count_active_jobs(jc.count[half].data(), (int)jc.count[half].size(), st));
-    jc.knn[half].clear(); jc.cov[half].clear(); jc.proj[half].clear(); jc.weight[half].clear(); jc.count[half].clear();
-  }
-  if (two) {
-    HIPCHECK(hipEventRecord(h->ev_fork_done, h->stream_fork));
-    HIPCHECK(hipStreamWaitEvent(h->stream, h->ev_fork_done, 0));
+  for (int s = 0; s < kParts; ++s) {
+    if (!used[s]) continue;
+    hipStream_t st = s ? h->part_stream[s] : h->stream;
+    if (s) HIPCHECK(hipStreamWaitEvent(st, h->part_fork, 0));
+    if (!jc.knn[s].empty()) HIPCHECK(sicp::launch_bvh_knn_packet_jobs(jc.knn_K, jc.knn[s].data(), (int)jc.knn[s].size(), st));
+    if (!jc.cov[s].empty()) HIPCHECK(sicp::launch_cov_jobs(jc.cov[s].data(), (int)jc.cov[s].size(), st));
+    if (!jc.proj[s].empty()) HIPCHECK(sicp::launch_proj_jobs(jc.proj[s].data(), (int)jc.proj[s].size(), st));
+    if (!jc.weight[s].empty()) HIPCHECK(sicp::launch_em_weight_jobs(jc.weight[s].data(), (int)jc.weight[s].size(), st));
+    if (!jc.count[s].empty()) HIPCHECK(sicp::launch_count_active_jobs(jc.count[s].data(), (int)jc.count[s].size(), st));
+    jc.knn[s].clear(); jc.cov[s].clear(); jc.proj[s].clear(); jc.weight[s].clear(); jc.count[s].clear();
+    if (s) {
+      HIPCHECK(hipEventRecord(h->part_done[s], st));
+      HIPCHECK(hipStreamWaitEvent(h->stream, h->part_done[s], 0));
+    }
   }
   return SICP_OK;
 }
@@ -1064,6 +1083,11 @@ int sicp_destroy(sicp_handle h) {
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_fork_done) (void)hipEventDestroy(h->ev_fork_done);
   if (h->stream_fork) (void)hipStreamDestroy(h->stream_fork);
+  if (h->part_fork) (void)hipEventDestroy(h->part_fork);
+  for (int s = 1; s < kParts; ++s) {
+    if (h->part_done[s]) (void)hipEventDestroy(h->part_done[s]);
+    if (h->part_stream[s]) (void)hipStreamDestroy(h->part_stream[s]);
+  }
   if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -1202,7 +1226,7 @@ int sicp_align_batch(sicp_handle* hs, int32_t n, const double* init_qt, double* 
   JobCollector jc;
   BatchGuard guard(hs, n, one_launch ? &jc : nullptr, L->stream);
   for (int p = 0; p < n; ++p) {
-    jc.half = (n >= 4 && p >= n / 2) ? 1 : 0;
+    jc.half = batch_slice(p, n);
     SICPCHECK(align_begin(hs[p], stats != nullptr));
   }
   if (one_launch) SICPCHECK(flush_jobs(L, jc));
@@ -1218,7 +1242,7 @@ int sicp_align_batch(sicp_handle* hs, int32_t n, const double* init_qt, double* 
       ++n_active;
       std::memcpy(o[p].est, o[p].cur, sizeof o[p].est);
       if (P.mode == SICP_MODE_SEMANTIC) o[p].count++;
-      jc.half = (n >= 4 && p >= n / 2) ? 1 : 0;
+      jc.half = batch_slice(p, n);
       SICPCHECK(run_correspondences(hs[p], o[p].cur, P.knn, true));
     }
     if (n_active == 0) break;
@@ -1236,7 +1260,7 @@ int sicp_align_batch(sicp_handle* hs, int32_t n, const double* init_qt, double* 
       h->st.final_cost = res[p].cost;
       h->st.t_solve_ms += dt;
       h->st.total_evals += res[p].evaluations;
-      jc.half = (n >= 4 && p >= n / 2) ? 1 : 0;
+      jc.half = batch_slice(p, n);
       if (stats) SICPCHECK(count_active(h));
       outer_finish(P, o[p]);
     }
