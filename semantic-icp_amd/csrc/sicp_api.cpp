@@ -105,7 +105,7 @@ constexpr int kParts = 4;  // slices of a batch whose stage sequences run on the
 
 struct JobCollector {
   int knn_K = 0;
-  int half = 0;  // which half of the batch the pair whose stage is running belongs to (set by the driver)
+  int slice = 0;  // slice of the batch the pair whose stage is running belongs to (set by the driver)
   std::vector<sicp::KnnArgs> knn[kParts];
   std::vector<sicp::CovArgs> cov[kParts];
   std::vector<sicp::ProjArgs> proj[kParts];
@@ -343,7 +343,7 @@ int run_nn(sicp_context* h, int K, const Cloud& Qc, int q_begin, int q_count, co
     static const bool lane_per_query = std::getenv("SICP_KNN_LANE_PER_QUERY") != nullptr;  // A/B aid
     if (h->collect) {  // lock-step batch (packet search, no profiling: checked by the driver)
       h->collect->knn_K = K;
-      h->collect->knn[h->collect->half].push_back(a);
+      h->collect->knn[h->collect->slice].push_back(a);
       return SICP_OK;
     }
     KernelTimer kt(h, stream == h->stream ? timer_bit : 0);
@@ -429,7 +429,7 @@ int ensure_proj(sicp_context* h, Cloud& c) {
   sicp::ProjArgs a;
   a.n = c.n; a.C = P.num_classes;
   a.hist = c.hist.p; a.cm = h->d_cm.p; a.hval = h->d_hval.p; a.proj = c.proj.p;
-  if (h->collect) h->collect->proj[h->collect->half].push_back(a);
+  if (h->collect) h->collect->proj[h->collect->slice].push_back(a);
   else HIPCHECK(sicp::launch_proj(a, h->stream));
   c.proj_valid = true;
   return SICP_OK;
@@ -462,7 +462,7 @@ int compute_features(sicp_context* h, Cloud& c, bool with_hist, hipStream_t stre
   a.float_products = P.quirk_float_products;
   a.nx = c.nx.p; a.ny = c.ny.p; a.nz = c.nz.p;
   a.hist = with_hist ? c.hist.p : nullptr;
-  if (h->collect) h->collect->cov[h->collect->half].push_back(a);
+  if (h->collect) h->collect->cov[h->collect->slice].push_back(a);
   else HIPCHECK(sicp::launch_cov(a, stream));
   c.feat_valid = true;
   c.proj_valid = false;
@@ -549,7 +549,7 @@ int run_correspondences(sicp_context* h, const double* qt, int K, bool weights) 
     a.one_m_eps = 1.0 - P.epsilon;
     a.bool_probability = P.quirk_bool_probability;
     a.w = h->w.p;
-    if (h->collect) h->collect->weight[h->collect->half].push_back(a);
+    if (h->collect) h->collect->weight[h->collect->slice].push_back(a);
     else HIPCHECK(sicp::launch_em_weight(a, h->stream));
     h->st.weight_launches += 1;
     h->st.weight_kernel_ms += kt.stop();
@@ -960,7 +960,7 @@ int run_solve_batch(sicp_context* h, sicp_handle* hs, int n, const char* active,
 // statistics only: add the number of live slots of the current search to the device counter
 int count_active(sicp_context* h) {
   if (h->collect) {
-    h->collect->count[h->collect->half].push_back(sicp::CountJob{h->idx.p, h->corr_n * h->corr_K, (unsigned long long*)h->d_count.p});
+    h->collect->count[h->collect->slice].push_back(sicp::CountJob{h->idx.p, h->corr_n * h->corr_K, (unsigned long long*)h->d_count.p});
     return SICP_OK;
   }
   HIPCHECK(sicp::launch_count_active(h->idx.p, h->corr_n * h->corr_K, (unsigned long long*)h->d_count.p, h->stream));
@@ -1226,7 +1226,7 @@ int sicp_align_batch(sicp_handle* hs, int32_t n, const double* init_qt, double* 
   JobCollector jc;
   BatchGuard guard(hs, n, one_launch ? &jc : nullptr, L->stream);
   for (int p = 0; p < n; ++p) {
-    jc.half = batch_slice(p, n);
+    jc.slice = batch_slice(p, n);
     SICPCHECK(align_begin(hs[p], stats != nullptr));
   }
   if (one_launch) SICPCHECK(flush_jobs(L, jc));
@@ -1242,7 +1242,7 @@ int sicp_align_batch(sicp_handle* hs, int32_t n, const double* init_qt, double* 
       ++n_active;
       std::memcpy(o[p].est, o[p].cur, sizeof o[p].est);
       if (P.mode == SICP_MODE_SEMANTIC) o[p].count++;
-      jc.half = batch_slice(p, n);
+      jc.slice = batch_slice(p, n);
       SICPCHECK(run_correspondences(hs[p], o[p].cur, P.knn, true));
     }
     if (n_active == 0) break;
@@ -1260,7 +1260,7 @@ int sicp_align_batch(sicp_handle* hs, int32_t n, const double* init_qt, double* 
       h->st.final_cost = res[p].cost;
       h->st.t_solve_ms += dt;
       h->st.total_evals += res[p].evaluations;
-      jc.half = batch_slice(p, n);
+      jc.slice = batch_slice(p, n);
       if (stats) SICPCHECK(count_active(h));
       outer_finish(P, o[p]);
     }
