@@ -6,7 +6,7 @@ Metric (BASELINE.json): correspondences/sec (+ ms per outer ICP iteration) for E
 subsampled to exactly 100 000 x 100 000 points -- the metric point of configs[1].
 
 A "step" registers one batch of independent scan pairs on each GPU: `--pairs-in-flight` S pairs
-(default 16), each a complete align() (covariances of both clouds + every outer ICP iteration:
+(default 32), each a complete align() (covariances of both clouds + every outer ICP iteration:
 transform -> kNN -> EM weights -> inner LM solve) on its own handle, with all clouds already
 resident in HBM when the timed region starts.  Independent pairs are the reference's unit of work
 (exec/kitti_eval.cc loops over them) and the north star shards them across GPUs.  By default the S
@@ -56,7 +56,7 @@ def parse_args():
     ap.add_argument("--nn-method", type=int, default=None, help="0 brute force, 1 box tree (default: library default)")
     ap.add_argument("--lm-on-device", type=int, default=None, help="0 host LM loop, 1 device-resident (default: library default)")
     ap.add_argument("--lm-batch", type=int, default=None)
-    ap.add_argument("--pairs-in-flight", type=int, default=16,
+    ap.add_argument("--pairs-in-flight", type=int, default=32,
                     help="independent scan pairs registered concurrently on each GPU (one handle + host thread each)")
     ap.add_argument("--profile", type=int, default=0,
                     help="SICP_PROFILE_* mask applied inside the timed region (default 0: the roofline kernels are timed with "
@@ -290,29 +290,33 @@ def main():
             # region runs it as accumulate_batch_kernel, one launch per LM evaluation for all S pairs of
             # the lock-step batch; here the same launch is timed alone with HIP events on its stream
             # (sicp_accumulate_batch: 50 launches back to back between two events, 6 rounds)
-            for e in engines:
+            # (the batched solve graph has two chains for S >= 4 -- the halves of the batch -- so one launch of the
+            # timed region covers S/2 pairs; that launch shape is what is timed here)
+            chains = 2 if (S >= 4 and args.concurrency == "lockstep" and os.environ.get("SICP_BATCH_CHAINS", "2") != "1") else 1
+            L = S // chains if args.concurrency == "lockstep" else 1
+            for e in engines[:L]:
                 e.correspondences(qt)
-            qts = np.tile(qt, (S, 1))
+            qts = np.tile(qt, (L, 1))
             acc_ms_l = []
             for _ in range(8):
-                _, ms = sicp.accumulate_batch(engines, qts, repeat=50)
+                _, ms = sicp.accumulate_batch(engines[:L], qts, repeat=50)
                 acc_ms_l.append(ms)
             acc_us = 1e3 * float(np.mean(acc_ms_l[2:]))
             n_acc = 50 * len(acc_ms_l[2:])
-            acc_bytes = S * (24 * n + 32 * K_CORR * n)      # pairs x (24*N_s + 32*K*N_s)
+            acc_bytes = L * (24 * n + 32 * K_CORR * n)      # pairs per launch x (24*N_s + 32*K*N_s)
             acc_gbs = acc_bytes / (acc_us * 1e-6) / 1e9
             out["roofline"] = {
                 "kernel": f"accumulate_batch_kernel<K=4> (Mahalanobis residual + 6-DoF Jacobian -> 28 doubles per pair; one launch per LM "
-                          f"evaluation covers the {S} pairs of the batch, {evals / max(1, outer):.1f} launches per outer iteration)",
+                          f"evaluation covers {L} pairs ({chains} concurrent chain(s) of the {S}-pair batch), {evals / max(1, outer):.1f} launches per chain and outer iteration)",
                 "bound": "hbm", "achieved": acc_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": acc_gbs / HBM_PEAK_GBS,
                 # PMC passes (profiles/): FETCH_SIZE + WRITE_SIZE per launch, raw (the guide's x2 FETCH correction is
                 # calibrated for 16-B streams only); filled from the committed profile for the default configuration
-                "traffic": PMC_TRAFFIC_BYTES.get((n, S)),
+                "traffic": PMC_TRAFFIC_BYTES.get((n, L)),
                 "avg_launch_us": acc_us, "launches_timed": n_acc, "algorithmic_bytes_per_launch": acc_bytes,
-                "pairs_per_launch": S,
+                "pairs_per_launch": L, "concurrent_chains": chains,
                 "note": "FP64 issue first (PMC: 245 VALU instructions per correspondence incl. reductions "
-                        f"-> {S * 4e5 * 245 / (1024 * 16 * 2.4e9) * 1e6:.0f} us on 1024 SIMDs), HBM second (what the launch really moves, f64 normals and "
-                        f"weights included: ~12 MB per pair -> {S * 12e6 / 6.3e12 * 1e6:.0f} us at the 6.3 TB/s achievable); two waves per SIMD "
+                        f"-> {L * 4e5 * 245 / (1024 * 16 * 2.4e9) * 1e6:.0f} us on 1024 SIMDs), HBM second (what the launch really moves, f64 normals and "
+                        f"weights included: ~12 MB per pair -> {L * 12e6 / 6.3e12 * 1e6:.0f} us at the 6.3 TB/s achievable); two waves per SIMD "
                         "(180 VGPRs); DESIGN.md section 3",
             }
             avg_ms = nn_ms / nn_launches

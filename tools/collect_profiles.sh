@@ -14,7 +14,7 @@ stats() {  # tag, bench args...
   [ -n "$f" ] && cp "$f" gpurun_out/${pre}_kernel_stats_${tag}.csv
   rm -rf gpurun_out/cp_$tag gpurun_out/cp_$tag.err
 }
-stats lockstep16
+stats lockstep32
 stats single_pair --pairs-in-flight 1
 pmc() {  # counter
   local c=$1
