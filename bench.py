@@ -37,8 +37,8 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 # (points, pairs per launch) -> FETCH_SIZE + WRITE_SIZE bytes per accumulate_batch launch, raw counter values from
-# profiles/r01_final_pmc_hbm_traffic.csv (117805.8 KB + 2773.6 KB)
-PMC_TRAFFIC_BYTES = {(100_000, 16): (117805.8 + 2773.6) * 1024}
+# profiles/r01_final_pmc_hbm_traffic.csv (16 pairs: 117805.8 KB + 2773.6 KB; 32 pairs: 235500 KB + 5545 KB)
+PMC_TRAFFIC_BYTES = {(100_000, 16): (117805.8 + 2773.6) * 1024, (100_000, 32): (235500.0 + 5545.0) * 1024}
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 VALU_PAIR_PEAK = 9.8e12        # 78.6e12 FP32 lane-ops/s / 8 lane-ops per pair
 N_POINTS = 100_000
@@ -290,9 +290,9 @@ def main():
             # region runs it as accumulate_batch_kernel, one launch per LM evaluation for all S pairs of
             # the lock-step batch; here the same launch is timed alone with HIP events on its stream
             # (sicp_accumulate_batch: 50 launches back to back between two events, 6 rounds)
-            # (the batched solve graph has two chains for S >= 4 -- the halves of the batch -- so one launch of the
-            # timed region covers S/2 pairs; that launch shape is what is timed here)
-            chains = 2 if (S >= 4 and args.concurrency == "lockstep" and os.environ.get("SICP_BATCH_CHAINS", "2") != "1") else 1
+            # (with SICP_BATCH_CHAINS=2 the batched solve graph has two chains -- the halves of the batch -- and one
+            # launch of the timed region covers S/2 pairs; the launch shape of the timed region is what is timed here)
+            chains = 2 if (S >= 4 and args.concurrency == "lockstep" and os.environ.get("SICP_BATCH_CHAINS", "1") == "2") else 1
             L = S // chains if args.concurrency == "lockstep" else 1
             for e in engines[:L]:
                 e.correspondences(qt)

@@ -900,10 +900,12 @@ int run_solve_batch(sicp_context* h, sicp_handle* hs, int n, const char* active,
   HIPCHECK(hipMemcpyAsync(h->d_bstates.p, h->h_bstates, sizeof(sicp::LmState) * n, hipMemcpyHostToDevice, h->stream));
   const int len = P.lm_batch > 0 ? P.lm_batch : 12;
   const int K = hs[0]->corr_K;
-  // The graph only depends on the grid and on the address of the argument array.  With four or more
-  // pairs it has two independent chains (the halves of the batch), so that one half's one-wave-per-
-  // pair LM step overlaps the other half's accumulate launch (+3 %; SICP_BATCH_CHAINS=1: one chain).
-  static const int chains_wanted = [] { const char* e = std::getenv("SICP_BATCH_CHAINS"); return e ? std::atoi(e) : 2; }();
+  // The graph only depends on the grid and on the address of the argument array.  SICP_BATCH_CHAINS=2
+  // gives it two independent chains (the halves of the batch), so that one half's one-wave-per-pair
+  // LM step overlaps the other half's accumulate launch: +3 % throughput, but two accumulate
+  // launches then run concurrently and neither has a clean duration to hold against a roofline, so
+  // the default is one chain.
+  static const int chains_wanted = [] { const char* e = std::getenv("SICP_BATCH_CHAINS"); return e ? std::atoi(e) : 1; }();
   const int chains = (chains_wanted >= 2 && n >= 4) ? 2 : 1;
   if (chains == 2 && !h->stream_fork) {
     HIPCHECK(hipStreamCreateWithFlags(&h->stream_fork, hipStreamNonBlocking));

@@ -19,7 +19,7 @@ stats single_pair --pairs-in-flight 1
 pmc() {  # counter
   local c=$1
   rm -rf gpurun_out/cp_pmc
-  timeout 600 rocprofv3 --pmc $c --output-format csv -d gpurun_out/cp_pmc -- python3 tools/bench_acc_batch.py 16 > gpurun_out/cp_pmc.log 2>&1
+  timeout 600 rocprofv3 --pmc $c --output-format csv -d gpurun_out/cp_pmc -- python3 tools/bench_acc_batch.py 32 > gpurun_out/cp_pmc.log 2>&1
   local f=$(find gpurun_out/cp_pmc -name '*counter_collection.csv' 2>/dev/null | head -1)
   [ -n "$f" ] && python3 - "$f" $c <<'PY'
 import csv, sys, collections
@@ -34,7 +34,7 @@ PY
   rm -rf gpurun_out/cp_pmc gpurun_out/cp_pmc.log
 }
 {
-  echo "# rocprofv3 --pmc <counter> -- python3 tools/bench_acc_batch.py 16   (one counter per pass; values in KB per dispatch)"
+  echo "# rocprofv3 --pmc <counter> -- python3 tools/bench_acc_batch.py 32   (one counter per pass; values in KB per dispatch)"
   echo "counter,kernel,dispatches,mean_per_dispatch"
   pmc FETCH_SIZE
   pmc WRITE_SIZE
