@@ -110,6 +110,34 @@ __device__ __forceinline__ void key_insert<20>(u64 (&bk)[20], u64 key) {
 }
 #undef SICP_KI_STEP
 
+// compare-exchange of two keys (v_min_f64 / v_max_f64, see above)
+__device__ __forceinline__ void key_cswap(u64& a, u64& b) {
+  const double x = __longlong_as_double((long long)a), y = __longlong_as_double((long long)b);
+  double lo, hi;
+  asm("v_min_f64 %0, %2, %3\n\tv_max_f64 %1, %2, %3" : "=&v"(lo), "=&v"(hi) : "v"(x), "v"(y));
+  a = (u64)__double_as_longlong(lo);
+  b = (u64)__double_as_longlong(hi);
+}
+
+// Batcher's odd-even merge sort of 16 keys (63 compare-exchanges, 2 instructions each)
+template <int K>
+__device__ __forceinline__ void key_sort16(u64 (&bk)[K]) {
+  static_assert(K >= 16, "sorts the first 16 entries");
+#define SICP_CSWAP(i, j) key_cswap(bk[i], bk[j]);
+  SICP_CSWAP(0, 1) SICP_CSWAP(2, 3) SICP_CSWAP(0, 2) SICP_CSWAP(1, 3) SICP_CSWAP(1, 2) SICP_CSWAP(4, 5)
+  SICP_CSWAP(6, 7) SICP_CSWAP(4, 6) SICP_CSWAP(5, 7) SICP_CSWAP(5, 6) SICP_CSWAP(0, 4) SICP_CSWAP(2, 6)
+  SICP_CSWAP(2, 4) SICP_CSWAP(1, 5) SICP_CSWAP(3, 7) SICP_CSWAP(3, 5) SICP_CSWAP(1, 2) SICP_CSWAP(3, 4)
+  SICP_CSWAP(5, 6) SICP_CSWAP(8, 9) SICP_CSWAP(10, 11) SICP_CSWAP(8, 10) SICP_CSWAP(9, 11) SICP_CSWAP(9, 10)
+  SICP_CSWAP(12, 13) SICP_CSWAP(14, 15) SICP_CSWAP(12, 14) SICP_CSWAP(13, 15) SICP_CSWAP(13, 14) SICP_CSWAP(8, 12)
+  SICP_CSWAP(10, 14) SICP_CSWAP(10, 12) SICP_CSWAP(9, 13) SICP_CSWAP(11, 15) SICP_CSWAP(11, 13) SICP_CSWAP(9, 10)
+  SICP_CSWAP(11, 12) SICP_CSWAP(13, 14) SICP_CSWAP(0, 8) SICP_CSWAP(4, 12) SICP_CSWAP(4, 8) SICP_CSWAP(2, 10)
+  SICP_CSWAP(6, 14) SICP_CSWAP(6, 10) SICP_CSWAP(2, 4) SICP_CSWAP(6, 8) SICP_CSWAP(10, 12) SICP_CSWAP(1, 9)
+  SICP_CSWAP(5, 13) SICP_CSWAP(5, 9) SICP_CSWAP(3, 11) SICP_CSWAP(7, 15) SICP_CSWAP(7, 11) SICP_CSWAP(3, 5)
+  SICP_CSWAP(7, 9) SICP_CSWAP(11, 13) SICP_CSWAP(1, 2) SICP_CSWAP(3, 4) SICP_CSWAP(5, 6) SICP_CSWAP(7, 8)
+  SICP_CSWAP(9, 10) SICP_CSWAP(11, 12) SICP_CSWAP(13, 14)
+#undef SICP_CSWAP
+}
+
 // a fresh list; the asm keeps the compiler from treating the K equal constants as one value (it
 // would share one register among them and copy at every control-flow join of the first scans)
 template <int K>
@@ -635,8 +663,27 @@ __device__ __forceinline__ void knn_packet_body(const KnnArgs& a, int wg, int n_
   }
   {
     const int l0 = seed * kFan, l1 = min(l0 + kFan, n_leaf);  // a one-leaf tree: leaf 0
+    if (K >= 16 && l1 - l0 == kFan) {
+      // K = 20: the 16 seed candidates of a lane all enter its (empty) list.  Sixteen insertions are
+      // 16 x 39 instructions; writing them into the first 16 slots and sorting those with a
+      // 63-comparator network is 126 (same list: the keys are unique up to identical padding keys).
+      if constexpr (K >= 16) {
+#pragma unroll
+        for (int l = 0; l < kFan; ++l) {
+          const float4* __restrict__ lp = pts + (size_t)(l0 + l) * kLeaf;
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            const float4 t = lp[4 * p];
+            bk[4 * l + p] = make_key(l2_simple(px, py, pz, t.x, t.y, t.z), __float_as_uint(t.w));
+          }
+        }
+        key_sort16<K>(bk);
+        wd = quad_bound<K>(bk);
+      }
+    } else {
 #pragma unroll 1
-    for (int l = l0; l < l1; ++l) scan_leaf_quad<K>(pts + (size_t)l * kLeaf, px, py, pz, bk, wd);
+      for (int l = l0; l < l1; ++l) scan_leaf_quad<K>(pts + (size_t)l * kLeaf, px, py, pz, bk, wd);
+    }
   }
 
   // --- shared depth-first walk: all of this state is wave-uniform.  Two nested loops: the inner
