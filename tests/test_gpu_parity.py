@@ -525,3 +525,26 @@ def test_align_batch_per_pair_launch_path(knob):
     finally:
         for e in engines:
             e.close()
+
+
+def test_align_batch_with_tiny_and_ragged_pairs():
+    """A batch mixing a one-leaf cloud, a cloud whose size is not a multiple of the leaf / group sizes
+    and a normal one: every job kernel sees q_count and tree depths that differ inside one launch."""
+    rng = np.random.default_rng(5)
+    ident = np.array([0, 0, 0, 1, 0, 0, 0.0])
+    engines, singles = [], []
+    try:
+        for n in (25, 333, 4000, 61):
+            tgt = rng.uniform(0, 4, (n, 3)).astype(np.float32)
+            tgt[:, 2] *= 0.05  # a slab: well-conditioned normals
+            R = Rotation.from_rotvec([0.01, -0.02, 0.015]).as_matrix()
+            src = ((tgt.astype(np.float64) - [0.03, 0.01, 0.0]) @ R).astype(np.float32)
+            e, p = make_engine(sicp.MODE_GICP)
+            e.set_source(src, None); e.set_target(tgt, None)
+            engines.append(e)
+            singles.append(e.align(ident))
+        for (qb, sb), (q1, s1) in zip(sicp.align_batch(engines), singles):
+            assert np.array_equal(qb, q1) and sb["outer_iters"] == s1["outer_iters"]
+    finally:
+        for e in engines:
+            e.close()
