@@ -548,3 +548,39 @@ def test_align_batch_with_tiny_and_ragged_pairs():
     finally:
         for e in engines:
             e.close()
+
+
+def test_knn_with_seed_hints_is_still_exact():
+    """The second and later searches of the same queries start from the previous result (seed hint,
+    trusted only while close).  Whatever the seed, the result must stay bit-identical to the kd-tree."""
+    ps, ls, pt, lt, T, cm = synth.lidar_pair(seed=9, n_points=20000)
+    e, p = make_engine(sicp.MODE_EM, 11, cm)
+    try:
+        e.set_source(ps, ls); e.set_target(pt, lt)
+        poses = [np.array([0, 0, 0, 1, 0, 0, 0.0]), mat_to_qt(synth.pose_matrix(0.2, (0, 0, 1), (0.02, 0.0, 0.0))),
+                 mat_to_qt(T), mat_to_qt(synth.pose_matrix(25.0, (0, 0, 1), (3.0, -2.0, 0.5))),  # far jump: stale hints
+                 mat_to_qt(T)]
+        for qt in poses:
+            idx, d2, _ = e.correspondences(qt)
+            q = O.transform_points(O.se3_matrix(qt), ps)
+            oi, od = O.knn(q, pt, 4)
+            want = np.where(od < np.float32(250), oi, -1)
+            assert np.array_equal(idx, want) and np.array_equal(d2, od)
+    finally:
+        e.close()
+
+
+def test_align_batch_at_metric_size_equals_single():
+    ps, ls, pt, lt, T, cm = synth.lidar_pair(seed=2, n_points=100000)
+    engines = []
+    try:
+        for k in range(4):
+            e, p = make_engine(sicp.MODE_EM, 11, cm)
+            e.set_source(ps, ls); e.set_target(pt, lt)
+            engines.append(e)
+        q1, s1 = engines[0].align()
+        for qb, sb in sicp.align_batch(engines):
+            assert np.array_equal(qb, q1) and sb["outer_iters"] == s1["outer_iters"] and sb["total_lm_iters"] == s1["total_lm_iters"]
+    finally:
+        for e in engines:
+            e.close()
