@@ -809,7 +809,6 @@ int batch_reserve(sicp_context* h, int n) {
   return SICP_OK;
 }
 
-// launches what the pairs' stages collected: searches, then the kernels that consume them
 // slice of the batch a pair belongs to: SICP_BATCH_PARTS (default 4) contiguous slices of >= 2 pairs
 int batch_slice(int p, int n) {
   static const int want = [] { const char* e = std::getenv("SICP_BATCH_PARTS"); return e ? std::atoi(e) : 4; }();
@@ -817,6 +816,7 @@ int batch_slice(int p, int n) {
   return (int)((long long)p * parts / n);
 }
 
+// launches what the pairs' stages collected: searches, then the kernels that consume them
 int flush_jobs(sicp_context* h, JobCollector& jc) {
   // The slices of the batch run their stage sequences (searches -> covariances -> projections ->
   // weights -> counts) on their own streams: the small kernels and the search tails of one slice
