@@ -228,6 +228,16 @@ def test_scenenet_eval_headless_rows_and_fused_labels(tmp_path):
                 assert np.allclose(fp, ps, atol=1e-5)
                 olab = O.fused_labels(p, ps, ls, pt, lt, cm, oq)
                 assert np.mean(fl == olab) > 0.999
+    # -b 2: both frame pairs registered together (alignBatch): identical rows and label files
+    prefix2 = str(tmp_path / "b_")
+    r2 = subprocess.run([exe, "-s", str(d), "-t", gt, "-m", cmf, "-o", prefix2, "-b", "2"], capture_output=True, text=True, timeout=900)
+    assert r2.returncode == 0, r2.stderr
+    for fname in ("EMICPscenenet.csv", "se3GICPscenenet.csv"):
+        one = [line.split(",") for line in open(prefix + fname) if line.strip()]
+        two = [line.split(",") for line in open(prefix2 + fname) if line.strip()]
+        assert len(one) == len(two) and all(ra[:5] == rb[:5] and ra[6:] == rb[6:] for ra, rb in zip(one, two))
+    for k in (1, 2):
+        assert open(f"{prefix}{k}.pcd").read() == open(f"{prefix2}{k}.pcd").read()
 
 
 # ------------------------------------------------------------------------------------------------
