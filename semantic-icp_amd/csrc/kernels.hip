@@ -1044,8 +1044,11 @@ __device__ __forceinline__ double log_ge1(double x) {
   return dk * 6.93147180369123816490e-01 - ((hfsq - (sq * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
 }
 
-// loss_eval for the accumulate kernels: g0 = sqrt(v) and g1 = 1 / (2 g0) both come from one
-// reciprocal square root (a square root and a division less per correspondence; ~1 ulp)
+// rho0 / rho1 of the reference's loss stacks at s = r^2 (em_icp.hpp:109-117, gicp.hpp:98-104,
+// semantic_icp.hpp:96; Ceres CauchyLoss/ScaledLoss/ComposedLoss, sqloss.h); b = a^2, c = 1/b.  rho2 < 0
+// for all of them, so Ceres' Corrector scales residual and Jacobian by sqrt(rho1).  g0 = sqrt(v) and
+// g1 = 1 / (2 g0) both come from one reciprocal square root (a square root and a division less per
+// correspondence; ~1 ulp), the logarithm is log_ge1.
 __device__ __forceinline__ void loss_eval_acc(const LossArgs& L, double b, double c, double s, double w, double& rho0, double& rho1) {
 #pragma clang fp contract(fast)
   if (L.use_sqloss) {
@@ -1058,28 +1061,6 @@ __device__ __forceinline__ void loss_eval_acc(const LossArgs& L, double b, doubl
   } else {
     const double sum = 1.0 + s * c, invs = rcp_newton(sum);
     rho0 = b * log_ge1(sum);
-    rho1 = fmax(2.2250738585072014e-308, invs);
-  }
-}
-
-// rho0 / rho1 of the reference's loss stacks at s = r^2 (em_icp.hpp:109-117,
-// gicp.hpp:98-104, semantic_icp.hpp:96; Ceres CauchyLoss/ScaledLoss/ComposedLoss, sqloss.h).
-// rho2 < 0 for all of them, so Ceres' Corrector scales residual and Jacobian by sqrt(rho1).
-__device__ __forceinline__ void loss_eval(const LossArgs& L, double s, double w, double& rho0, double& rho1) {
-#pragma clang fp contract(fast)
-  const double b = L.cauchy_a * L.cauchy_a, c = 1.0 / b;
-  if (L.use_sqloss) {
-    const double v = s + 2.220446049250313e-16;  // std::numeric_limits<double>::epsilon()
-    const double g0 = sqrt(v), g1 = 1.0 / (2.0 * g0);
-    const double sum = 1.0 + g0 * c, invs = 1.0 / sum;
-    double f0 = b * log(sum);
-    double f1 = fmax(2.2250738585072014e-308, invs);
-    f0 *= w; f1 *= w;  // ScaledLoss (w == 1 outside EM)
-    rho0 = f0;
-    rho1 = f1 * g1;
-  } else {
-    const double sum = 1.0 + s * c, invs = 1.0 / sum;
-    rho0 = b * log(sum);
     rho1 = fmax(2.2250738585072014e-308, invs);
   }
 }
@@ -1523,7 +1504,7 @@ __global__ __launch_bounds__(64) void finalize_kernel(const double* partials, in
   if (threadIdx.x < 28) {
     double v = 0.0;
 #pragma unroll
-    for (int k = 0; k < 28; ++k) v = threadIdx.x == k ? o[k] : v;
+    for (int k = 0; k < 28; ++k) v = (int)threadIdx.x == k ? o[k] : v;
     out28[threadIdx.x] = v;
   }
 }
@@ -1565,7 +1546,7 @@ __global__ __launch_bounds__(64) void finalize_batch_kernel(const BatchArgs* __r
   if (threadIdx.x < 28) {
     double v = 0.0;
 #pragma unroll
-    for (int k = 0; k < 28; ++k) v = threadIdx.x == k ? o[k] : v;
+    for (int k = 0; k < 28; ++k) v = (int)threadIdx.x == k ? o[k] : v;
     out28[28 * blockIdx.x + threadIdx.x] = v;
   }
 }
