@@ -10,8 +10,8 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libsicp.so")
-SOURCES = ["kernels.hip", "build_tree.hip", "sicp_api.cpp"]
-HEADERS = ["kernels.h", "lm.hpp", "se3.hpp", "bvh.hpp", "build_tree.h"]
+SOURCES = ["knn_kernels.hip", "feature_kernels.hip", "solve_kernels.hip", "build_tree.hip", "sicp_api.cpp"]
+HEADERS = ["kernels.h", "device_geometry.hpp", "lm.hpp", "se3.hpp", "bvh.hpp", "build_tree.h"]
 ARCH = "gfx950"
 
 

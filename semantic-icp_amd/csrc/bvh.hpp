@@ -34,7 +34,7 @@ struct TreeLevels {
 // curve", 2004: axes -> transposed index, then bit interleave).  Unlike Morton order, cells that
 // are consecutive on the curve are always face neighbours, so LEAF consecutive points (and the
 // 64-point seed group) are always spatially compact.  SICP_HD is empty on the host and
-// __host__ __device__ when kernels.hip includes this header, so both sides share one definition.
+// __host__ __device__ when the kernel files include this header, so both sides share one definition.
 #ifndef SICP_HD
 #define SICP_HD
 #endif

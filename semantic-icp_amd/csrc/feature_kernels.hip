@@ -1,0 +1,337 @@
+// feature_kernels.hip -- per-point covariance normals and label histograms, the EM label-posterior
+// weights, fused labels and the small utility kernels (gfx950, wave64).
+//
+//   cov_kernel       : ComputeCovariances body                 em_icp.hpp:298-340
+//   proj / em_weight : label posterior * Probability           em_icp.hpp:77-89,108
+//   fused_label      : getFusedLabels                          em_icp.hpp:224-266
+//   transform_float  : the final_cloud of align()              em_icp.hpp:192-198
+//
+// Design notes (MI355X): clouds live in HBM in Hilbert-curve order (SoA float32 + a packed float4
+// x,y,z,caller-index copy for the search kernels).  Top-K lists are 64-bit (distance, caller index)
+// keys in statically indexed VGPRs.  No floating-point atomics anywhere, so every result is
+// run-to-run reproducible.  Nothing here is GEMM shaped: no MFMA.  All three kernel files are
+// compiled with -ffp-contract=off; fused multiply-adds are re-enabled per function where the float64
+// algebra only needs tolerance-level parity.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#define SICP_HD __host__ __device__
+#include "kernels.h"
+#include "device_geometry.hpp"
+
+namespace sicp {
+// ------------------------------------------------------------------------------------------
+// covariance / normal / label histogram from the k-neighbour lists   (em_icp.hpp:298-340)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void jacobi_rotate(double (&A)[3][3], double (&V)[3][3], int p, int q) {
+  const double apq = A[p][q];
+  if (apq == 0.0) return;
+  const double tau = (A[q][q] - A[p][p]) / (2.0 * apq);
+  const double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+  const double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double akp = A[k][p], akq = A[k][q];
+    A[k][p] = c * akp - s * akq;
+    A[k][q] = s * akp + c * akq;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double apk = A[p][k], aqk = A[q][k];
+    A[p][k] = c * apk - s * aqk;
+    A[q][k] = s * apk + c * aqk;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double vkp = V[k][p], vkq = V[k][q];
+    V[k][p] = c * vkp - s * vkq;
+    V[k][q] = s * vkp + c * vkq;
+  }
+}
+
+__device__ __forceinline__ void cov_body(const CovArgs& a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  double mean0 = 0, mean1 = 0, mean2 = 0;
+  double c00 = 0, c10 = 0, c11 = 0, c20 = 0, c21 = 0, c22 = 0;
+  const int* nn = a.nn_stride > 0 ? a.nn + i : a.nn + (size_t)i * a.k;
+  const size_t js = a.nn_stride > 0 ? (size_t)a.nn_stride : 1;
+  for (int j = 0; j < a.k; ++j) {
+    const int g = nn[j * js];
+    if (g < 0) continue;
+    const float x = a.x[g], y = a.y[g], z = a.z[g];
+    mean0 += (double)x; mean1 += (double)y; mean2 += (double)z;
+    if (a.float_products) {
+      // quirk Q2: pt.y*pt.x is a float32 product (em_icp.hpp:307-314)
+      c00 += (double)__fmul_rn(x, x);
+      c10 += (double)__fmul_rn(y, x);
+      c11 += (double)__fmul_rn(y, y);
+      c20 += (double)__fmul_rn(z, x);
+      c21 += (double)__fmul_rn(z, y);
+      c22 += (double)__fmul_rn(z, z);
+    } else {
+      const double dx = x, dy = y, dz = z;
+      c00 += dx * dx; c10 += dy * dx; c11 += dy * dy;
+      c20 += dz * dx; c21 += dz * dy; c22 += dz * dz;
+    }
+  }
+  // quirk Q3: divide by k whatever the neighbour count (em_icp.hpp:317,320)
+  const double kk = (double)a.k;
+  mean0 /= kk; mean1 /= kk; mean2 /= kk;
+  double A[3][3], V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  A[0][0] = __dsub_rn(c00 / kk, __dmul_rn(mean0, mean0));
+  A[1][0] = A[0][1] = __dsub_rn(c10 / kk, __dmul_rn(mean1, mean0));
+  A[1][1] = __dsub_rn(c11 / kk, __dmul_rn(mean1, mean1));
+  A[2][0] = A[0][2] = __dsub_rn(c20 / kk, __dmul_rn(mean2, mean0));
+  A[2][1] = A[1][2] = __dsub_rn(c21 / kk, __dmul_rn(mean2, mean1));
+  A[2][2] = __dsub_rn(c22 / kk, __dmul_rn(mean2, mean2));
+  // stand-in for Eigen::JacobiSVD(ComputeFullU) on a symmetric matrix: cyclic Jacobi;
+  // singular values = |eigenvalues|, the "normal" is the column of smallest |eigenvalue|
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    const double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+    const double dia = A[0][0] * A[0][0] + A[1][1] * A[1][1] + A[2][2] * A[2][2];
+    if (off <= 1e-300 || off <= 1e-34 * dia) break;
+    jacobi_rotate(A, V, 0, 1);
+    jacobi_rotate(A, V, 0, 2);
+    jacobi_rotate(A, V, 1, 2);
+  }
+  const double e0 = fabs(A[0][0]), e1 = fabs(A[1][1]), e2 = fabs(A[2][2]);
+  // last column after a stable descending sort by |eigenvalue| (ties keep the later column)
+  int col = 0;
+  double em = e0;
+  if (e1 <= em) { em = e1; col = 1; }
+  if (e2 <= em) { em = e2; col = 2; }
+  double nx = col == 0 ? V[0][0] : (col == 1 ? V[0][1] : V[0][2]);
+  double ny = col == 0 ? V[1][0] : (col == 1 ? V[1][1] : V[1][2]);
+  double nz = col == 0 ? V[2][0] : (col == 1 ? V[2][1] : V[2][2]);
+  a.nx[i] = nx; a.ny[i] = ny; a.nz[i] = nz;
+  if (a.hist) {
+    // label histogram as neighbour counts (em_icp.hpp:301: dist(label-1) += 1/k)
+    uint8_t* h = a.hist + (size_t)i * a.C;  // this lane owns the row
+    for (int c = 0; c < a.C; ++c) h[c] = 0;
+    for (int j = 0; j < a.k; ++j) {
+      const int g = nn[j * js];
+      if (g < 0) continue;
+      const uint32_t l = a.label[g];
+      if (l >= 1u && l <= (uint32_t)a.C) h[l - 1] = (uint8_t)(h[l - 1] + 1);
+    }
+  }
+}
+
+// per-point projections of the label distribution through the confusion matrix:
+//   proj[i][s] = dist_i^T * CM[:, s]   (the two factors of em_icp.hpp:86-87), dist = counts * 1/k
+// accumulated over r in ascending order exactly like the reference's dot product.  Computed once per
+// align() per cloud, so the per-correspondence weight is a C-term product-sum of two such rows.
+__global__ __launch_bounds__(256) void cov_kernel(CovArgs a) { cov_body(a); }
+__global__ __launch_bounds__(256) void cov_jobs_kernel(CovJobs jobs) { cov_body(jobs.job[blockIdx.y]); }
+
+__device__ __forceinline__ void proj_body(const ProjArgs& a) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= a.n * a.C) return;
+  const int i = e / a.C, s = e - i * a.C;
+  const uint8_t* h = a.hist + (size_t)i * a.C;
+  double temp = 0.0;
+  for (int r = 0; r < a.C; ++r) temp += a.hval[h[r]] * a.cm[r * a.C + s];
+  a.proj[e] = temp;
+}
+
+// ------------------------------------------------------------------------------------------
+// EM weight: label posterior from the confusion matrix x the (bool) geometric gate
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void proj_kernel(ProjArgs a) { proj_body(a); }
+__global__ __launch_bounds__(256) void proj_jobs_kernel(ProjJobs jobs) { proj_body(jobs.job[blockIdx.y]); }
+
+__device__ __forceinline__ void em_weight_body(const WeightArgs& a) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= a.n_s * a.K) return;
+  const int i = e / a.K;
+  const int j = a.idx[e];
+  if (j < 0) { a.w[e] = 0.0; return; }
+  // em_icp.hpp:84-89 with the two dot products of each term taken from the per-point projections
+  const double* __restrict__ ps = a.s_proj + (size_t)i * a.C;
+  const double* __restrict__ pt = a.t_proj + (size_t)j * a.C;
+  double prob = 0.0;
+  for (int s = 0; s < a.C; ++s) {
+    double temp = pt[s];
+    temp *= ps[s];
+    prob += temp;
+  }
+  // em_icp.hpp:108 -> gicp_cost_function.h:75-87
+  Corr c;
+  corr_eval<false>(a.pose, a.one_m_eps, a.sx[i], a.sy[i], a.sz[i], a.snx[i], a.sny[i], a.snz[i],
+                   a.tx[j], a.ty[j], a.tz[j], a.tnx[j], a.tny[j], a.tnz[j], c);
+  const double two_pi = 6.283185307179586;
+  const double probability = pow(two_pi * two_pi * two_pi * c.detA, -0.5) * exp(-0.5 * c.r);
+  if (a.bool_probability) {
+    prob *= (probability != 0.0) ? 1.0 : 0.0;  // quirk Q1: double -> bool (NaN -> true)
+  } else {
+    prob *= probability;
+  }
+  a.w[e] = prob;
+}
+
+__global__ __launch_bounds__(256) void em_weight_kernel(WeightArgs a) { em_weight_body(a); }
+__global__ __launch_bounds__(256) void em_weight_jobs_kernel(WeightJobs jobs) { em_weight_body(jobs.job[blockIdx.y]); }
+
+__global__ void transform_float_kernel(int n, const float* x, const float* y, const float* z, Mat4f M,
+                                       float* ox, float* oy, float* oz) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float px = x[i], py = y[i], pz = z[i];
+  const float* m = M.m;
+  ox[i] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(m[0], px), __fmul_rn(m[1], py)), __fmul_rn(m[2], pz)), m[3]);
+  oy[i] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(m[4], px), __fmul_rn(m[5], py)), __fmul_rn(m[6], pz)), m[7]);
+  oz[i] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(m[8], px), __fmul_rn(m[9], py)), __fmul_rn(m[10], pz)), m[11]);
+}
+
+// fused label = arg max_s sum_c prob_c * (t_c . CM[:,s]) (s_i . CM[:,s])   (em_icp.hpp:224-266)
+__global__ __launch_bounds__(256) void fused_label_kernel(WeightArgs a, uint32_t* out_labels) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n_s) return;
+  // the geometric factor of each of the K correspondences does not depend on s
+  double gprob[4];
+  int jj[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int j = c < a.K ? a.idx[(size_t)i * a.K + c] : -1;
+    jj[c] = j;
+    gprob[c] = 0.0;
+    if (j >= 0) {
+      Corr cr;
+      corr_eval<false>(a.pose, a.one_m_eps, a.sx[i], a.sy[i], a.sz[i], a.snx[i], a.sny[i], a.snz[i],
+                       a.tx[j], a.ty[j], a.tz[j], a.tnx[j], a.tny[j], a.tnz[j], cr);
+      const double two_pi = 6.283185307179586;
+      const double probability = pow(two_pi * two_pi * two_pi * cr.detA, -0.5) * exp(-0.5 * cr.r);
+      gprob[c] = a.bool_probability ? ((probability != 0.0) ? 1.0 : 0.0) : probability;
+    }
+  }
+  const double* __restrict__ ps = a.s_proj + (size_t)i * a.C;
+  double max_prob = 0.0;
+  int max_s = 0;
+  for (int s = 0; s < a.C; ++s) {
+    double sprob = 0.0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (jj[c] < 0) continue;
+      double temp = a.t_proj[(size_t)jj[c] * a.C + s];
+      temp *= ps[s];
+      sprob += temp * gprob[c];  // em_icp.hpp:249-253
+    }
+    if (sprob > max_prob) { max_s = s; max_prob = sprob; }  // first max wins (em_icp.hpp:259)
+  }
+  out_labels[i] = (uint32_t)(max_s + 1);
+}
+
+// statistics: number of live correspondence slots (integer atomics: order independent)
+__global__ __launch_bounds__(256) void count_active_kernel(const int* idx, int n, unsigned long long* out) {
+  __shared__ unsigned cnt[4];
+  unsigned c = 0;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) c += idx[e] >= 0 ? 1u : 0u;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+  if ((threadIdx.x & 63) == 0) cnt[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, (unsigned long long)(cnt[0] + cnt[1] + cnt[2] + cnt[3]));
+}
+
+
+hipError_t launch_cov(const CovArgs& a, hipStream_t st) {
+  if (a.n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(cov_kernel, dim3((a.n + 255) / 256), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_proj(const ProjArgs& a, hipStream_t st) {
+  const int total = a.n * a.C;
+  if (total <= 0) return hipSuccess;
+  hipLaunchKernelGGL(proj_kernel, dim3((total + 255) / 256), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_em_weight(const WeightArgs& a, hipStream_t st) {
+  const int total = a.n_s * a.K;
+  if (total <= 0) return hipSuccess;
+  hipLaunchKernelGGL(em_weight_kernel, dim3((total + 255) / 256), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+// job-array launches (lock-step batch): every job of one launch, grid.y = job
+hipError_t launch_cov_jobs(const CovArgs* jobs, int n, hipStream_t st) {
+  for (int b = 0; b < n; b += kMaxSmallJobs) {
+    const int cnt = n - b < kMaxSmallJobs ? n - b : kMaxSmallJobs;
+    CovJobs J;
+    int mx = 0;
+    for (int i = 0; i < cnt; ++i) { J.job[i] = jobs[b + i]; mx = jobs[b + i].n > mx ? jobs[b + i].n : mx; }
+    if (mx <= 0) continue;
+    hipLaunchKernelGGL(cov_jobs_kernel, dim3((mx + 255) / 256, cnt), dim3(256), 0, st, J);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_proj_jobs(const ProjArgs* jobs, int n, hipStream_t st) {
+  for (int b = 0; b < n; b += kMaxSmallJobs) {
+    const int cnt = n - b < kMaxSmallJobs ? n - b : kMaxSmallJobs;
+    ProjJobs J;
+    int mx = 0;
+    for (int i = 0; i < cnt; ++i) { J.job[i] = jobs[b + i]; const int t = jobs[b + i].n * jobs[b + i].C; mx = t > mx ? t : mx; }
+    if (mx <= 0) continue;
+    hipLaunchKernelGGL(proj_jobs_kernel, dim3((mx + 255) / 256, cnt), dim3(256), 0, st, J);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_em_weight_jobs(const WeightArgs* jobs, int n, hipStream_t st) {
+  for (int b = 0; b < n; b += kMaxKnnJobs) {
+    const int cnt = n - b < kMaxKnnJobs ? n - b : kMaxKnnJobs;
+    WeightJobs J;
+    int mx = 0;
+    for (int i = 0; i < cnt; ++i) { J.job[i] = jobs[b + i]; const int t = jobs[b + i].n_s * jobs[b + i].K; mx = t > mx ? t : mx; }
+    if (mx <= 0) continue;
+    hipLaunchKernelGGL(em_weight_jobs_kernel, dim3((mx + 255) / 256, cnt), dim3(256), 0, st, J);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_fused_labels(const WeightArgs& a, uint32_t* out, hipStream_t st) {
+  if (a.n_s <= 0) return hipSuccess;
+  hipLaunchKernelGGL(fused_label_kernel, dim3((a.n_s + 255) / 256), dim3(256), 0, st, a, out);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void count_active_jobs_kernel(CountJobs jobs) {
+  const CountJob& J = jobs.job[blockIdx.y];
+  const int* idx = J.idx;
+  unsigned long long cnt = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < J.n; i += gridDim.x * blockDim.x) cnt += idx[i] >= 0;
+  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
+  if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(J.out, cnt);
+}
+
+hipError_t launch_count_active_jobs(const CountJob* jobs, int n, hipStream_t st) {
+  for (int b = 0; b < n; b += kMaxSmallJobs) {
+    const int cnt = n - b < kMaxSmallJobs ? n - b : kMaxSmallJobs;
+    CountJobs J;
+    int mx = 0;
+    for (int i = 0; i < cnt; ++i) { J.job[i] = jobs[b + i]; mx = jobs[b + i].n > mx ? jobs[b + i].n : mx; }
+    if (mx <= 0) continue;
+    const int gx = (mx + 255) / 256 < 256 ? (mx + 255) / 256 : 256;
+    hipLaunchKernelGGL(count_active_jobs_kernel, dim3(gx, cnt), dim3(256), 0, st, J);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_count_active(const int* idx, int n, unsigned long long* out, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(count_active_kernel, dim3(min(256, (n + 255) / 256)), dim3(256), 0, st, idx, n, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_transform_float(int n, const float* x, const float* y, const float* z, const Mat4f& M,
+                                  float* ox, float* oy, float* oz, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(transform_float_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, x, y, z, M, ox, oy, oz);
+  return hipGetLastError();
+}
+
+}  // namespace sicp

@@ -1,4 +1,4 @@
-// kernels.h -- argument blocks and launch wrappers of the gfx950 kernels (kernels.hip).
+// kernels.h -- argument blocks and launch wrappers of the gfx950 kernels (knn_kernels.hip, feature_kernels.hip, solve_kernels.hip).
 #ifndef SICP_KERNELS_H_
 #define SICP_KERNELS_H_
 

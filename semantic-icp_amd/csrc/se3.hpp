@@ -10,7 +10,7 @@
 #include <math.h>
 #include <string.h>
 
-// empty on the host; kernels.hip defines it as __host__ __device__ so that the device-resident
+// empty on the host; the kernel files define it as __host__ __device__ so that the device-resident
 // solve (lm.hpp) runs the very same SE(3) code
 #ifndef SICP_HD
 #define SICP_HD
