@@ -34,7 +34,8 @@ extern "C" {
 #endif
 
 #define SICP_VERSION_MAJOR 0
-#define SICP_VERSION_MINOR 1
+#define SICP_VERSION_MINOR 2
+#define SICP_MAX_K_COV 32  /* largest covariance neighbourhood (ctor argument k) */
 
 /* ---- status codes ------------------------------------------------------- */
 enum {
@@ -73,7 +74,8 @@ typedef struct sicp_context* sicp_handle;
 typedef struct sicp_params {
   int32_t mode;            /* SICP_MODE_*                                              */
   int32_t knn;             /* correspondences per source point: 4 (em_icp.hpp:60) or 1  */
-  int32_t k_cov;           /* covariance neighbourhood (ctor arg k = 20, em_icp.h:42)   */
+  int32_t k_cov;           /* covariance neighbourhood (ctor arg k = 20, em_icp.h:42):
+                              any 1..SICP_MAX_K_COV                                      */
   int32_t num_classes;     /* runtime C, replaces template parameter N (em_icp.h:16)    */
   double epsilon;          /* ctor arg epsilon = 1e-3 (em_icp.h:43)                     */
   double gate_sq;          /* 250, strict < (em_icp.hpp:65)                             */
@@ -115,6 +117,13 @@ typedef struct sicp_params {
                                      block (measured: no faster).  Same machine
                                      (csrc/lm.hpp), same iterates.                       */
   int32_t lm_batch;               /* evaluations queued per host poll (lm_on_device)    */
+  int32_t reuse_features;         /* 0 (default) = recompute normals / histograms on every
+                                     align() like em_icp.hpp:28-29 and gicp.hpp:33-34 do;
+                                     1 = keep them while the uploaded cloud, k and C are
+                                     unchanged (same values: they only depend on the cloud),
+                                     what setSourceCloud(cloud, kdtree, covs) gicp.h:48-56
+                                     exists for                                          */
+  int32_t reserved_;
 } sicp_params;
 
 /* Per-align() counters; times in milliseconds.  *_kernel_ms are HIP-event
@@ -133,6 +142,11 @@ typedef struct sicp_stats {
   double weight_kernel_ms;  /* EM weight kernel launches                             */
   double acc_kernel_ms;     /* accumulate + finalize pairs                           */
   int32_t cov_launches, nn_launches, weight_launches, acc_launches; /* timed launches */
+  /* lock-step batches (sicp_align_batch): LM evaluation launches this pair was part of,
+   * including those it sat through after its own inner solve had finished (idle slots =
+   * lockstep_slots - total_evals); 0 for a lone sicp_align */
+  int32_t lockstep_slots;
+  int32_t graph_builds;     /* hipGraph instantiations during this align (leader handle of a batch) */
 } sicp_stats;
 
 /* ---- lifetime ------------------------------------------------------------- */
@@ -161,6 +175,15 @@ int sicp_set_cloud(sicp_handle h, int which, int32_t n, const float* x, const fl
 int sicp_set_cloud_device(sicp_handle h, int which, int32_t n, const float* x_device,
                           const float* y_device, const float* z_device,
                           const uint32_t* label_device);
+/* setSourceCloud(cloud, kdtree, covs) / setTargetCloud(cloud, kdtree, covs) (gicp.h:48-56,
+ * 64-70, em_icp.h:50-66 via getTargetKdTree()/getTargetCovariances(), used by
+ * exec/kitti_eval.cc:207-226 to hand one scan's search tree and covariances from one
+ * registration to the next): slot `which` of `h` refers to the SAME device-resident cloud
+ * (points, search structure, normals, histograms) as slot `from_which` of `from`; nothing is
+ * copied or rebuilt.  Both handles must be on the same device.  Handles that share a cloud may
+ * run in one sicp_align_batch, or one after the other, but not concurrently from different host
+ * threads. */
+int sicp_share_cloud(sicp_handle h, int which, sicp_handle from, int from_which);
 /* setConfusionMatrix (em_icp.h:68-71); cm is C*C row-major, cm[r*C+s] */
 int sicp_set_confusion(sicp_handle h, int32_t C, const double* cm_rowmajor);
 

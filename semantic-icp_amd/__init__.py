@@ -61,6 +61,8 @@ class SicpParams(C.Structure):
         ("profile", C.c_int32),
         ("lm_on_device", C.c_int32),
         ("lm_batch", C.c_int32),
+        ("reuse_features", C.c_int32),
+        ("reserved_", C.c_int32),
     ]
 
 
@@ -86,6 +88,8 @@ class SicpStats(C.Structure):
         ("nn_launches", C.c_int32),
         ("weight_launches", C.c_int32),
         ("acc_launches", C.c_int32),
+        ("lockstep_slots", C.c_int32),
+        ("graph_builds", C.c_int32),
     ]
 
     def as_dict(self):
@@ -144,6 +148,7 @@ def lib():
             "sicp_get_params": [C.c_void_p, C.POINTER(SicpParams)],
             "sicp_set_cloud": [C.c_void_p, C.c_int, C.c_int32, _fp, _fp, _fp, _up],
             "sicp_set_cloud_device": [C.c_void_p, C.c_int, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+            "sicp_share_cloud": [C.c_void_p, C.c_int, C.c_void_p, C.c_int],
             "sicp_set_confusion": [C.c_void_p, C.c_int32, _dp],
             "sicp_align": [C.c_void_p, _dp, _dp, _ip, C.POINTER(SicpStats)],
             "sicp_align_batch": [C.POINTER(C.c_void_p), C.c_int32, _dp, _dp, _ip, C.POINTER(SicpStats)],
@@ -204,7 +209,7 @@ class Engine:
 
     def _check(self, st, where):
         if st != OK:
-            detail = lib().sicp_last_error(self._h).decode() if st == ERR_HIP else ""
+            detail = lib().sicp_last_error(self._h).decode() if st in (ERR_HIP, ERR_INVALID_ARGUMENT) else ""
             raise SicpError(st, where, detail)
 
     def close(self):
@@ -248,6 +253,17 @@ class Engine:
 
     def set_target(self, xyz, labels=None):
         self.set_cloud(TARGET, xyz, labels)
+
+    def share_cloud(self, which: int, other: "Engine", other_which: int):
+        """sicp_share_cloud: slot `which` refers to the device-resident cloud (tree, normals,
+        histograms) in slot `other_which` of `other`; nothing is copied or rebuilt."""
+        self._check(lib().sicp_share_cloud(self._h, which, other._h, other_which), "sicp_share_cloud")
+        self.n[which] = other.n[other_which]
+
+    def set_cloud_device(self, which: int, n: int, x_dev: int, y_dev: int, z_dev: int, label_dev: int | None = None):
+        """sicp_set_cloud_device: SoA float32 / uint32 buffers resident on the handle's device (raw addresses)."""
+        self._check(lib().sicp_set_cloud_device(self._h, which, n, x_dev, y_dev, z_dev, label_dev), "sicp_set_cloud_device")
+        self.n[which] = n
 
     def set_confusion(self, cm):
         cm = np.ascontiguousarray(cm, dtype=np.float64)

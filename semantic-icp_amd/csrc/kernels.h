@@ -42,8 +42,9 @@ struct MergeArgs {
   const unsigned long long* part;
   const int* inv;   // caller index -> device index of the target cloud
   float gate_sq;    // +inf for the covariance self-query
-  int* out_i;       // [n][K] device indices of the target cloud, -1 = none / gated out
-  float* out_d;     // [n][K] or nullptr
+  int* out_i;       // [n][k_out] device indices of the target cloud, -1 = none / gated out
+  float* out_d;     // [n][k_out] or nullptr
+  int k_out;        // neighbours written per query (<= the list length K the kernels run with)
 };
 
 // one tree = one cloud segment (bvh.hpp)
@@ -76,8 +77,9 @@ struct KnnArgs {
   const int* seed_hint;  // nullable, packet kernel: [query][hint_K] device indices found by the previous search of
                          // the same queries (the seed of the walk; any valid target index is a legal hint)
   int hint_K, t_begin;   // t_begin = device index of the target segment's first point
-  int out_stride;  // 0: out_i / out_d are [query][K]; > 0: [K][out_stride] (packet kernel only: coalesced
+  int out_stride;  // 0: out_i / out_d are [query][k_out]; > 0: [k_out][out_stride] (packet kernel only: coalesced
                    // for the covariance kernel, which reads one neighbour rank of 64 points at a time)
+  int k_out;       // neighbours written per query (<= the list length K the kernel runs with)
 };
 
 struct CovArgs {
@@ -146,6 +148,24 @@ struct BatchArgs {
   int pad_;
 };
 
+// [accumulate_batch, lm_step_batch] x len of a lock-step batch as an instantiated graph with explicit
+// kernel nodes: when the number of pairs or the largest pair changes, only the nodes' grids are
+// updated (hipGraphExecKernelNodeSetParams) -- no capture, no re-instantiation
+constexpr int kMaxBatchLen = 32;
+struct BatchGraph {
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  hipGraphNode_t acc[kMaxBatchLen], step[kMaxBatchLen];
+  int len = 0, K = 0, n = 0, max_nb = 0;
+  const BatchArgs* batch = nullptr;
+};
+// *built is set to 1 when the graph had to be (re)instantiated
+hipError_t batch_graph_prepare(BatchGraph& g, int K, const BatchArgs* batch, int n, int max_nb, int len, int* built);
+void batch_graph_destroy(BatchGraph& g);
+
+// neighbour-list length the search kernels run with for a request of k neighbours (the k nearest
+// are the first k of any longer exact list): 1, 4, 20 or 32; 0 = unsupported (k < 1 or k > 32)
+int nn_list_len(int k);
 bool nn_k_supported(int K);
 int nn_queries_per_thread(int K);
 hipError_t launch_nn_partial(int K, const NNArgs& a, int n_chunks, hipStream_t st);

@@ -81,6 +81,15 @@ template <int K>
 __device__ __forceinline__ void key_insert(u64 (&bk)[K], u64 key);
 
 #define SICP_KI_STEP(hi, lo) "v_max_f64 %" #hi ", %" #lo ", %0\n\tv_min_f64 %0, %" #lo ", %0\n\t"
+// any list length (the padded lists of uncommon k): one two-instruction asm statement per element
+template <int K>
+__device__ __forceinline__ void key_insert(u64 (&bk)[K], u64 key) {
+  double c = __longlong_as_double((long long)key);
+  double* b = reinterpret_cast<double*>(bk);
+#pragma unroll
+  for (int j = K - 1; j >= 1; --j) asm("v_max_f64 %1, %2, %0\n\tv_min_f64 %0, %2, %0" : "+v"(c), "=&v"(b[j]) : "v"(b[j - 1]));
+  b[0] = c;
+}
 template <>
 __device__ __forceinline__ void key_insert<1>(u64 (&bk)[1], u64 key) { bk[0] = key; }
 template <>
@@ -170,10 +179,12 @@ __device__ __forceinline__ void load_query(const float* qx, const float* qy, con
 }
 
 // results -> device indices (caller index -> device index through inv[]), gate, distances
+// k_out <= K entries are written (the k nearest are the first k of a longer exact list)
 template <int K>
-__device__ __forceinline__ void emit(const u64 (&bk)[K], const int* inv, float gate_sq, int* out_i, float* out_d, size_t o) {
+__device__ __forceinline__ void emit(const u64 (&bk)[K], const int* inv, float gate_sq, int* out_i, float* out_d, size_t o, int k_out) {
 #pragma unroll
   for (int k = 0; k < K; ++k) {
+    if (k >= k_out) break;
     const unsigned orig = (unsigned)bk[k];
     const float d = bk[k] == KEY_EMPTY ? INFINITY : key_dist(bk[k]);
     const bool keep = orig != 0xffffffffu && d < gate_sq;  // strict <, float compare (em_icp.hpp:65)
@@ -244,7 +255,7 @@ __global__ __launch_bounds__(256) void nn_merge_kernel(MergeArgs a) {
       if (key < bk[K - 1]) key_insert<K>(bk, key);
     }
   }
-  emit<K>(bk, a.inv, a.gate_sq, a.out_i, a.out_d, (size_t)(a.q_begin + q) * K);
+  emit<K>(bk, a.inv, a.gate_sq, a.out_i, a.out_d, (size_t)(a.q_begin + q) * a.k_out, a.k_out);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -381,7 +392,7 @@ __global__ __launch_bounds__(64) void bvh_knn_kernel(KnnArgs a) {
   } else if (top == 1) {
     // two levels: the seed group was one level-1 node == the root; nothing else exists
   }
-  emit<K>(bk, a.inv, a.gate_sq, a.out_i, a.out_d, (size_t)(a.q_begin + q) * K);
+  emit<K>(bk, a.inv, a.gate_sq, a.out_i, a.out_d, (size_t)(a.q_begin + q) * a.k_out, a.k_out);
   if (a.dbg) { a.dbg[2 * q] = dbg_nodes; a.dbg[2 * q + 1] = dbg_leaves; }
 }
 
@@ -534,8 +545,8 @@ __global__ __launch_bounds__(64) void bvh_knn_quad_kernel(KnnArgs a) {
   __syncthreads();
   if (sub == 0 && q_raw < a.q_count) {
     int p0 = 0, p1 = 0, p2 = 0, p3 = 0;
-    const size_t o = (size_t)(a.q_begin + q) * K;
-    for (int k = 0; k < K; ++k) {
+    const size_t o = (size_t)(a.q_begin + q) * a.k_out;
+    for (int k = 0; k < a.k_out; ++k) {
       const u64 h0 = p0 < K ? s_merge[slot][0][p0] : KEY_EMPTY, h1 = p1 < K ? s_merge[slot][1][p1] : KEY_EMPTY;
       const u64 h2 = p2 < K ? s_merge[slot][2][p2] : KEY_EMPTY, h3 = p3 < K ? s_merge[slot][3][p3] : KEY_EMPTY;
       const u64 m01 = h0 <= h1 ? h0 : h1, m23 = h2 <= h3 ? h2 : h3;
@@ -732,9 +743,9 @@ __device__ __forceinline__ void knn_packet_body(const KnnArgs& a, int wg, int n_
   if (sub == 0 && q_raw < a.q_count) {
     int p0 = 0, p1 = 0, p2 = 0, p3 = 0;
     // [query][K], or [K][out_stride] (consecutive queries -> consecutive addresses)
-    const size_t o = a.out_stride > 0 ? (size_t)(a.q_begin + q) : (size_t)(a.q_begin + q) * K;
+    const size_t o = a.out_stride > 0 ? (size_t)(a.q_begin + q) : (size_t)(a.q_begin + q) * a.k_out;
     const size_t ks = a.out_stride > 0 ? (size_t)a.out_stride : 1;
-    for (int k = 0; k < K; ++k) {
+    for (int k = 0; k < a.k_out; ++k) {
       const u64 h0 = p0 < K ? s_merge[slot][0][p0] : KEY_EMPTY, h1 = p1 < K ? s_merge[slot][1][p1] : KEY_EMPTY;
       const u64 h2 = p2 < K ? s_merge[slot][2][p2] : KEY_EMPTY, h3 = p3 < K ? s_merge[slot][3][p3] : KEY_EMPTY;
       const u64 m01 = h0 <= h1 ? h0 : h1, m23 = h2 <= h3 ? h2 : h3;
@@ -786,6 +797,7 @@ hipError_t launch_nn_partial(int K, const NNArgs& a, int n_chunks, hipStream_t s
     case 1: return launch_nn_partial<1, 4>(a, n_chunks, st);
     case 4: return launch_nn_partial<4, 2>(a, n_chunks, st);
     case 20: return launch_nn_partial<20, 1>(a, n_chunks, st);
+    case 32: return launch_nn_partial<32, 1>(a, n_chunks, st);
     default: return hipErrorInvalidValue;
   }
 }
@@ -796,6 +808,7 @@ hipError_t launch_nn_merge(int K, const MergeArgs& m, hipStream_t st) {
     case 1: hipLaunchKernelGGL((nn_merge_kernel<1>), grid, dim3(256), 0, st, m); break;
     case 4: hipLaunchKernelGGL((nn_merge_kernel<4>), grid, dim3(256), 0, st, m); break;
     case 20: hipLaunchKernelGGL((nn_merge_kernel<20>), grid, dim3(256), 0, st, m); break;
+    case 32: hipLaunchKernelGGL((nn_merge_kernel<32>), grid, dim3(256), 0, st, m); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -808,6 +821,7 @@ hipError_t launch_bvh_knn_quad(int K, const KnnArgs& a, hipStream_t st) {
     case 1: hipLaunchKernelGGL((bvh_knn_quad_kernel<1>), grid, dim3(64), 0, st, a); break;
     case 4: hipLaunchKernelGGL((bvh_knn_quad_kernel<4>), grid, dim3(64), 0, st, a); break;
     case 20: hipLaunchKernelGGL((bvh_knn_quad_kernel<20>), grid, dim3(64), 0, st, a); break;
+    case 32: hipLaunchKernelGGL((bvh_knn_quad_kernel<32>), grid, dim3(64), 0, st, a); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -824,6 +838,7 @@ hipError_t launch_bvh_knn_packet(int K, const KnnArgs& a, hipStream_t st) {
     case 1: if (wpb_small == 1) SICP_PK(1, 1); else if (wpb_small == 2) SICP_PK(1, 2); else SICP_PK(1, 4); break;
     case 4: if (wpb_small == 1) SICP_PK(4, 1); else if (wpb_small == 2) SICP_PK(4, 2); else SICP_PK(4, 4); break;
     case 20: if (wpb_big == 1) SICP_PK(20, 1); else if (wpb_big == 2) SICP_PK(20, 2); else SICP_PK(20, 4); break;
+    case 32: SICP_PK(32, 2); break;
     default: return hipErrorInvalidValue;
   }
 #undef SICP_PK
@@ -837,12 +852,14 @@ hipError_t launch_bvh_knn(int K, const KnnArgs& a, hipStream_t st) {
     case 1: hipLaunchKernelGGL((bvh_knn_kernel<1>), grid, dim3(64), 0, st, a); break;
     case 4: hipLaunchKernelGGL((bvh_knn_kernel<4>), grid, dim3(64), 0, st, a); break;
     case 20: hipLaunchKernelGGL((bvh_knn_kernel<20>), grid, dim3(64), 0, st, a); break;
+    case 32: hipLaunchKernelGGL((bvh_knn_kernel<32>), grid, dim3(64), 0, st, a); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }
 
-bool nn_k_supported(int K) { return K == 1 || K == 4 || K == 20; }
+bool nn_k_supported(int K) { return K == 1 || K == 4 || K == 20; }  // correspondences per source point (accumulate kernels)
+int nn_list_len(int k) { return k < 1 ? 0 : (k == 1 ? 1 : (k <= 4 ? 4 : (k <= 20 ? 20 : (k <= 32 ? 32 : 0)))); }
 
 hipError_t launch_bvh_knn_packet_jobs(int K, const KnnArgs* jobs, int n, hipStream_t st) {
   for (int b = 0; b < n; b += kMaxKnnJobs) {
@@ -857,6 +874,7 @@ hipError_t launch_bvh_knn_packet_jobs(int K, const KnnArgs* jobs, int n, hipStre
       case 1: SICP_PKJ(1, 4); break;
       case 4: SICP_PKJ(4, 4); break;
       case 20: SICP_PKJ(20, 2); break;
+      case 32: SICP_PKJ(32, 2); break;
       default: return hipErrorInvalidValue;
     }
 #undef SICP_PKJ

@@ -6,12 +6,14 @@
 // and every entry point fails with SICP_ERR_NO_DEVICE / SICP_ERR_HIP if it cannot.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <memory>
 #include <new>
 #include <string>
 #include <vector>
@@ -88,9 +90,18 @@ struct Cloud {
   bool feat_valid = false;
   int feat_k = 0, feat_C = 0, feat_float_products = 0;
   bool feat_hist = false;
+  // which align() / align_batch() call computed the features last (a cloud shared by two handles of
+  // one batch is only searched once per call), and which confusion matrix the projections belong to
+  unsigned long long feat_epoch = 0;
+  unsigned long long proj_cm_id = 0;
   int n_seg() const { return (int)seg_label.size(); }
   int caller_index(int d) const { return perm[d]; }
 };
+
+unsigned long long next_epoch() {
+  static std::atomic<unsigned long long> counter{0};
+  return ++counter;
+}
 
 double now_ms() {
   using namespace std::chrono;
@@ -120,9 +131,13 @@ struct sicp_context {
   hipStream_t stream2 = nullptr;  // second cloud's feature kernels run beside the first's
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_join = nullptr;
   sicp_params params;
-  Cloud cloud[2];
+  std::shared_ptr<Cloud> cl[2] = {std::make_shared<Cloud>(), std::make_shared<Cloud>()};
+  Cloud& cloud(int which) { return *cl[which]; }
+  const Cloud& cloud(int which) const { return *cl[which]; }
+  unsigned long long epoch = 0;  // id of the running align() / align_batch() call
   int C = 0;
   std::vector<double> cm;
+  unsigned long long cm_id = 0;  // changes with every sicp_set_confusion
   DevBuf<double> d_cm, d_hval;
   int hval_k = 0;
   // correspondences of the last search
@@ -157,13 +172,9 @@ struct sicp_context {
   sicp::LmState* h_bstates = nullptr;
   double* h_bout28 = nullptr;
   int h_batch_cap = 0;
-  hipGraphExec_t b_graph = nullptr;
-  int b_graph_n = 0, b_graph_maxnb = 0, b_graph_K = 0, b_graph_len = 0, b_graph_chains = 0;
-  hipStream_t stream_fork = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_fork_done = nullptr;
+  sicp::BatchGraph b_graph;
   hipStream_t part_stream[kParts] = {};
   hipEvent_t part_fork = nullptr, part_done[kParts] = {};
-  const void* b_graph_ptr = nullptr;
   std::string last_error;
   sicp_stats st;
 };
@@ -312,6 +323,10 @@ int prepare_cloud(sicp_context* h, Cloud& c) {
 int run_nn(sicp_context* h, int K, const Cloud& Qc, int q_begin, int q_count, const double* M34, const Cloud& Tc,
            int tseg, bool self, float gate_sq, int* out_i, float* out_d, int timer_bit, hipStream_t stream, int out_stride = 0) {
   if (q_count <= 0) return SICP_OK;
+  // the kernels run with a list of L >= K entries and write the first K (the K nearest neighbours
+  // are the first K of any longer exact list): any K in 1..32 works
+  const int L = sicp::nn_list_len(K);
+  if (L == 0) return SICP_ERR_INVALID_ARGUMENT;
   const Cloud::SegTree& tr = Tc.trees[tseg];
   auto account = [&](double ms) {
     if (timer_bit == SICP_PROFILE_NN) { h->st.nn_kernel_ms += ms; h->st.nn_launches += 1; }
@@ -333,6 +348,7 @@ int run_nn(sicp_context* h, int K, const Cloud& Qc, int q_begin, int q_count, co
     a.out_i = out_i; a.out_d = out_d;
     a.dbg = nullptr;
     a.out_stride = out_stride;
+    a.k_out = K;
     // seed hint: what the previous search of the same queries found (same clouds, same K, this align)
     a.seed_hint = (!self && h->hint_ok && out_i == h->idx.p && h->corr_K == K && h->corr_n == Qc.n) ? h->idx.p : nullptr;
     a.hint_K = K;
@@ -342,14 +358,14 @@ int run_nn(sicp_context* h, int K, const Cloud& Qc, int q_begin, int q_count, co
     if (want_dbg) { HIPCHECK(dbg.reserve((size_t)2 * q_count)); a.dbg = dbg.p; }
     static const bool lane_per_query = std::getenv("SICP_KNN_LANE_PER_QUERY") != nullptr;  // A/B aid
     if (h->collect) {  // lock-step batch (packet search, no profiling: checked by the driver)
-      h->collect->knn_K = K;
+      h->collect->knn_K = L;
       h->collect->knn[h->collect->slice].push_back(a);
       return SICP_OK;
     }
     KernelTimer kt(h, stream == h->stream ? timer_bit : 0);
-    if (lane_per_query) HIPCHECK(sicp::launch_bvh_knn(K, a, stream));
-    else if (h->params.nn_method == 2) HIPCHECK(sicp::launch_bvh_knn_quad(K, a, stream));
-    else HIPCHECK(sicp::launch_bvh_knn_packet(K, a, stream));
+    if (lane_per_query) HIPCHECK(sicp::launch_bvh_knn(L, a, stream));
+    else if (h->params.nn_method == 2) HIPCHECK(sicp::launch_bvh_knn_quad(L, a, stream));
+    else HIPCHECK(sicp::launch_bvh_knn_packet(L, a, stream));
     account(kt.stop());
     if (want_dbg) {
       std::vector<int> hd((size_t)2 * q_count);
@@ -369,7 +385,7 @@ int run_nn(sicp_context* h, int K, const Cloud& Qc, int q_begin, int q_count, co
     return SICP_OK;
   }
   const int t_count = tr.n;
-  const int Q = sicp::nn_queries_per_thread(K);
+  const int Q = sicp::nn_queries_per_thread(L);
   const int qblocks = (q_count + 256 * Q - 1) / (256 * Q);
   // >= ~8 workgroups per CU so the search fills the chip, but never chunks below one LDS tile
   int chunks = (2048 + qblocks - 1) / qblocks;
@@ -380,7 +396,7 @@ int run_nn(sicp_context* h, int K, const Cloud& Qc, int q_begin, int q_count, co
   chunk_len = ((chunk_len + 1023) / 1024) * 1024;
   if (chunk_len < 1024) chunk_len = 1024;
   chunks = t_count > 0 ? (t_count + chunk_len - 1) / chunk_len : 1;
-  const size_t need = (size_t)chunks * q_count * K;
+  const size_t need = (size_t)chunks * q_count * L;
   HIPCHECK(h->part.reserve(need));
   sicp::NNArgs a;
   a.qx = Qc.x.p; a.qy = Qc.y.p; a.qz = Qc.z.p;
@@ -397,12 +413,13 @@ int run_nn(sicp_context* h, int K, const Cloud& Qc, int q_begin, int q_count, co
   m.inv = Tc.inv.p;
   m.gate_sq = gate_sq;
   m.out_i = out_i; m.out_d = out_d;
+  m.k_out = K;
   {
     KernelTimer kt(h, stream == h->stream ? timer_bit : 0);
-    HIPCHECK(sicp::launch_nn_partial(K, a, chunks, stream));
+    HIPCHECK(sicp::launch_nn_partial(L, a, chunks, stream));
     account(kt.stop());
   }
-  HIPCHECK(sicp::launch_nn_merge(K, m, stream));
+  HIPCHECK(sicp::launch_nn_merge(L, m, stream));
   return SICP_OK;
 }
 
@@ -422,8 +439,11 @@ int ensure_hval(sicp_context* h, int k) {
 
 // projections of the label histograms through the confusion matrix (once per cloud per align)
 int ensure_proj(sicp_context* h, Cloud& c) {
-  if (c.proj_valid) return SICP_OK;
   const sicp_params& P = h->params;
+  // the projections depend on the cloud's histograms, the confusion matrix and k: a cloud shared by
+  // handles that hold the same matrix is projected once
+  const unsigned long long want_id = h->cm_id * 1099511628211ull + (unsigned long long)P.k_cov;
+  if (c.proj_valid && c.proj_cm_id == want_id) return SICP_OK;
   SICPCHECK(ensure_hval(h, P.k_cov));
   HIPCHECK(c.proj.reserve((size_t)(c.n > 0 ? c.n : 1) * P.num_classes));
   sicp::ProjArgs a;
@@ -432,6 +452,7 @@ int ensure_proj(sicp_context* h, Cloud& c) {
   if (h->collect) h->collect->proj[h->collect->slice].push_back(a);
   else HIPCHECK(sicp::launch_proj(a, h->stream));
   c.proj_valid = true;
+  c.proj_cm_id = want_id;
   return SICP_OK;
 }
 
@@ -469,6 +490,7 @@ int compute_features(sicp_context* h, Cloud& c, bool with_hist, hipStream_t stre
   c.feat_k = k; c.feat_C = with_hist ? P.num_classes : 0;
   c.feat_float_products = P.quirk_float_products;
   c.feat_hist = with_hist;
+  c.feat_epoch = h->epoch;
   return SICP_OK;
 }
 
@@ -479,16 +501,16 @@ bool features_current(const sicp_context* h, const Cloud& c, bool with_hist) {
 
 int check_ready(sicp_context* h, bool need_cm) {
   const sicp_params& P = h->params;
-  if (!h->cloud[0].is_set || !h->cloud[1].is_set) return SICP_ERR_NOT_READY;
-  if (!sicp::nn_k_supported(P.knn) || !sicp::nn_k_supported(P.k_cov)) return SICP_ERR_INVALID_ARGUMENT;
-  if (P.mode != SICP_MODE_GICP && (!h->cloud[0].has_label || !h->cloud[1].has_label)) return SICP_ERR_NOT_READY;
+  if (!h->cloud(0).is_set || !h->cloud(1).is_set) return SICP_ERR_NOT_READY;
+  if (!sicp::nn_k_supported(P.knn) || sicp::nn_list_len(P.k_cov) == 0) return SICP_ERR_INVALID_ARGUMENT;
+  if (P.mode != SICP_MODE_GICP && (!h->cloud(0).has_label || !h->cloud(1).has_label)) return SICP_ERR_NOT_READY;
   if (P.mode == SICP_MODE_EM || need_cm) {
     if (P.num_classes < 1 || P.num_classes > 255 || h->C != P.num_classes) return SICP_ERR_NOT_READY;
     for (int wch = 0; wch < 2; ++wch)
-      for (uint32_t l : h->cloud[wch].hl)
+      for (uint32_t l : h->cloud(wch).hl)
         if (l < 1 || l > (uint32_t)P.num_classes) return SICP_ERR_BAD_LABEL;  // em_icp.hpp:301 indexes label-1
   }
-  if (P.mode != SICP_MODE_SEMANTIC && h->cloud[1].n < P.knn) return SICP_ERR_TOO_FEW_POINTS;
+  if (P.mode != SICP_MODE_SEMANTIC && h->cloud(1).n < P.knn) return SICP_ERR_TOO_FEW_POINTS;
   return SICP_OK;
 }
 
@@ -506,7 +528,7 @@ int segment_of(const Cloud& c, uint32_t label) {
 // transform + kNN + gate (+ EM weight) at pose qt: the loop em_icp.hpp:46-108
 int run_correspondences(sicp_context* h, const double* qt, int K, bool weights) {
   const sicp_params& P = h->params;
-  Cloud &S = h->cloud[0], &T = h->cloud[1];
+  Cloud &S = h->cloud(0), &T = h->cloud(1);
   const size_t slots = (size_t)(S.n > 0 ? S.n : 1) * K;
   HIPCHECK(h->idx.reserve(slots));
   HIPCHECK(h->d2.reserve(slots));
@@ -565,7 +587,7 @@ int run_correspondences(sicp_context* h, const double* qt, int K, bool weights) 
 
 void fill_acc(sicp_context* h, sicp::AccArgs& a) {
   const sicp_params& P = h->params;
-  Cloud &S = h->cloud[0], &T = h->cloud[1];
+  Cloud &S = h->cloud(0), &T = h->cloud(1);
   a.n_s = h->corr_n; a.K = h->corr_K;
   a.idx = h->idx.p;
   a.w = h->corr_weighted ? h->w.p : nullptr;
@@ -690,6 +712,7 @@ int run_solve(sicp_context* h, const double* init_qt, double* out_qt, SolveResul
     hipError_t ie = hipGraphInstantiate(&h->lm_graph, g, nullptr, nullptr, 0);
     (void)hipGraphDestroy(g);
     HIPCHECK(ie);
+    h->st.graph_builds += 1;
     std::memcpy(&h->lm_graph_args, &a, sizeof a);
     h->lm_graph_batch = batch;
     h->lm_graph_chain = (int)chain;
@@ -732,7 +755,7 @@ int align_begin(sicp_context* h, bool want_stats) {
   const bool em = P.mode == SICP_MODE_EM, sem = P.mode == SICP_MODE_SEMANTIC;
   std::memset(&h->st, 0, sizeof h->st);
   h->hint_ok = false;  // every align() starts its first search from the curve position, like a first call would
-  Cloud &S = h->cloud[0], &T = h->cloud[1];
+  Cloud &S = h->cloud(0), &T = h->cloud(1);
   HIPCHECK(h->d_count.reserve(1));
   if (want_stats) HIPCHECK(hipMemsetAsync(h->d_count.p, 0, sizeof(long long), h->stream));
   SICPCHECK(prepare_cloud(h, S));
@@ -743,13 +766,25 @@ int align_begin(sicp_context* h, bool want_stats) {
   // the two clouds' feature kernels are independent and latency bound: run them side by side
   // (not with brute force, which shares one scratch buffer, nor while those kernels are timed)
   const bool side_by_side = P.nn_method >= 1 && !(P.profile & SICP_PROFILE_COV);
-  if (!sem || !features_current(h, S, false)) SICPCHECK(compute_features(h, S, em));
-  if (!sem || !features_current(h, T, false)) {
+  // A cloud is searched at most once per align() / align_batch() call (it may be shared by two
+  // handles of a batch: one scan is the source of a pair and the target of the next), and not at
+  // all when reuse_features is set and the features already belong to this cloud, k and C.
+  auto stale = [&](const Cloud& c) {
+    if (!features_current(h, c, em)) return true;
+    if (sem || P.reuse_features) return false;
+    return c.feat_epoch != h->epoch;
+  };
+  if (stale(S)) SICPCHECK(compute_features(h, S, em));
+  if (stale(T)) {
     SICPCHECK(compute_features(h, T, em, side_by_side ? h->stream2 : h->stream));
-    if (side_by_side) {
+    if (side_by_side && !h->collect) {
       HIPCHECK(hipEventRecord(h->ev_join, h->stream2));
       HIPCHECK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
     }
+  }
+  if (em) {  // label distributions through the confusion matrix: same phase as the features they read
+    SICPCHECK(ensure_proj(h, S));
+    SICPCHECK(ensure_proj(h, T));
   }
   if (P.profile) HIPCHECK(hipStreamSynchronize(h->stream));
   h->st.t_cov_ms = now_ms() - t0;
@@ -789,7 +824,8 @@ int align_end(sicp_context* h, const OuterState& o, double t_begin, int32_t* out
 
 // ---- lock-step batch -----------------------------------------------------------------------------
 bool same_solver(const sicp_params& a, const sicp_params& b) {
-  return a.mode == b.mode && a.knn == b.knn && a.lm_batch == b.lm_batch && a.use_sqloss == b.use_sqloss;
+  return a.mode == b.mode && a.knn == b.knn && a.lm_batch == b.lm_batch && a.use_sqloss == b.use_sqloss &&
+         a.nn_method == b.nn_method && a.lm_on_device == b.lm_on_device && a.profile == b.profile && a.k_cov == b.k_cov;
 }
 
 int batch_reserve(sicp_context* h, int n) {
@@ -877,13 +913,15 @@ struct BatchGuard {
 int run_solve_batch(sicp_context* h, sicp_handle* hs, int n, const char* active, OuterState* o, SolveResult* res) {
   const sicp_params& P = h->params;
   SICPCHECK(batch_reserve(h, n));
-  int max_nb = 0;
+  // The argument array only holds the pairs that still iterate (compacted: grid.y = their number);
+  // the LM states stay indexed by pair.
+  int max_nb = 0, n_act = 0;
   for (int p = 0; p < n; ++p) {
     sicp_context* g = hs[p];
-    sicp::BatchArgs& B = h->h_batch[p];
-    std::memset(&B, 0, sizeof B);
     sicp::lm_init(h->h_bstates[p], lm_options(g->params), o[p].est);
-    if (!active[p]) { h->h_bstates[p].status = sicp::LM_CONVERGED; B.nb = 0; B.a.lm = B.a.lm_step = h->d_bstates.p + p; continue; }
+    if (!active[p]) { h->h_bstates[p].status = sicp::LM_CONVERGED; continue; }
+    sicp::BatchArgs& B = h->h_batch[n_act++];
+    std::memset(&B, 0, sizeof B);
     const int nb = sicp::accumulate_blocks(g->corr_n * g->corr_K);
     if (g->partials.reserve((size_t)nb * 28) != hipSuccess) return SICP_ERR_OUT_OF_MEMORY;
     fill_acc(g, B.a);
@@ -891,59 +929,30 @@ int run_solve_batch(sicp_context* h, sicp_handle* hs, int n, const char* active,
     B.nb = nb;
     max_nb = std::max(max_nb, nb);
     // the batched kernels (leader stream) read what the pair's stream is still producing
-    if (g != h) {
+    if (g != h && g->stream != h->stream) {
       HIPCHECK(hipEventRecord(g->ev_join, g->stream));
       HIPCHECK(hipStreamWaitEvent(h->stream, g->ev_join, 0));
     }
   }
-  HIPCHECK(hipMemcpyAsync(h->d_batch.p, h->h_batch, sizeof(sicp::BatchArgs) * n, hipMemcpyHostToDevice, h->stream));
+  if (n_act == 0) return SICP_OK;
+  HIPCHECK(hipMemcpyAsync(h->d_batch.p, h->h_batch, sizeof(sicp::BatchArgs) * n_act, hipMemcpyHostToDevice, h->stream));
   HIPCHECK(hipMemcpyAsync(h->d_bstates.p, h->h_bstates, sizeof(sicp::LmState) * n, hipMemcpyHostToDevice, h->stream));
-  const int len = P.lm_batch > 0 ? P.lm_batch : 12;
+  const int len = std::min(P.lm_batch > 0 ? P.lm_batch : 12, sicp::kMaxBatchLen);
   const int K = hs[0]->corr_K;
-  // The graph only depends on the grid and on the address of the argument array.  SICP_BATCH_CHAINS=2
-  // gives it two independent chains (the halves of the batch), so that one half's one-wave-per-pair
-  // LM step overlaps the other half's accumulate launch: +3 % throughput, but two accumulate
-  // launches then run concurrently and neither has a clean duration to hold against a roofline, so
-  // the default is one chain.
-  static const int chains_wanted = [] { const char* e = std::getenv("SICP_BATCH_CHAINS"); return e ? std::atoi(e) : 1; }();
-  const int chains = (chains_wanted >= 2 && n >= 4) ? 2 : 1;
-  if (chains == 2 && !h->stream_fork) {
-    HIPCHECK(hipStreamCreateWithFlags(&h->stream_fork, hipStreamNonBlocking));
-    HIPCHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-    HIPCHECK(hipEventCreateWithFlags(&h->ev_fork_done, hipEventDisableTiming));
-  }
-  if (!h->b_graph || h->b_graph_n != n || h->b_graph_maxnb != max_nb || h->b_graph_K != K || h->b_graph_len != len ||
-      h->b_graph_ptr != (const void*)h->d_batch.p || h->b_graph_chains != chains) {
-    if (h->b_graph) { (void)hipGraphExecDestroy(h->b_graph); h->b_graph = nullptr; }
-    hipGraph_t g = nullptr;
-    const int n0 = chains == 2 ? n / 2 : n, n1 = n - n0;
-    HIPCHECK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-    hipError_t ce = hipSuccess;
-    if (chains == 2) {
-      ce = hipEventRecord(h->ev_fork, h->stream);
-      if (ce == hipSuccess) ce = hipStreamWaitEvent(h->stream_fork, h->ev_fork, 0);
-    }
-    for (int b = 0; b < len && ce == hipSuccess; ++b) {
-      ce = sicp::launch_accumulate_batch(K, h->d_batch.p, n0, max_nb, h->stream);
-      if (ce == hipSuccess) ce = sicp::launch_lm_step_batch(h->d_batch.p, n0, h->stream);
-      if (chains == 2 && ce == hipSuccess) ce = sicp::launch_accumulate_batch(K, h->d_batch.p + n0, n1, max_nb, h->stream_fork);
-      if (chains == 2 && ce == hipSuccess) ce = sicp::launch_lm_step_batch(h->d_batch.p + n0, n1, h->stream_fork);
-    }
-    if (chains == 2 && ce == hipSuccess) ce = hipEventRecord(h->ev_fork_done, h->stream_fork);
-    if (chains == 2 && ce == hipSuccess) ce = hipStreamWaitEvent(h->stream, h->ev_fork_done, 0);
-    hipError_t ee = hipStreamEndCapture(h->stream, &g);
-    HIPCHECK(ce);
-    HIPCHECK(ee);
-    hipError_t ie = hipGraphInstantiate(&h->b_graph, g, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(g);
-    HIPCHECK(ie);
-    h->b_graph_n = n; h->b_graph_maxnb = max_nb; h->b_graph_K = K; h->b_graph_len = len; h->b_graph_ptr = h->d_batch.p;
-    h->b_graph_chains = chains;
+  // [accumulate_batch, lm_step_batch] x len as an explicit graph: it only depends on the grids and on
+  // the address of the argument array, and when the number of active pairs or the largest pair
+  // changes the grids of the instantiated graph are updated in place (no re-instantiation).
+  {
+    int built = 0;
+    HIPCHECK(sicp::batch_graph_prepare(h->b_graph, K, h->d_batch.p, n_act, max_nb, len, &built));
+    h->st.graph_builds += built;
   }
   for (;;) {
-    HIPCHECK(hipGraphLaunch(h->b_graph, h->stream));
-    for (int p = 0; p < n; ++p)
+    HIPCHECK(hipGraphLaunch(h->b_graph.exec, h->stream));
+    for (int p = 0; p < n; ++p) {
+      hs[p]->st.lockstep_slots += len;  // every pair of the batch waits for this launch, iterating or not
       if (active[p]) hs[p]->st.acc_launches += len;
+    }
     HIPCHECK(hipMemcpyAsync(h->h_bstates, h->d_bstates.p, sizeof(sicp::LmState) * n, hipMemcpyDeviceToHost, h->stream));
     HIPCHECK(hipStreamSynchronize(h->stream));
     bool running = false;
@@ -1077,14 +1086,11 @@ int sicp_destroy(sicp_handle h) {
   if (h->h_batch) (void)hipHostFree(h->h_batch);
   if (h->h_bstates) (void)hipHostFree(h->h_bstates);
   if (h->h_bout28) (void)hipHostFree(h->h_bout28);
-  if (h->b_graph) (void)hipGraphExecDestroy(h->b_graph);
+  sicp::batch_graph_destroy(h->b_graph);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->lm_graph) (void)hipGraphExecDestroy(h->lm_graph);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
-  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-  if (h->ev_fork_done) (void)hipEventDestroy(h->ev_fork_done);
-  if (h->stream_fork) (void)hipStreamDestroy(h->stream_fork);
   if (h->part_fork) (void)hipEventDestroy(h->part_fork);
   for (int s = 1; s < kParts; ++s) {
     if (h->part_done[s]) (void)hipEventDestroy(h->part_done[s]);
@@ -1099,7 +1105,14 @@ int sicp_destroy(sicp_handle h) {
 int sicp_set_params(sicp_handle h, const sicp_params* p) {
   if (!h || !p) return SICP_ERR_INVALID_ARGUMENT;
   if (p->mode < SICP_MODE_GICP || p->mode > SICP_MODE_SEMANTIC) return SICP_ERR_INVALID_ARGUMENT;
-  if (!sicp::nn_k_supported(p->knn) || !sicp::nn_k_supported(p->k_cov)) return SICP_ERR_INVALID_ARGUMENT;
+  if (!sicp::nn_k_supported(p->knn)) {
+    h->last_error = "sicp_set_params: knn (correspondences per source point) must be 1, 4 or 20";
+    return SICP_ERR_INVALID_ARGUMENT;
+  }
+  if (sicp::nn_list_len(p->k_cov) == 0) {
+    h->last_error = "sicp_set_params: k_cov (covariance neighbourhood, the constructors' k) must be in 1..32";
+    return SICP_ERR_INVALID_ARGUMENT;
+  }
   if (!(p->epsilon > 0) || !(p->cauchy_a > 0) || p->nn_method < 0 || p->nn_method > 2) return SICP_ERR_INVALID_ARGUMENT;
   // engine knobs (profiling, batching) do not invalidate the correspondences held on the device
   sicp_params a = h->params, b = *p;
@@ -1120,7 +1133,8 @@ int sicp_set_cloud(sicp_handle h, int which, int32_t n, const float* x, const fl
   if (!h || (which != SICP_SOURCE && which != SICP_TARGET) || n < 0) return SICP_ERR_INVALID_ARGUMENT;
   if (n > 0 && (!x || !y || !z)) return SICP_ERR_INVALID_ARGUMENT;
   SICPCHECK(set_device(h));
-  Cloud& c = h->cloud[which];
+  if (h->cl[which].use_count() > 1) h->cl[which] = std::make_shared<Cloud>();  // shared with another handle: leave theirs alone
+  Cloud& c = h->cloud(which);
   c.n = n;
   c.hx.assign(x, x + n); c.hy.assign(y, y + n); c.hz.assign(z, z + n);
   c.has_label = label != nullptr;
@@ -1153,12 +1167,31 @@ int sicp_set_cloud_device(sicp_handle h, int which, int32_t n, const float* xd, 
   return sicp_set_cloud(h, which, n, x.data(), y.data(), z.data(), ld ? l.data() : nullptr);
 }
 
+int sicp_share_cloud(sicp_handle h, int which, sicp_handle from, int from_which) {
+  if (!h || !from || (which != SICP_SOURCE && which != SICP_TARGET) || (from_which != SICP_SOURCE && from_which != SICP_TARGET))
+    return SICP_ERR_INVALID_ARGUMENT;
+  if (h->device != from->device) {
+    h->last_error = "sicp_share_cloud: the handles are on different devices";
+    return SICP_ERR_INVALID_ARGUMENT;
+  }
+  if (!from->cloud(from_which).is_set) return SICP_ERR_NOT_READY;
+  h->cl[which] = from->cl[from_which];
+  h->corr_valid = false;
+  h->hint_ok = false;
+  return SICP_OK;
+}
+
 int sicp_set_confusion(sicp_handle h, int32_t C, const double* cm) {
   if (!h || C < 1 || C > 255 || !cm) return SICP_ERR_INVALID_ARGUMENT;
   SICPCHECK(set_device(h));
   h->C = C;
   h->cm.assign(cm, cm + (size_t)C * C);
-  h->cloud[0].proj_valid = h->cloud[1].proj_valid = false;
+  {  // FNV-1a of the contents: handles holding the same matrix share the projections of a shared cloud
+    unsigned long long id = 1469598103934665603ull ^ (unsigned long long)C;
+    const unsigned char* b = reinterpret_cast<const unsigned char*>(h->cm.data());
+    for (size_t i = 0; i < sizeof(double) * h->cm.size(); ++i) id = (id ^ b[i]) * 1099511628211ull;
+    h->cm_id = id;
+  }
   HIPCHECK(h->d_cm.reserve((size_t)C * C));
   HIPCHECK(hipMemcpyAsync(h->d_cm.p, h->cm.data(), sizeof(double) * C * C, hipMemcpyHostToDevice, h->stream));
   HIPCHECK(hipStreamSynchronize(h->stream));
@@ -1171,6 +1204,7 @@ int sicp_align(sicp_handle h, const double init_qt[7], double out_qt[7], int32_t
   SICPCHECK(check_ready(h, false));
   const sicp_params& P = h->params;
   const double t_begin = now_ms();
+  h->epoch = next_epoch();
   SICPCHECK(align_begin(h, stats != nullptr));
   OuterState o;
   std::memcpy(o.cur, init_qt, sizeof o.cur);
@@ -1209,7 +1243,7 @@ int sicp_align_batch(sicp_handle* hs, int32_t n, const double* init_qt, double* 
       if (hs[q] == h) return SICP_ERR_INVALID_ARGUMENT;  // every pair needs its own handle
     // one launch evaluates every pair: they must agree on what a launch does
     if (h->device != L->device || !same_solver(h->params, L->params)) {
-      h->last_error = "sicp_align_batch: handles differ in device, mode, knn or solver parameters";
+      h->last_error = "sicp_align_batch: handles differ in device, mode, knn, k_cov, nn_method, lm_on_device, lm_batch, profile or loss";
       return SICP_ERR_INVALID_ARGUMENT;
     }
     SICPCHECK(check_ready(h, false));
@@ -1227,11 +1261,22 @@ int sicp_align_batch(sicp_handle* hs, int32_t n, const double* init_qt, double* 
   }
   JobCollector jc;
   BatchGuard guard(hs, n, one_launch ? &jc : nullptr, L->stream);
+  const unsigned long long epoch = next_epoch();
   for (int p = 0; p < n; ++p) {
+    hs[p]->epoch = epoch;
     jc.slice = batch_slice(p, n);
     SICPCHECK(align_begin(hs[p], stats != nullptr));
   }
-  if (one_launch) SICPCHECK(flush_jobs(L, jc));
+  if (one_launch) {
+    SICPCHECK(flush_jobs(L, jc));
+  } else {
+    // per-pair launches on the pairs' own streams: a cloud shared by two pairs has just been given
+    // its features on ONE of them
+    for (int p = 0; p < n; ++p) {
+      sicp_context* h = hs[p];
+      HIPCHECK(hipStreamSynchronize(h->stream));
+    }
+  }
   std::vector<OuterState> o(n);
   for (int p = 0; p < n; ++p) std::memcpy(o[p].cur, init_qt + 7 * p, sizeof o[p].cur);
   std::vector<SolveResult> res(n);
@@ -1314,7 +1359,7 @@ int sicp_accumulate_batch(sicp_handle* hs, int32_t n, const double* qt, double* 
 int sicp_transform_source(sicp_handle h, const double qt[7], float* ox, float* oy, float* oz) {
   if (!h || !qt || !ox || !oy || !oz) return SICP_ERR_INVALID_ARGUMENT;
   SICPCHECK(set_device(h));
-  Cloud& S = h->cloud[0];
+  Cloud& S = h->cloud(0);
   SICPCHECK(prepare_cloud(h, S));
   const int n = S.n;
   const size_t m = (size_t)(n > 0 ? n : 1);
@@ -1343,15 +1388,16 @@ int sicp_covariances(sicp_handle h, int which, double* cov9, double* normal3, ui
   if (!h || (which != SICP_SOURCE && which != SICP_TARGET)) return SICP_ERR_INVALID_ARGUMENT;
   SICPCHECK(set_device(h));
   const sicp_params& P = h->params;
-  if (!sicp::nn_k_supported(P.k_cov)) return SICP_ERR_INVALID_ARGUMENT;
-  Cloud& c = h->cloud[which];
+  if (sicp::nn_list_len(P.k_cov) == 0) return SICP_ERR_INVALID_ARGUMENT;
+  Cloud& c = h->cloud(which);
   SICPCHECK(prepare_cloud(h, c));
   const bool with_hist = P.mode == SICP_MODE_EM && c.has_label && P.num_classes >= 1;
   if (hist && !with_hist) return SICP_ERR_NOT_READY;
   if (with_hist)
     for (uint32_t l : c.hl)
       if (l < 1 || l > (uint32_t)P.num_classes) return SICP_ERR_BAD_LABEL;
-  SICPCHECK(compute_features(h, c, with_hist));
+  // what align() left behind is returned as it is (getSourceCovariances(), gicp.h:72-90)
+  if (!features_current(h, c, with_hist) || (nn_idx && !c.nn.p)) SICPCHECK(compute_features(h, c, with_hist));
   const int n = c.n, k = P.k_cov;
   std::vector<double> nx(n), ny(n), nz(n);
   if (n > 0) {
@@ -1394,7 +1440,7 @@ int sicp_correspondences(sicp_handle h, const double qt[7], int32_t* idx, float*
   SICPCHECK(check_ready(h, false));
   const sicp_params& P = h->params;
   const bool em = P.mode == SICP_MODE_EM;
-  Cloud &S = h->cloud[0], &T = h->cloud[1];
+  Cloud &S = h->cloud(0), &T = h->cloud(1);
   SICPCHECK(prepare_cloud(h, S));
   SICPCHECK(prepare_cloud(h, T));
   if (!features_current(h, S, em)) SICPCHECK(compute_features(h, S, em));
@@ -1450,7 +1496,7 @@ int sicp_fused_labels(sicp_handle h, const double qt[7], uint32_t* out_labels) {
   if (h->params.mode != SICP_MODE_EM) return SICP_ERR_INVALID_ARGUMENT;
   SICPCHECK(check_ready(h, true));
   const sicp_params& P = h->params;
-  Cloud &S = h->cloud[0], &T = h->cloud[1];
+  Cloud &S = h->cloud(0), &T = h->cloud(1);
   if (T.n < 4) return SICP_ERR_TOO_FEW_POINTS;
   SICPCHECK(prepare_cloud(h, S));
   SICPCHECK(prepare_cloud(h, T));

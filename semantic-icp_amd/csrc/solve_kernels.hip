@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 
 #define SICP_HD __host__ __device__
 #include "kernels.h"
@@ -627,6 +628,72 @@ hipError_t launch_accumulate_batch(int K, const BatchArgs* batch, int n, int max
   }
 #undef SICP_AB
   return hipGetLastError();
+}
+
+// ---- the batched inner solve as a graph with explicit nodes --------------------------------------
+static void* accumulate_batch_fn(int K) {
+  static const int pf = [] { const char* e = getenv("SICP_ACC_BATCH_PF"); return e ? atoi(e) : 4; }();  // tuning aid
+  switch (K) {
+    case 1: return pf == 8 ? (void*)accumulate_batch_kernel<1, 256, 8> : (void*)accumulate_batch_kernel<1, 256, 4>;
+    case 4: return pf == 8 ? (void*)accumulate_batch_kernel<4, 256, 8> : (void*)accumulate_batch_kernel<4, 256, 4>;
+    case 20: return pf == 8 ? (void*)accumulate_batch_kernel<20, 256, 8> : (void*)accumulate_batch_kernel<20, 256, 4>;
+    default: return nullptr;
+  }
+}
+
+static void batch_node_params(int K, const BatchArgs** arg, void** slot, int n, int max_nb, hipKernelNodeParams& acc, hipKernelNodeParams& step) {
+  slot[0] = (void*)arg;
+  memset(&acc, 0, sizeof acc);
+  acc.func = accumulate_batch_fn(K);
+  acc.gridDim = dim3(max_nb, n);
+  acc.blockDim = dim3(256);
+  acc.kernelParams = slot;
+  memset(&step, 0, sizeof step);
+  step.func = (void*)lm_step_batch_kernel;
+  step.gridDim = dim3(n);
+  step.blockDim = dim3(64);
+  step.kernelParams = slot;
+}
+
+void batch_graph_destroy(BatchGraph& g) {
+  if (g.exec) (void)hipGraphExecDestroy(g.exec);
+  if (g.graph) (void)hipGraphDestroy(g.graph);
+  g.exec = nullptr; g.graph = nullptr; g.len = 0;
+}
+
+hipError_t batch_graph_prepare(BatchGraph& g, int K, const BatchArgs* batch, int n, int max_nb, int len, int* built) {
+  *built = 0;
+  if (n <= 0 || max_nb <= 0 || len < 1 || len > kMaxBatchLen || !accumulate_batch_fn(K)) return hipErrorInvalidValue;
+  const BatchArgs* arg = batch;
+  void* slot[1];
+  hipKernelNodeParams pa, ps;
+  batch_node_params(K, &arg, slot, n, max_nb, pa, ps);
+  if (g.exec && g.K == K && g.len == len && g.batch == batch) {
+    if (g.n == n && g.max_nb == max_nb) return hipSuccess;
+    hipError_t e = hipSuccess;
+    for (int b = 0; b < len && e == hipSuccess; ++b) {
+      e = hipGraphExecKernelNodeSetParams(g.exec, g.acc[b], &pa);
+      if (e == hipSuccess) e = hipGraphExecKernelNodeSetParams(g.exec, g.step[b], &ps);
+    }
+    if (e == hipSuccess) { g.n = n; g.max_nb = max_nb; return hipSuccess; }
+    (void)hipGetLastError();  // fall through: rebuild
+  }
+  batch_graph_destroy(g);
+  hipError_t e = hipGraphCreate(&g.graph, 0);
+  if (e != hipSuccess) return e;
+  hipGraphNode_t prev = nullptr;
+  for (int b = 0; b < len; ++b) {
+    e = hipGraphAddKernelNode(&g.acc[b], g.graph, prev ? &prev : nullptr, prev ? 1 : 0, &pa);
+    if (e != hipSuccess) return e;
+    e = hipGraphAddKernelNode(&g.step[b], g.graph, &g.acc[b], 1, &ps);
+    if (e != hipSuccess) return e;
+    prev = g.step[b];
+  }
+  e = hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0);
+  if (e != hipSuccess) return e;
+  g.K = K; g.len = len; g.n = n; g.max_nb = max_nb; g.batch = batch;
+  *built = 1;
+  return hipSuccess;
 }
 
 hipError_t launch_lm_step_batch(const BatchArgs* batch, int n, hipStream_t st) {

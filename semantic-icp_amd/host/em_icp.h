@@ -18,8 +18,13 @@ class EmIterativeClosestPoint {
   typedef pcl::PointXYZL PointT;
   typedef typename pcl::PointCloud<PointT> PointCloud;
   typedef typename PointCloud::Ptr PointCloudPtr;
+  // reference: em_icp.h:22-35
   typedef std::vector<Eigen::Matrix3d, Eigen::aligned_allocator<Eigen::Matrix3d>> MatricesVector;
+  typedef std::vector<Eigen::Matrix<double, 6, 6>, Eigen::aligned_allocator<Eigen::Matrix<double, 6, 6>>> CovarianceVector;
+  typedef std::vector<Eigen::Matrix<double, (int)N, 1>, Eigen::aligned_allocator<Eigen::Matrix<double, (int)N, 1>>> DistVector;
   typedef std::shared_ptr<MatricesVector> MatricesVectorPtr;
+  typedef std::shared_ptr<const MatricesVector> MatricesVectorConstPtr;
+  typedef std::shared_ptr<DistVector> DistVectorPtr;
   typedef typename pcl::KdTreeFLANN<PointT> KdTree;
   typedef typename KdTree::Ptr KdTreePtr;
   typedef Eigen::Matrix<double, 6, 1> Vector6d;
@@ -40,6 +45,9 @@ class EmIterativeClosestPoint {
     detail::check(sicp_set_confusion(h, (int32_t)N, cm), h, "sicp_set_confusion");
     cm_set_ = true;
   }
+
+  // reference: em_icp.h:73-74 declares this overload (and never defines it): identity start
+  void align(PointCloudPtr finalCloud) { align(finalCloud, Sophus::SE3d()); }
 
   // reference: impl/em_icp.hpp:25-200 (finalCloud may be nullptr, :194)
   void align(PointCloudPtr finalCloud, const Sophus::SE3d& initTransform) {

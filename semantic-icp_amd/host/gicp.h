@@ -29,6 +29,8 @@ class GICP {
   // accepted and handed back by the getters, but align() recomputes the covariances from the
   // cloud, as the reference does (impl/gicp.hpp:33-34).  (exec/kitti_eval.cc:213 passes the tree
   // of a *different* scan there -- SURVEY.md quirk Q7 -- which this engine therefore ignores.)
+  // The covariance vectors align() fills (impl/gicp.hpp:33-34) are fetched from the GPU on the
+  // first getSourceCovariances() / getTargetCovariances() call after an align(), not inside it.
   inline void setSourceCloud(const PointCloudPtr& cloud) {
     sourceCloud_ = cloud;
     sourceKdTree_ = KdTreePtr(new KdTree());
@@ -48,9 +50,9 @@ class GICP {
     targetCloud_ = cloud; targetKdTree_ = tree; targetCovariances_ = covs;
   }
   inline KdTreePtr getSourceKdTree() { return sourceKdTree_; }
-  inline MatricesVectorPtr getSourceCovariances() { return sourceCovariances_; }
+  inline MatricesVectorPtr getSourceCovariances() { fetch_covariances(SICP_SOURCE, sourceCovariances_, source_cov_stale_); return sourceCovariances_; }
   inline KdTreePtr getTargetKdTree() { return targetKdTree_; }
-  inline MatricesVectorPtr getTargetCovariances() { return targetCovariances_; }
+  inline MatricesVectorPtr getTargetCovariances() { fetch_covariances(SICP_TARGET, targetCovariances_, target_cov_stale_); return targetCovariances_; }
 
   void align(PointCloudPtr finalCloud) {  // reference: impl/gicp.hpp:21-27
     Sophus::SE3d init;
@@ -72,8 +74,7 @@ class GICP {
     detail::check(sicp_align(h, initTransform.data(), out, &iters, nullptr), h, "sicp_align");
     finalTransformation_ = detail::to_se3(out);
     outer_iter = iters;
-    fill_covariances(h, SICP_SOURCE, s.size(), sourceCovariances_);
-    fill_covariances(h, SICP_TARGET, t.size(), targetCovariances_);
+    source_cov_stale_ = target_cov_stale_ = true;  // filled on demand by the getters
     if (finalCloud != nullptr) {  // impl/gicp.hpp:166-172
       Eigen::Matrix4f mat = (finalTransformation_.matrix()).template cast<float>();
       pcl::transformPointCloud(*sourceCloud_, *finalCloud, mat);
@@ -94,7 +95,6 @@ class GICP {
     std::vector<sicp_handle> hs(n);
     std::vector<double> init(7 * n), out(7 * n);
     std::vector<int32_t> iters(n, 0);
-    std::vector<int> ns(n), nt(n);
     for (size_t q = 0; q < n; ++q) {
       GICP& o = *objs[q];
       sicp_handle h = hs[q] = o.engine_.get();
@@ -104,7 +104,6 @@ class GICP {
       p.epsilon = o.epsilon_;
       detail::check(sicp_set_params(h, &p), h, "sicp_set_params");
       detail::FlatCloud s = detail::flatten(*o.sourceCloud_), t = detail::flatten(*o.targetCloud_);
-      ns[q] = s.size(); nt[q] = t.size();
       detail::check(sicp_set_cloud(h, SICP_SOURCE, s.size(), s.x.data(), s.y.data(), s.z.data(), nullptr), h, "sicp_set_cloud");
       detail::check(sicp_set_cloud(h, SICP_TARGET, t.size(), t.x.data(), t.y.data(), t.z.data(), nullptr), h, "sicp_set_cloud");
       for (int i = 0; i < 7; ++i) init[7 * q + i] = initTransforms[q].data()[i];
@@ -114,8 +113,7 @@ class GICP {
       GICP& o = *objs[q];
       o.finalTransformation_ = detail::to_se3(&out[7 * q]);
       o.outer_iter = iters[q];
-      o.fill_covariances(hs[q], SICP_SOURCE, ns[q], o.sourceCovariances_);
-      o.fill_covariances(hs[q], SICP_TARGET, nt[q], o.targetCovariances_);
+      o.source_cov_stale_ = o.target_cov_stale_ = true;
       if (finalClouds[q] != nullptr) {
         Eigen::Matrix4f mat = (o.finalTransformation_.matrix()).template cast<float>();
         pcl::transformPointCloud(*o.sourceCloud_, *finalClouds[q], mat);
@@ -124,7 +122,12 @@ class GICP {
   }
 
  protected:
-  void fill_covariances(sicp_handle h, int which, int n, MatricesVectorPtr& out) {
+  // what align() computed on the GPU (normals -> C = I - (1-eps) n n^T), copied out once per align
+  void fetch_covariances(int which, MatricesVectorPtr& out, bool& stale) {
+    if (!stale) return;
+    stale = false;
+    sicp_handle h = engine_.get();
+    const int n = (int)(which == SICP_SOURCE ? sourceCloud_ : targetCloud_)->size();
     if (!out) out = MatricesVectorPtr(new MatricesVector());
     out->resize(n);
     if (n == 0) return;
@@ -138,6 +141,7 @@ class GICP {
   int kCorrespondences_;
   double epsilon_;
   int outer_iter;
+  bool source_cov_stale_ = false, target_cov_stale_ = false;
   Sophus::SE3d finalTransformation_;
   PointCloudPtr sourceCloud_;
   KdTreePtr sourceKdTree_;
