@@ -236,6 +236,16 @@ int sicp_accumulate_batch(sicp_handle* handles, int32_t n, const double* qt, dou
 int sicp_solve(sicp_handle h, const double init_qt[7], double out_qt[7], int32_t* lm_iters,
                int32_t* evals, double* final_cost);
 
+/* the device build of csrc/se3.hpp (what the device-resident LM step runs in place of Sophus,
+ * local_parameterization_se3.h:17-25), one lane per item; op and layouts:
+ *   SICP_SE3_EXP  in n*6 tangents [upsilon; omega]      -> out n*7 poses
+ *   SICP_SE3_LOG  in n*7 poses                          -> out n*6
+ *   SICP_SE3_PLUS in n*13 = pose (7) | delta (6)        -> out n*7 = pose * exp(delta)
+ *   SICP_SE3_MUL  in n*14 = pose a (7) | pose b (7)     -> out n*7
+ *   SICP_SE3_INV  in n*7                                -> out n*7 */
+enum { SICP_SE3_EXP = 0, SICP_SE3_LOG = 1, SICP_SE3_PLUS = 2, SICP_SE3_MUL = 3, SICP_SE3_INV = 4 };
+int sicp_se3_device(sicp_handle h, int op, int32_t n, const double* in, double* out);
+
 /* counters accumulated since the last sicp_align() began (the hooks above add to them) */
 int sicp_get_stats(sicp_handle h, sicp_stats* stats);
 

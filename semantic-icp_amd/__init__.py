@@ -24,6 +24,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 
 MODE_GICP, MODE_EM, MODE_SEMANTIC = 0, 1, 2
 SOURCE, TARGET = 0, 1
+SE3_EXP, SE3_LOG, SE3_PLUS, SE3_MUL, SE3_INV = 0, 1, 2, 3, 4
 
 OK = 0
 ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_READY = -1, -2, -3, -4
@@ -159,6 +160,7 @@ def lib():
             "sicp_correspondences": [C.c_void_p, _dp, _ip, _fp, _dp],
             "sicp_accumulate": [C.c_void_p, _dp, _dp],
             "sicp_solve": [C.c_void_p, _dp, _dp, _ip, _ip, _dp],
+            "sicp_se3_device": [C.c_void_p, C.c_int, C.c_int32, _dp, _dp],
             "sicp_get_stats": [C.c_void_p, C.POINTER(SicpStats)],
             "sicp_synchronize": [C.c_void_p],
         }.items():
@@ -327,6 +329,14 @@ class Engine:
         it, ev, fc = C.c_int32(), C.c_int32(), C.c_double()
         self._check(lib().sicp_solve(self._h, _ptr(init, _dp), _ptr(out, _dp), C.byref(it), C.byref(ev), C.byref(fc)), "sicp_solve")
         return out, dict(lm_iters=it.value, evals=ev.value, cost=fc.value)
+
+    def se3_device(self, op: int, x):
+        """sicp_se3_device: csrc/se3.hpp evaluated on the GPU (op = SE3_EXP / LOG / PLUS / MUL / INV), one row per item."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        n = x.shape[0]
+        out = np.empty((n, 6 if op == SE3_LOG else 7))
+        self._check(lib().sicp_se3_device(self._h, op, n, _ptr(x, _dp), _ptr(out, _dp)), "sicp_se3_device")
+        return out
 
     def stats(self):
         st = SicpStats()

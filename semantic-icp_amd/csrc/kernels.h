@@ -193,6 +193,8 @@ hipError_t launch_accumulate_batch(int K, const BatchArgs* batch, int n, int max
 hipError_t launch_lm_step_batch(const BatchArgs* batch, int n, hipStream_t st);
 hipError_t launch_finalize_batch(const BatchArgs* batch, int n, double* out28, hipStream_t st);
 hipError_t launch_count_active(const int* idx, int n, unsigned long long* out, hipStream_t st);
+// test hook: csrc/se3.hpp on the device, one lane per item (op = SICP_SE3_*; in/out strides per op)
+hipError_t launch_se3_ops(int op, int n, const double* in, double* out, hipStream_t st);
 hipError_t launch_transform_float(int n, const float* x, const float* y, const float* z, const Mat4f& M,
                                   float* ox, float* oy, float* oz, hipStream_t st);
 

@@ -1527,6 +1527,22 @@ int sicp_fused_labels(sicp_handle h, const double qt[7], uint32_t* out_labels) {
   return SICP_OK;
 }
 
+int sicp_se3_device(sicp_handle h, int op, int32_t n, const double* in, double* out) {
+  if (!h || op < SICP_SE3_EXP || op > SICP_SE3_INV || n < 0 || (n > 0 && (!in || !out))) return SICP_ERR_INVALID_ARGUMENT;
+  if (n == 0) return SICP_OK;
+  SICPCHECK(set_device(h));
+  const size_t n_in = op == SICP_SE3_EXP ? 6 : (op == SICP_SE3_PLUS ? 13 : (op == SICP_SE3_MUL ? 14 : 7));
+  const size_t n_out = op == SICP_SE3_LOG ? 6 : 7;
+  DevBuf<double> d_in, d_out;
+  HIPCHECK(d_in.reserve(n_in * n));
+  HIPCHECK(d_out.reserve(n_out * n));
+  HIPCHECK(hipMemcpyAsync(d_in.p, in, sizeof(double) * n_in * n, hipMemcpyHostToDevice, h->stream));
+  HIPCHECK(sicp::launch_se3_ops(op, n, d_in.p, d_out.p, h->stream));
+  HIPCHECK(hipMemcpyAsync(out, d_out.p, sizeof(double) * n_out * n, hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  return SICP_OK;
+}
+
 int sicp_get_stats(sicp_handle h, sicp_stats* stats) {
   if (!h || !stats) return SICP_ERR_INVALID_ARGUMENT;
   *stats = h->st;

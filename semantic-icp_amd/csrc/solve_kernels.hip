@@ -733,6 +733,29 @@ hipError_t launch_accumulate_fused(const AccArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 
+// test hook (sicp_se3_device): the SE(3) code of the device-resident solve, one lane per item
+__global__ __launch_bounds__(64) void se3_ops_kernel(int op, int n, const double* __restrict__ in, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double a[14], o[7];
+  const int n_in = op == 0 ? 6 : (op == 2 ? 13 : (op == 3 ? 14 : 7)), n_out = op == 1 ? 6 : 7;
+  for (int k = 0; k < n_in; ++k) a[k] = in[(size_t)i * n_in + k];
+  switch (op) {
+    case 0: se3::exp(a, o); break;
+    case 1: se3::log(a, o); break;
+    case 2: se3::plus(a, a + 7, o); break;
+    case 3: se3::mul(a, a + 7, o); break;
+    default: se3::inverse(a, o); break;
+  }
+  for (int k = 0; k < n_out; ++k) out[(size_t)i * n_out + k] = o[k];
+}
+
+hipError_t launch_se3_ops(int op, int n, const double* in, double* out, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(se3_ops_kernel, dim3((n + 63) / 64), dim3(64), 0, st, op, n, in, out);
+  return hipGetLastError();
+}
+
 hipError_t launch_accumulate_kernel(const AccArgs& a, hipStream_t st) {
   return launch_accumulate_only(a, accumulate_blocks(a.n_s * a.K), st);
 }

@@ -1,0 +1,306 @@
+"""GPU parity at the FULL sizes of BASELINE.json's configs (-m gpu), through the C ABI.
+
+  config 2: KITTI-like full scan pair (~142K x 142K, 11 classes): EM-ICP and SE3-GICP (K = 1)
+            exec/kitti_eval.cc:184-192, 207-216
+  config 3: RGB-D frame pair, 640x480 = 307 200 points, 13 classes, eps = 1e-6: EM-ICP
+            (exec/scenenet_eval.cc:174) and SemanticICP (exec/nyu_eval.cc:139)
+  config 4: 1M x 1M points, 20 classes, full EM outer loop
+  and a lock-step batch of 16 DIFFERENT pairs (seeds and sizes 60K..140K).
+
+At these sizes the oracle is used three ways: whole `align()` runs where it finishes in tens of
+seconds (142K, 307K), 2000 sampled kd-tree rows for the searches, and one full evaluation sweep
+(the 28 sums over every correspondence) at 1M.  Everything else is a size-independent property:
+sortedness, the gate, distance self-consistency, SPD Hessian, planted-pose recovery,
+bit-determinism.
+"""
+import importlib
+
+import numpy as np
+import pytest
+from scipy.spatial.transform import Rotation
+
+import oracle_lib as O
+import synth
+from checks import assert_normals_match
+from np_ref import mat_to_qt
+
+pytestmark = pytest.mark.gpu
+
+sicp = importlib.import_module("semantic-icp_amd")
+IDENT = np.array([0, 0, 0, 1, 0, 0, 0.0])
+ROT_TOL, TRANS_TOL = 1e-4, 1e-3  # north star: pose within 1e-4 rad / 1e-3 m of the reference solve
+
+
+def pose_delta(qa, qb):
+    D = np.linalg.inv(O.se3_matrix(qa)) @ O.se3_matrix(qb)
+    return np.linalg.norm(Rotation.from_matrix(D[:3, :3]).as_rotvec()), np.linalg.norm(D[:3, 3])
+
+
+def pose_err_to_matrix(q, T):
+    D = np.linalg.inv(T) @ O.se3_matrix(q)
+    return np.linalg.norm(Rotation.from_matrix(D[:3, :3]).as_rotvec()), np.linalg.norm(D[:3, 3])
+
+
+def make_engine(mode, C=0, cm=None, **kw):
+    p = sicp.default_params(mode)
+    p.num_classes = C
+    for k, v in kw.items():
+        setattr(p, k, v)
+    e = sicp.Engine(0, p)
+    if cm is not None:
+        e.set_confusion(cm)
+    return e
+
+
+def oracle_params(mode, C=0, **kw):
+    p = O.default_params(mode)
+    p.num_classes = C
+    p.use_kdtree = 1
+    p.num_threads = 8
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def check_search_properties(e, src, tgt, qt, K, n_rows=2000, gate=250.0):
+    """Sorted, gated, self-consistent float32 distances; `n_rows` rows bit-equal to the kd-tree oracle."""
+    idx, d2, w = e.correspondences(qt)
+    n = len(src)
+    assert idx.shape == (n, K) and d2.shape == (n, K)
+    assert (np.diff(d2, axis=1) >= 0).all()
+    assert ((idx >= 0) == (d2 < np.float32(gate))).all()
+    assert idx.max() < len(tgt)
+    q = O.transform_points(O.se3_matrix(qt), src)
+    rows = np.random.default_rng(0).choice(n, n_rows, replace=False)
+    oi, od = O.knn(q[rows], tgt, K, kdtree=True)
+    oi[~(od < np.float32(gate))] = -1
+    assert np.array_equal(idx[rows], oi) and np.array_equal(d2[rows], od)
+    # every reported distance is the FLANN L2_Simple float32 distance to the reported point
+    dd = q[:, None, :] - tgt[np.maximum(idx, 0)]
+    rec = (dd[..., 0] * dd[..., 0] + dd[..., 1] * dd[..., 1]) + dd[..., 2] * dd[..., 2]
+    assert np.array_equal(rec[idx >= 0], d2[idx >= 0])
+    assert (w >= 0).all() and (w[idx < 0] == 0).all() and w.max() <= 1.0 + 1e-12
+    return idx, d2, w
+
+
+def hessian_of(a28):
+    H = np.zeros((6, 6))
+    H[np.triu_indices(6)] = a28[:21]
+    return H + H.T - np.diag(np.diag(H))
+
+
+# ------------------------------------------------------------------------------------------------
+# config 2: full LiDAR scan pair
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def lidar_full():
+    return synth.lidar_pair(seed=2, n_points=None)
+
+
+@pytest.mark.parametrize("mode,K,C", [(sicp.MODE_EM, 4, 11), (sicp.MODE_GICP, 1, 0)], ids=["em", "se3gicp"])
+def test_config2_full_scan_vs_oracle(lidar_full, mode, K, C):
+    src, sl, tgt, tl, T_gt, cm = lidar_full
+    assert 120_000 < len(src) < 150_000 and 120_000 < len(tgt) < 150_000
+    labelled = mode == sicp.MODE_EM
+    e = make_engine(mode, C, cm if labelled else None)
+    try:
+        e.set_source(src, sl if labelled else None)
+        e.set_target(tgt, tl if labelled else None)
+        qt0 = mat_to_qt(synth.pose_matrix(0.5, (0, 0, 1), (0.2, 0.1, 0.0)))
+        check_search_properties(e, src, tgt, qt0, K)
+        a1, a2 = e.accumulate(qt0), e.accumulate(qt0)
+        assert np.array_equal(a1, a2) and np.linalg.eigvalsh(hessian_of(a1)).min() > 0
+        qt, st = e.align()
+        oq, ost = O.align(oracle_params(mode, C), src, sl if labelled else None, tgt, tl if labelled else None,
+                          cm if labelled else None, IDENT)
+        rot, tr = pose_delta(qt, oq)
+        assert rot < ROT_TOL and tr < TRANS_TOL, (rot, tr)
+        assert rot < 1e-7 and tr < 1e-7, (rot, tr)  # what is actually achieved
+        assert st["outer_iters"] == ost["outer_iters"] and st["total_corr"] == ost["total_corr"]
+        assert st["total_active"] == ost["total_active"] and st["total_lm_iters"] == ost["total_lm_iters"]
+        rot, tr = pose_err_to_matrix(qt, T_gt)
+        assert rot < 2e-3 and tr < 2e-2, (rot, tr)
+        qt_b, st_b = e.align()
+        assert np.array_equal(qt, qt_b) and st["total_evals"] == st_b["total_evals"]  # bit-deterministic
+    finally:
+        e.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# config 3: 640x480 RGB-D frame pair, 13 classes, eps = 1e-6
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def rgbd_full():
+    return synth.rgbd_pair(seed=3)
+
+
+def test_config3_full_frame_em_vs_oracle(rgbd_full):
+    src, sl, tgt, tl, T_gt, cm = rgbd_full
+    assert len(src) == 307_200 and len(tgt) == 307_200
+    e = make_engine(sicp.MODE_EM, 13, cm, epsilon=1e-6)
+    try:
+        e.set_source(src, sl)
+        e.set_target(tgt, tl)
+        qt0 = mat_to_qt(synth.pose_matrix(0.4, (0.2, 1.0, 0.1), (0.01, 0.0, 0.01)))
+        check_search_properties(e, src, tgt, qt0, 4)
+        a1 = e.accumulate(qt0)
+        assert np.array_equal(a1, e.accumulate(qt0)) and np.linalg.eigvalsh(hessian_of(a1)).min() > 0
+        # covariance neighbourhoods: 2000 self-kNN rows (k = 20) and their label histograms
+        _, nrm, hist, nbr = e.covariances(sicp.SOURCE, want_hist=True, want_nn=True)
+        rows = np.random.default_rng(1).choice(len(src), 2000, replace=False)
+        onn, _ = O.knn(src[rows], src, 20, kdtree=True)
+        assert np.array_equal(nbr[rows], onn)
+        want_hist = np.stack([np.bincount(sl[onn[r]] - 1, minlength=13) for r in range(len(rows))]).astype(np.uint8)
+        assert np.array_equal(hist[rows], want_hist)
+        assert np.allclose(np.linalg.norm(nrm, axis=1), 1.0, atol=1e-12)
+        # whole align() against the oracle
+        qt, st = e.align()
+        oq, ost = O.align(oracle_params(sicp.MODE_EM, 13, epsilon=1e-6), src, sl, tgt, tl, cm, IDENT)
+        rot, tr = pose_delta(qt, oq)
+        assert rot < ROT_TOL and tr < TRANS_TOL, (rot, tr)
+        assert st["outer_iters"] == ost["outer_iters"] and st["total_active"] == ost["total_active"]
+        assert st["total_lm_iters"] == ost["total_lm_iters"]
+        rot, tr = pose_err_to_matrix(qt, T_gt)
+        assert rot < 2e-3 and tr < 1e-2, (rot, tr)
+        qt_b, _ = e.align()
+        assert np.array_equal(qt, qt_b)
+        # getFusedLabels at full size: bit-equal to the oracle's arg-max
+        lab = e.fused_labels(qt)
+        olab = O.fused_labels(oracle_params(sicp.MODE_EM, 13, epsilon=1e-6), src, sl, tgt, tl, cm, qt)
+        assert np.array_equal(lab, olab)
+    finally:
+        e.close()
+
+
+def test_config3_full_frame_semantic_icp_vs_oracle(rgbd_full):
+    src, sl, tgt, tl, T_gt, cm = rgbd_full
+    e = make_engine(sicp.MODE_SEMANTIC)
+    try:
+        e.set_source(src, sl)
+        e.set_target(tgt, tl)
+        idx, d2, w = e.correspondences(IDENT)
+        # per-class search: a correspondence never crosses labels; classes with <= 400 source points are skipped
+        live = idx[:, 0] >= 0
+        assert (tl[idx[live, 0]] == sl[live]).all()
+        counts = {int(l): int((sl == l).sum()) for l in np.unique(sl)}
+        for l, c in counts.items():
+            if c <= 400 or not (tl == l).any():
+                assert (idx[sl == l] == -1).all()
+        qt, st = e.align()
+        oq, ost = O.align(oracle_params(sicp.MODE_SEMANTIC), src, sl, tgt, tl, None, IDENT)
+        rot, tr = pose_delta(qt, oq)
+        assert rot < ROT_TOL and tr < TRANS_TOL, (rot, tr)
+        assert st["outer_iters"] == ost["outer_iters"] and st["total_active"] == ost["total_active"]
+        rot, tr = pose_err_to_matrix(qt, T_gt)
+        assert rot < 3e-3 and tr < 2e-2, (rot, tr)
+        qt_b, _ = e.align()
+        assert np.array_equal(qt, qt_b)
+    finally:
+        e.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# config 4: 1M x 1M, 20 classes, full EM outer loop
+# ------------------------------------------------------------------------------------------------
+def test_config4_one_million_points():
+    src, sl, tgt, tl, T_gt, cm = synth.facets_pair(seed=4)
+    assert len(src) == 1_000_000 and len(tgt) == 1_000_000
+    e = make_engine(sicp.MODE_EM, 20, cm)
+    try:
+        e.set_source(src, sl)
+        e.set_target(tgt, tl)
+        qt0 = mat_to_qt(synth.pose_matrix(1.5, (0.3, -0.2, 1.0), (0.3, -0.2, 0.2)))
+        idx, d2, w = check_search_properties(e, src, tgt, qt0, 4)
+        # one full evaluation sweep over all 4M correspondence slots against the oracle's literal
+        # GICPCostFunction::Evaluate + losses (full 3x3 covariances from the oracle's own k = 20 PCA)
+        scov, snrm, _ = O.covariances(src, None, 20, 1e-3, kdtree=True)
+        tcov, tnrm, _ = O.covariances(tgt, None, 20, 1e-3, kdtree=True)
+        got = e.accumulate(qt0)
+        ref = O.accumulate(oracle_params(sicp.MODE_EM, 20), qt0, src, scov, tgt, tcov, idx, w)
+        scale = np.abs(ref[:21]).max()
+        assert np.allclose(got[:21], ref[:21], rtol=0, atol=1e-9 * scale)
+        assert np.allclose(got[21:27], ref[21:27], rtol=0, atol=1e-9 * np.abs(ref[21:27]).max() + 1e-9 * scale)
+        assert np.isclose(got[27], ref[27], rtol=1e-10)
+        assert np.array_equal(got, e.accumulate(qt0))
+        assert np.linalg.eigvalsh(hessian_of(got)).min() > 0
+        # GPU normals vs the oracle's at full size, wherever the PCA direction is well conditioned
+        _, nrm, _, nbr = e.covariances(sicp.SOURCE, want_nn=True)
+        assert_normals_match(nrm, snrm, src, nbr)
+        # whole align(): planted-pose recovery, counters, bit-determinism
+        qt, st = e.align()
+        rot, tr = pose_err_to_matrix(qt, T_gt)
+        assert rot < 1e-3 and tr < 1e-2, (rot, tr)
+        assert st["total_corr"] == 4_000_000 * st["outer_iters"] and 0 < st["total_active"] <= st["total_corr"]
+        qt_b, st_b = e.align()
+        assert np.array_equal(qt, qt_b) and st_b["total_evals"] == st["total_evals"]
+        qt2, st2 = e.align(qt)
+        assert st2["outer_iters"] == 1
+    finally:
+        e.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# lock-step batch of 16 different pairs: different scenes, motions and sizes
+# ------------------------------------------------------------------------------------------------
+def heterogeneous_pairs(n_pairs=16):
+    rng = np.random.default_rng(99)
+    pairs = []
+    for k in range(n_pairs):
+        n = int(rng.integers(60_000, 140_001))
+        motion = (float(rng.uniform(0.4, 1.6)), float(rng.uniform(-3.0, 3.0)))
+        ps, ls, pt, lt, T, cm = synth.lidar_pair(seed=100 + k, n_points=None, motion=motion)
+        # ragged: source and target sizes differ, and differ between pairs
+        ns, nt = min(n, len(ps)), min(int(n * rng.uniform(0.85, 1.0)), len(pt))
+        ss = np.sort(rng.choice(len(ps), ns, replace=False))
+        tt = np.sort(rng.choice(len(pt), nt, replace=False))
+        pairs.append((ps[ss], ls[ss], pt[tt], lt[tt], T, cm))
+    return pairs
+
+
+@pytest.mark.parametrize("mode", ["em", "gicp"])
+def test_heterogeneous_batch_equals_lone_aligns(mode):
+    m = sicp.MODE_EM if mode == "em" else sicp.MODE_GICP
+    pairs = heterogeneous_pairs(16)
+    engines, singles = [], []
+    try:
+        for ps, ls, pt, lt, T, cm in pairs:
+            e = make_engine(m, 11 if mode == "em" else 0, cm if mode == "em" else None)
+            e.set_source(ps, ls if mode == "em" else None)
+            e.set_target(pt, lt if mode == "em" else None)
+            engines.append(e)
+            singles.append(e.align(IDENT))
+        sizes = {(len(p[0]), len(p[2])) for p in pairs}
+        assert len(sizes) == 16
+        outers = [s["outer_iters"] for _, s in singles]
+        evals = [s["total_evals"] for _, s in singles]
+        assert len(set(evals)) > 4, evals  # the pairs really do differ in work
+        res = sicp.align_batch(engines)
+        for k, ((qb, sb), (q1, s1)) in enumerate(zip(res, singles)):
+            assert np.array_equal(qb, q1), k  # per pair the bits of a lone align()
+            for key in ("outer_iters", "total_lm_iters", "total_evals", "total_corr", "total_active"):
+                assert sb[key] == s1[key], (k, key)
+            rot, tr = pose_err_to_matrix(qb, pairs[k][4])
+            assert rot < 3e-3 and tr < 3e-2, (k, rot, tr)
+        # idle accounting: a pair sits through every launch of the batch, its own evaluations are fewer
+        slots = [s["lockstep_slots"] for _, s in res]
+        assert len(set(slots)) == 1 and slots[0] >= max(evals)
+        assert sum(s["graph_builds"] for _, s in res) <= 1
+        # a different sub-batch (other leader, other sizes) and the first batch again: same bits,
+        # and the instantiated graph is updated in place rather than rebuilt
+        res2 = sicp.align_batch(engines[3:11])
+        for (qb, _), (q1, _) in zip(res2, singles[3:11]):
+            assert np.array_equal(qb, q1)
+        res3 = sicp.align_batch(engines)
+        for (qb, sb), (q1, _) in zip(res3, singles):
+            assert np.array_equal(qb, q1)
+        assert sum(s["graph_builds"] for _, s in res3) == 0
+        # spot check against the oracle: the smallest pair, whole align()
+        k = int(np.argmin([len(p[0]) for p in pairs]))
+        ps, ls, pt, lt, T, cm = pairs[k]
+        oq, ost = O.align(oracle_params(m, 11 if mode == "em" else 0), ps, ls if mode == "em" else None, pt,
+                          lt if mode == "em" else None, cm if mode == "em" else None, IDENT)
+        rot, tr = pose_delta(res[k][0], oq)
+        assert rot < 1e-7 and tr < 1e-7 and res[k][1]["outer_iters"] == ost["outer_iters"]
+    finally:
+        for e in engines:
+            e.close()

@@ -227,7 +227,7 @@ def test_scenenet_eval_headless_rows_and_fused_labels(tmp_path):
                 fp, fl = read_pcd_ascii(f"{prefix}{b}.pcd")
                 assert np.allclose(fp, ps, atol=1e-5)
                 olab = O.fused_labels(p, ps, ls, pt, lt, cm, oq)
-                assert np.mean(fl == olab) > 0.999
+                assert np.array_equal(fl, olab)
     # -b 2: both frame pairs registered together (alignBatch): identical rows and label files
     prefix2 = str(tmp_path / "b_")
     r2 = subprocess.run([exe, "-s", str(d), "-t", gt, "-m", cmf, "-o", prefix2, "-b", "2"], capture_output=True, text=True, timeout=900)
