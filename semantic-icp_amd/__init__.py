@@ -143,6 +143,7 @@ def lib():
         for name, args in {
             "sicp_device_count": [C.POINTER(C.c_int)],
             "sicp_create": [C.c_int, C.POINTER(C.c_void_p)],
+            "sicp_release_pool": [C.c_int],
             "sicp_destroy": [C.c_void_p],
             "sicp_default_params": [C.c_int, C.POINTER(SicpParams)],
             "sicp_set_params": [C.c_void_p, C.POINTER(SicpParams)],

@@ -182,14 +182,16 @@ __device__ __forceinline__ void load_query(const float* qx, const float* qy, con
 // k_out <= K entries are written (the k nearest are the first k of a longer exact list)
 template <int K>
 __device__ __forceinline__ void emit(const u64 (&bk)[K], const int* inv, float gate_sq, int* out_i, float* out_d, size_t o, int k_out) {
+  // fully unrolled (the list lives in registers: no dynamic index), entries beyond k_out predicated off
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    if (k >= k_out) break;
     const unsigned orig = (unsigned)bk[k];
     const float d = bk[k] == KEY_EMPTY ? INFINITY : key_dist(bk[k]);
     const bool keep = orig != 0xffffffffu && d < gate_sq;  // strict <, float compare (em_icp.hpp:65)
-    out_i[o + k] = keep ? inv[orig] : -1;
-    if (out_d) out_d[o + k] = d;
+    if (k < k_out) {
+      out_i[o + k] = keep ? inv[orig] : -1;
+      if (out_d) out_d[o + k] = d;
+    }
   }
 }
 

@@ -14,6 +14,7 @@
 #include <cstring>
 #include <limits>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -52,15 +53,49 @@ struct DevBuf {
   }
 };
 
+// pinned host memory: uploads and read-backs through it are real asynchronous DMA copies
+template <class T>
+struct HostBuf {
+  T* p = nullptr;
+  size_t cap = 0, n = 0;
+  HostBuf() = default;
+  HostBuf(const HostBuf&) = delete;
+  HostBuf& operator=(const HostBuf&) = delete;
+  ~HostBuf() { if (p) (void)hipHostFree(p); }
+  hipError_t resize(size_t count) {
+    if (count > cap) {
+      if (p) (void)hipHostFree(p);
+      p = nullptr; cap = 0;
+      const size_t want = count + count / 8 + 64;
+      hipError_t e = hipHostMalloc((void**)&p, want * sizeof(T), hipHostMallocDefault);
+      if (e != hipSuccess) { p = nullptr; n = 0; return e; }
+      cap = want;
+    }
+    n = count;
+    return hipSuccess;
+  }
+  hipError_t assign(const T* src, size_t count) {
+    hipError_t e = resize(count);
+    if (e == hipSuccess && count) std::memcpy(p, src, count * sizeof(T));
+    return e;
+  }
+  T* data() { return p; }
+  const T* data() const { return p; }
+  size_t size() const { return n; }
+  T& operator[](size_t i) { return p[i]; }
+  const T& operator[](size_t i) const { return p[i]; }
+};
+
 struct Cloud {
   int n = 0;
   bool is_set = false, has_label = false;
-  std::vector<float> hx, hy, hz;  // caller order
-  std::vector<uint32_t> hl;
+  HostBuf<float> hx, hy, hz;  // caller order (pinned: the staging buffers of the upload)
+  HostBuf<uint32_t> hl;
+  uint32_t label_min = 0, label_max = 0;  // of hl (EM labels are validated against 1..C)
   // device layout: one segment (GICP / EM) or one segment per label in first-seen order
   // (SEMANTIC); inside a segment the points are in Morton order
   int layout = -1;        // -1 none, 0 flat, 1 grouped
-  std::vector<int> perm;  // device index -> caller index
+  HostBuf<int> perm;  // device index -> caller index
   std::vector<uint32_t> seg_label;
   std::vector<int> seg_off;  // n_seg + 1
   DevBuf<float> x, y, z;
@@ -79,6 +114,7 @@ struct Cloud {
   DevBuf<float> rx, ry, rz;
   DevBuf<uint32_t> rl;
   DevBuf<int> ids, d_perm, vals_in, vals_out;
+  HostBuf<int> h_ids;
   DevBuf<unsigned long long> keys_in, keys_out;
   DevBuf<unsigned char> sort_temp;
   DevBuf<double> nx, ny, nz;
@@ -97,6 +133,37 @@ struct Cloud {
   int n_seg() const { return (int)seg_label.size(); }
   int caller_index(int d) const { return perm[d]; }
 };
+
+// Clouds (with all their device and pinned buffers) are recycled through a per-device pool: a scan
+// sequence uploads a new cloud per registration, and allocating / freeing ~25 buffers each time would
+// serialise the pipeline (hipFree synchronises the device).  The pool is never destroyed (it may
+// outlive the HIP runtime at process exit); sicp_release_pool frees what it holds.
+struct CloudPool {
+  std::mutex m;
+  std::vector<Cloud*> free_list[64];
+};
+CloudPool& cloud_pool() {
+  static CloudPool* pool = new CloudPool;
+  return *pool;
+}
+
+std::shared_ptr<Cloud> acquire_cloud(int device) {
+  CloudPool& pool = cloud_pool();
+  const int slot = device & 63;
+  Cloud* c = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(pool.m);
+    if (!pool.free_list[slot].empty()) { c = pool.free_list[slot].back(); pool.free_list[slot].pop_back(); }
+  }
+  if (!c) c = new Cloud();
+  return std::shared_ptr<Cloud>(c, [slot](Cloud* dead) {
+    dead->n = 0; dead->is_set = false; dead->has_label = false; dead->layout = -1;
+    dead->feat_valid = false; dead->proj_valid = false; dead->feat_epoch = 0; dead->proj_cm_id = 0;
+    CloudPool& pl = cloud_pool();
+    std::lock_guard<std::mutex> lock(pl.m);
+    pl.free_list[slot].push_back(dead);
+  });
+}
 
 unsigned long long next_epoch() {
   static std::atomic<unsigned long long> counter{0};
@@ -131,7 +198,7 @@ struct sicp_context {
   hipStream_t stream2 = nullptr;  // second cloud's feature kernels run beside the first's
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_join = nullptr;
   sicp_params params;
-  std::shared_ptr<Cloud> cl[2] = {std::make_shared<Cloud>(), std::make_shared<Cloud>()};
+  std::shared_ptr<Cloud> cl[2];
   Cloud& cloud(int which) { return *cl[which]; }
   const Cloud& cloud(int which) const { return *cl[which]; }
   unsigned long long epoch = 0;  // id of the running align() / align_batch() call
@@ -275,9 +342,9 @@ int prepare_cloud(sicp_context* h, Cloud& c) {
     st.lv = g.lv; st.n = g.cnt; st.pt_begin = g.pt_begin; st.node_begin = g.node_begin; st.code_begin = g.code_begin;
     st.lo[0] = g.lo[0]; st.lo[1] = g.lo[1]; st.lo[2] = g.lo[2]; st.scale = g.scale;
   }
-  std::vector<int> ids;
+  HostBuf<int>& ids = c.h_ids;
   if (want) {  // caller indices grouped by segment, cloud order inside a segment
-    ids.resize(n);
+    HIPCHECK(ids.resize(n));
     std::vector<int> fill(c.seg_off.begin(), c.seg_off.end() - 1);
     for (int i = 0; i < n; ++i) ids[fill[which[i]]++] = i;
   }
@@ -308,7 +375,7 @@ int prepare_cloud(sicp_context* h, Cloud& c) {
   b.x = c.x.p; b.y = c.y.p; b.z = c.z.p; b.label = c.label.p; b.perm = c.d_perm.p; b.inv = c.inv.p;
   b.pts4 = c.pts4.p; b.box_lo = c.box_lo.p; b.box_hi = c.box_hi.p; b.leaf_code = c.leaf_code.p;
   HIPCHECK(sicp::build_tree_device(b, segs.data(), n_seg, h->stream));
-  c.perm.resize(n);  // device -> caller order, for returning results in the caller's order
+  HIPCHECK(c.perm.resize(n));  // device -> caller order, for returning results in the caller's order
   if (n > 0) HIPCHECK(hipMemcpyAsync(c.perm.data(), c.d_perm.p, sizeof(int) * n, hipMemcpyDeviceToHost, h->stream));
   HIPCHECK(hipStreamSynchronize(h->stream));  // staging vectors go out of scope
   c.layout = want;
@@ -506,9 +573,10 @@ int check_ready(sicp_context* h, bool need_cm) {
   if (P.mode != SICP_MODE_GICP && (!h->cloud(0).has_label || !h->cloud(1).has_label)) return SICP_ERR_NOT_READY;
   if (P.mode == SICP_MODE_EM || need_cm) {
     if (P.num_classes < 1 || P.num_classes > 255 || h->C != P.num_classes) return SICP_ERR_NOT_READY;
-    for (int wch = 0; wch < 2; ++wch)
-      for (uint32_t l : h->cloud(wch).hl)
-        if (l < 1 || l > (uint32_t)P.num_classes) return SICP_ERR_BAD_LABEL;  // em_icp.hpp:301 indexes label-1
+    for (int wch = 0; wch < 2; ++wch) {
+      const Cloud& c = h->cloud(wch);  // em_icp.hpp:301 indexes label-1
+      if (c.n > 0 && (c.label_min < 1 || c.label_max > (uint32_t)P.num_classes)) return SICP_ERR_BAD_LABEL;
+    }
   }
   if (P.mode != SICP_MODE_SEMANTIC && h->cloud(1).n < P.knn) return SICP_ERR_TOO_FEW_POINTS;
   return SICP_OK;
@@ -1058,6 +1126,8 @@ int sicp_create(int device_id, sicp_handle* out) {
   sicp_context* h = new (std::nothrow) sicp_context();
   if (!h) return SICP_ERR_OUT_OF_MEMORY;
   h->device = device_id;
+  h->cl[0] = acquire_cloud(device_id);
+  h->cl[1] = acquire_cloud(device_id);
   sicp_default_params(SICP_MODE_GICP, &h->params);
   std::memset(&h->st, 0, sizeof h->st);
   bool ok = hipSetDevice(device_id) == hipSuccess &&
@@ -1102,6 +1172,18 @@ int sicp_destroy(sicp_handle h) {
   return SICP_OK;
 }
 
+int sicp_release_pool(int device_id) {
+  CloudPool& pool = cloud_pool();
+  std::vector<Cloud*> dead;
+  {
+    std::lock_guard<std::mutex> lock(pool.m);
+    dead.swap(pool.free_list[device_id & 63]);
+  }
+  if (!dead.empty() && hipSetDevice(device_id) != hipSuccess) return SICP_ERR_NO_DEVICE;
+  for (Cloud* c : dead) delete c;
+  return SICP_OK;
+}
+
 int sicp_set_params(sicp_handle h, const sicp_params* p) {
   if (!h || !p) return SICP_ERR_INVALID_ARGUMENT;
   if (p->mode < SICP_MODE_GICP || p->mode > SICP_MODE_SEMANTIC) return SICP_ERR_INVALID_ARGUMENT;
@@ -1133,12 +1215,17 @@ int sicp_set_cloud(sicp_handle h, int which, int32_t n, const float* x, const fl
   if (!h || (which != SICP_SOURCE && which != SICP_TARGET) || n < 0) return SICP_ERR_INVALID_ARGUMENT;
   if (n > 0 && (!x || !y || !z)) return SICP_ERR_INVALID_ARGUMENT;
   SICPCHECK(set_device(h));
-  if (h->cl[which].use_count() > 1) h->cl[which] = std::make_shared<Cloud>();  // shared with another handle: leave theirs alone
+  if (h->cl[which].use_count() > 1) h->cl[which] = acquire_cloud(h->device);  // shared with another handle: leave theirs alone
   Cloud& c = h->cloud(which);
   c.n = n;
-  c.hx.assign(x, x + n); c.hy.assign(y, y + n); c.hz.assign(z, z + n);
+  HIPCHECK(c.hx.assign(x, n)); HIPCHECK(c.hy.assign(y, n)); HIPCHECK(c.hz.assign(z, n));
   c.has_label = label != nullptr;
-  if (label) c.hl.assign(label, label + n); else c.hl.clear();
+  HIPCHECK(c.hl.assign(label, label ? n : 0));
+  c.label_min = 0xffffffffu; c.label_max = 0;
+  for (int i = 0; i < (label ? n : 0); ++i) {
+    c.label_min = std::min(c.label_min, label[i]);
+    c.label_max = std::max(c.label_max, label[i]);
+  }
   c.is_set = true;
   c.layout = -1;
   c.feat_valid = false;
@@ -1393,9 +1480,7 @@ int sicp_covariances(sicp_handle h, int which, double* cov9, double* normal3, ui
   SICPCHECK(prepare_cloud(h, c));
   const bool with_hist = P.mode == SICP_MODE_EM && c.has_label && P.num_classes >= 1;
   if (hist && !with_hist) return SICP_ERR_NOT_READY;
-  if (with_hist)
-    for (uint32_t l : c.hl)
-      if (l < 1 || l > (uint32_t)P.num_classes) return SICP_ERR_BAD_LABEL;
+  if (with_hist && c.n > 0 && (c.label_min < 1 || c.label_max > (uint32_t)P.num_classes)) return SICP_ERR_BAD_LABEL;
   // what align() left behind is returned as it is (getSourceCovariances(), gicp.h:72-90)
   if (!features_current(h, c, with_hist) || (nn_idx && !c.nn.p)) SICPCHECK(compute_features(h, c, with_hist));
   const int n = c.n, k = P.k_cov;

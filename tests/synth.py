@@ -203,6 +203,30 @@ def lidar_sequence(seed: int = 5, n_scans: int = 7, n_points: int | None = 20000
     return scans, np.stack(poses), cm
 
 
+def lidar_sequence_scan(seed: int, i: int, n_points: int | None = 100_000, C: int = 11, n_az: int = 2250, max_range: float = 40.0,
+                        sigma: float = 0.01, label_noise: float = 0.10, step=(1.0, 2.0), wobble: float = 0.15):
+    """Scan `i` of a long KITTI-odometry-like sequence, generated independently of the others (so a
+    sequence can be produced by a process pool): the street of `seed`, the sensor of config 2 after
+    `i` steps of `step[0]` m forward and `step[1]` deg yaw, modulated per scan by +-`wobble` so that
+    consecutive registrations differ in difficulty.  The heading swings between -8 and +8 degrees with a
+    period of 16 scans, which keeps the vehicle inside the 120 m street.  Returns (xyz, labels, world pose 4x4)."""
+    boxes, poles = _street(np.random.default_rng(seed))
+    cm = confusion_matrix(C)
+    pose = np.eye(4); pose[:3, 3] = (-40.0, 0.3, 1.73)
+    for j in range(i):
+        r = np.random.default_rng([seed, 7919, j])
+        f = 1.0 + wobble * r.uniform(-1, 1)
+        yaw = step[1] * (1.0 if (j % 16) < 4 or (j % 16) >= 12 else -1.0)
+        pose = pose @ pose_matrix(yaw, (0, 0, 1), (0.6 * step[0] * f, 0.0, 0.0))
+    rng = np.random.default_rng([seed, i])
+    p, l = _lidar_scan(rng, pose, boxes, poles, n_az, max_range, sigma)
+    l = _noisy_labels(rng, l, cm, label_noise)
+    if n_points is not None:
+        sel = np.sort(rng.choice(p.shape[0], n_points, replace=False))
+        p, l = p[sel], l[sel]
+    return p.astype(np.float32), l.astype(np.uint32), pose
+
+
 # -----------------------------------------------------------------------------
 # config 3: RGB-D frame pair of a box room (pinhole depth render)
 # -----------------------------------------------------------------------------

@@ -27,9 +27,27 @@ def test_world_size_2_gloo_dry_run():
         assert out["scaling"] == "weak" and out["higher_is_better"] is True and out["data"] == "dry-run"
         assert out["metric"] == "correspondences/sec" and out["unit"] == "correspondences/s"
         assert out["vs_baseline"] is None and "workload" in out["config"]
-    # dry-run step of rank r sleeps 10*(1+r) ms and reports 3 outer iterations of 20000*4 slots:
-    # the aggregate counts both ranks' correspondences over the slower rank's time
-    corr_per_rank = 2 * 3 * 20000 * 4
+    # dry-run step of rank r sleeps 10*(1+r) ms and reports 3 outer iterations of 20000*4 slots for each of
+    # its 32 pairs: the aggregate counts both ranks' correspondences over the slower rank's time
+    corr_per_rank = 2 * 3 * 20000 * 4 * 32
     assert abs(one["value"] * one["ms_per_step"] * 2e-3 - corr_per_rank) < 1e-6 * corr_per_rank
     assert abs(two["value"] * two["ms_per_step"] * 2e-3 - 2 * corr_per_rank) < 1e-6 * corr_per_rank
     assert two["ms_per_step"] > 1.5 * one["ms_per_step"]  # max over ranks, rank 1 is slower
+
+
+def test_bare_gpus_flag_fans_out_by_itself():
+    """`python bench.py --gpus 2` with no launcher starts its own two ranks (child processes) and
+    reports what they did; a rank count that contradicts --gpus is refused."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run", "--points", "20000"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "pairs-sharded x2"
+    assert abs(out["value"] * out["ms_per_step"] * 2e-3 - 2 * 2 * 3 * 20000 * 4 * 32) < 1.0
+    # one rank launched for --gpus 2: mismatch, loud failure
+    bad = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--dry-run"], cwd=ROOT, env=dict(env, WORLD_SIZE="1", RANK="0"),
+                         capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0 and "WORLD_SIZE" in (bad.stderr + bad.stdout)
