@@ -105,7 +105,12 @@ __device__ __forceinline__ void cov_body(const CovArgs& a) {
   double nx = col == 0 ? V[0][0] : (col == 1 ? V[0][1] : V[0][2]);
   double ny = col == 0 ? V[1][0] : (col == 1 ? V[1][1] : V[1][2]);
   double nz = col == 0 ? V[2][0] : (col == 1 ? V[2][1] : V[2][2]);
-  a.nx[i] = nx; a.ny[i] = ny; a.nz[i] = nz;
+  {
+    PointRec r;
+    r.x = a.x[i]; r.y = a.y[i]; r.z = a.z[i]; r.pad0 = 0u;
+    r.nx = nx; r.ny = ny; r.nz = nz; r.pad1 = 0.0;
+    a.rec[i] = r;
+  }
   if (a.hist) {
     // label histogram as neighbour counts (em_icp.hpp:301: dist(label-1) += 1/k)
     uint8_t* h = a.hist + (size_t)i * a.C;  // this lane owns the row
@@ -159,8 +164,8 @@ __device__ __forceinline__ void em_weight_body(const WeightArgs& a) {
   }
   // em_icp.hpp:108 -> gicp_cost_function.h:75-87
   Corr c;
-  corr_eval<false>(a.pose, a.one_m_eps, a.sx[i], a.sy[i], a.sz[i], a.snx[i], a.sny[i], a.snz[i],
-                   a.tx[j], a.ty[j], a.tz[j], a.tnx[j], a.tny[j], a.tnz[j], c);
+  const PointRec sr = a.srec[i], tr = a.trec[j];
+  corr_eval<false>(a.pose, a.one_m_eps, sr.x, sr.y, sr.z, sr.nx, sr.ny, sr.nz, tr.x, tr.y, tr.z, tr.nx, tr.ny, tr.nz, c);
   const double two_pi = 6.283185307179586;
   const double probability = pow(two_pi * two_pi * two_pi * c.detA, -0.5) * exp(-0.5 * c.r);
   if (a.bool_probability) {
@@ -192,6 +197,7 @@ __global__ __launch_bounds__(256) void fused_label_kernel(WeightArgs a, uint32_t
   // the geometric factor of each of the K correspondences does not depend on s
   double gprob[4];
   int jj[4];
+  const PointRec sr = a.srec[i];
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     const int j = c < a.K ? a.idx[(size_t)i * a.K + c] : -1;
@@ -199,8 +205,8 @@ __global__ __launch_bounds__(256) void fused_label_kernel(WeightArgs a, uint32_t
     gprob[c] = 0.0;
     if (j >= 0) {
       Corr cr;
-      corr_eval<false>(a.pose, a.one_m_eps, a.sx[i], a.sy[i], a.sz[i], a.snx[i], a.sny[i], a.snz[i],
-                       a.tx[j], a.ty[j], a.tz[j], a.tnx[j], a.tny[j], a.tnz[j], cr);
+      const PointRec tr = a.trec[j];
+      corr_eval<false>(a.pose, a.one_m_eps, sr.x, sr.y, sr.z, sr.nx, sr.ny, sr.nz, tr.x, tr.y, tr.z, tr.nx, tr.ny, tr.nz, cr);
       const double two_pi = 6.283185307179586;
       const double probability = pow(two_pi * two_pi * two_pi * cr.detA, -0.5) * exp(-0.5 * cr.r);
       gprob[c] = a.bool_probability ? ((probability != 0.0) ? 1.0 : 0.0) : probability;

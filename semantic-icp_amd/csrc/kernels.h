@@ -8,6 +8,10 @@
 #include "bvh.hpp"
 #include "lm.hpp"
 
+#ifndef SICP_HD
+#define SICP_HD
+#endif
+
 namespace sicp {
 
 struct Pose {
@@ -18,6 +22,34 @@ struct Pose {
 struct Mat4f {
   float m[16];
 };
+
+// One point as the weight / accumulate kernels gather it: position (the float32 the search ran on) and
+// the unit normal of its k-neighbourhood in double (its covariance is I - (1-eps) n n^T), 48 bytes =
+// three 16-byte loads instead of one load from each of six arrays.  Written by cov_kernel.
+struct alignas(16) PointRec {
+  float x, y, z;
+  uint32_t pad0;
+  double nx, ny, nz;
+  double pad1;
+};
+static_assert(sizeof(PointRec) == 48, "PointRec is read with three dwordx4 / dwordx2 loads");
+
+// Decomposition of a pair's correspondence slots into chunks (solve_kernels.hip): groups of
+// `slots_per_group` slots, chunks of 512 m groups (m = 1 up to 1024 chunks), one row of 28 partial
+// sums per chunk.  Host and device compute it from the slot count alone.
+struct AccGeometry {
+  int n_groups, m, chunk_groups, n_chunks;
+};
+SICP_HD inline AccGeometry acc_geometry(int total_slots, int slots_per_group) {
+  AccGeometry g;
+  g.n_groups = (total_slots + slots_per_group - 1) / slots_per_group;
+  g.m = (g.n_groups + 512 * 1024 - 1) / (512 * 1024);
+  if (g.m < 1) g.m = 1;
+  g.chunk_groups = 512 * g.m;
+  g.n_chunks = (g.n_groups + g.chunk_groups - 1) / g.chunk_groups;
+  if (g.n_chunks < 1) g.n_chunks = 1;
+  return g;
+}
 
 struct LossArgs {
   double cauchy_a;
@@ -89,7 +121,7 @@ struct CovArgs {
   const int* nn;          // neighbour lists, device indices: [n][k], or [k][nn_stride] when nn_stride > 0
   int nn_stride;
   int float_products;
-  double *nx, *ny, *nz;
+  PointRec* rec;          // out: position + normal of every point
   uint8_t* hist;          // [n][C] or nullptr
 };
 
@@ -104,8 +136,7 @@ struct ProjArgs {
 struct WeightArgs {
   int n_s, K, C;
   const int* idx;
-  const float *sx, *sy, *sz, *tx, *ty, *tz;
-  const double *snx, *sny, *snz, *tnx, *tny, *tnz;
+  const PointRec *srec, *trec;
   const double *s_proj, *t_proj;  // [n][C] label distributions projected through CM (proj_kernel)
   Pose pose;
   double one_m_eps;
@@ -117,16 +148,13 @@ struct AccArgs {
   int n_s, K;
   const int* idx;
   const double* w;  // nullable (weight 1)
-  const float *sx, *sy, *sz, *tx, *ty, *tz;
-  const double *snx, *sny, *snz, *tnx, *tny, *tnz;
+  const PointRec *srec, *trec;
   Pose pose;            // used when lm == nullptr
   const LmState* lm;    // device-resident solve: evaluate at lm->pose, skip when it has finished
-  LmState* lm_step;     // fused solve step: the last block to finish reduces the partials and feeds *lm_step
-  unsigned* ticket;     // block-arrival counter of the fused step (zero between launches)
+  LmState* lm_step;     // batched solve: the state lm_step_batch_kernel advances (== lm)
   double one_m_eps;
   LossArgs loss;
   double* partials;  // [28][accumulate_blocks]
-  const double* partials_in;  // chained solve: the previous launch's partials (fed in this launch's prologue)
 };
 
 // job arrays passed by value to one launch (lock-step batch); sized to stay inside the 4 KB of
@@ -144,23 +172,30 @@ static_assert(sizeof(KnnJobs) <= 4000 && sizeof(WeightJobs) <= 4000 && sizeof(Co
 // one pair of a lock-step batch (sicp_align_batch); an array of these lives in HBM
 struct BatchArgs {
   AccArgs a;
-  int nb;    // accumulate blocks of this pair (its partials are [28][nb])
-  int pad_;
+  int nb;          // chunks of this pair (its partials are [28][nb])
+  int item_begin;  // index of the pair's first chunk in the batch's flattened (pair, chunk) list
+};
+// what the batched kernels need to know about the current outer iteration; lives in HBM next to the
+// BatchArgs array, so the instantiated graph never changes
+struct BatchHeader {
+  int n_pairs;   // pairs that still iterate = entries of the BatchArgs array
+  int n_items;   // sum of their chunk counts
+  int pad_[2];
 };
 
-// [accumulate_batch, lm_step_batch] x len of a lock-step batch as an instantiated graph with explicit
-// kernel nodes: when the number of pairs or the largest pair changes, only the nodes' grids are
-// updated (hipGraphExecKernelNodeSetParams) -- no capture, no re-instantiation
+// [accumulate_stream, lm_step_batch] x len of a lock-step batch as an instantiated graph with explicit
+// kernel nodes and fixed grids (solve_kernels.hip)
 constexpr int kMaxBatchLen = 32;
 struct BatchGraph {
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
-  hipGraphNode_t acc[kMaxBatchLen], step[kMaxBatchLen];
-  int len = 0, K = 0, n = 0, max_nb = 0;
+  int len = 0, K = 0, sqloss = 0, capacity = 0;
   const BatchArgs* batch = nullptr;
+  const BatchHeader* hdr = nullptr;
 };
 // *built is set to 1 when the graph had to be (re)instantiated
-hipError_t batch_graph_prepare(BatchGraph& g, int K, const BatchArgs* batch, int n, int max_nb, int len, int* built);
+hipError_t batch_graph_prepare(BatchGraph& g, int K, int use_sqloss, const BatchHeader* hdr, const BatchArgs* batch, int capacity, int len,
+                               int* built);
 void batch_graph_destroy(BatchGraph& g);
 
 // neighbour-list length the search kernels run with for a request of k neighbours (the k nearest
@@ -182,15 +217,14 @@ hipError_t launch_cov_jobs(const CovArgs* jobs, int n, hipStream_t st);
 hipError_t launch_proj_jobs(const ProjArgs* jobs, int n, hipStream_t st);
 hipError_t launch_em_weight_jobs(const WeightArgs* jobs, int n, hipStream_t st);
 hipError_t launch_count_active_jobs(const CountJob* jobs, int n, hipStream_t st);
-int accumulate_blocks(int total);
+int accumulate_blocks(int total, int K);  // chunks of a pair with `total` slots, K correspondences per source point
 hipError_t launch_accumulate_kernel(const AccArgs& a, hipStream_t st);
 hipError_t launch_finalize(const AccArgs& a, double* out28, hipStream_t st);
 // one evaluation of the device-resident solve: accumulate at lm->pose, then feed the LM machine
 hipError_t launch_accumulate_lm(const AccArgs& a, LmState* lm, hipStream_t st);
-hipError_t launch_accumulate_fused(const AccArgs& a, hipStream_t st);
-hipError_t launch_accumulate_chain(const AccArgs& a, hipStream_t st);
-hipError_t launch_accumulate_batch(int K, const BatchArgs* batch, int n, int max_nb, hipStream_t st);
-hipError_t launch_lm_step_batch(const BatchArgs* batch, int n, hipStream_t st);
+// every pair of the batch in one launch: hdr / batch in HBM, capacity = slots of the batch buffers
+hipError_t launch_accumulate_batch(int K, int use_sqloss, const BatchHeader* hdr, const BatchArgs* batch, int capacity, hipStream_t st);
+hipError_t launch_lm_step_batch(const BatchHeader* hdr, const BatchArgs* batch, int capacity, hipStream_t st);
 hipError_t launch_finalize_batch(const BatchArgs* batch, int n, double* out28, hipStream_t st);
 hipError_t launch_count_active(const int* idx, int n, unsigned long long* out, hipStream_t st);
 // test hook: csrc/se3.hpp on the device, one lane per item (op = SICP_SE3_*; in/out strides per op)

@@ -117,7 +117,7 @@ struct Cloud {
   HostBuf<int> h_ids;
   DevBuf<unsigned long long> keys_in, keys_out;
   DevBuf<unsigned char> sort_temp;
-  DevBuf<double> nx, ny, nz;
+  DevBuf<sicp::PointRec> rec;  // position + normal of every point (what the weight / accumulate kernels gather)
   DevBuf<uint8_t> hist;
   DevBuf<double> proj;  // [n][C] label distribution x confusion matrix
   bool proj_valid = false;
@@ -218,12 +218,10 @@ struct sicp_context {
   DevBuf<double> partials, out28;
   DevBuf<long long> d_count;
   DevBuf<sicp::LmState> d_lm;
-  DevBuf<unsigned> d_ticket;  // arrival counter of the fused LM step (zero between launches)
   // one batch of the device-resident solve ([accumulate, lm_step] x lm_batch) captured as a graph:
   // a single launch call per batch instead of 2 x lm_batch trips through the runtime's launch path
   hipGraphExec_t lm_graph = nullptr;
   sicp::AccArgs lm_graph_args;
-  int lm_graph_chain = 0;
   int lm_graph_batch = 0;
   sicp::LmState* h_lm = nullptr;  // pinned mirror of the device-resident LM state
   double* h_out28 = nullptr;      // pinned, 28 doubles
@@ -233,6 +231,8 @@ struct sicp_context {
   // lock-step batch (sicp_align_batch), owned by the batch's first handle: one BatchArgs and one LM
   // state per pair, pinned mirrors, and the captured [accumulate_batch, lm_step_batch] x lm_batch graph
   DevBuf<sicp::BatchArgs> d_batch;
+  DevBuf<sicp::BatchHeader> d_bhdr;
+  sicp::BatchHeader* h_bhdr = nullptr;
   DevBuf<sicp::LmState> d_bstates;
   DevBuf<double> d_bout28;
   sicp::BatchArgs* h_batch = nullptr;
@@ -240,6 +240,8 @@ struct sicp_context {
   double* h_bout28 = nullptr;
   int h_batch_cap = 0;
   sicp::BatchGraph b_graph;
+  hipStream_t side_stream = nullptr;  // batch leader: searches of the pairs between two inner solves
+  hipEvent_t side_done = nullptr, main_done = nullptr;
   hipStream_t part_stream[kParts] = {};
   hipEvent_t part_fork = nullptr, part_done[kParts] = {};
   std::string last_error;
@@ -528,7 +530,7 @@ int compute_features(sicp_context* h, Cloud& c, bool with_hist, hipStream_t stre
   const sicp_params& P = h->params;
   const int k = P.k_cov, n = c.n;
   const size_t m = (size_t)(n > 0 ? n : 1);
-  HIPCHECK(c.nx.reserve(m)); HIPCHECK(c.ny.reserve(m)); HIPCHECK(c.nz.reserve(m));
+  HIPCHECK(c.rec.reserve(m));
   HIPCHECK(c.nn.reserve(m * k));
   if (with_hist) HIPCHECK(c.hist.reserve(m * P.num_classes));
   // the packet search writes the lists rank-major ([k][n]): coalesced stores there and coalesced
@@ -548,7 +550,7 @@ int compute_features(sicp_context* h, Cloud& c, bool with_hist, hipStream_t stre
   a.nn = c.nn.p;
   a.nn_stride = nn_stride;
   a.float_products = P.quirk_float_products;
-  a.nx = c.nx.p; a.ny = c.ny.p; a.nz = c.nz.p;
+  a.rec = c.rec.p;
   a.hist = with_hist ? c.hist.p : nullptr;
   if (h->collect) h->collect->cov[h->collect->slice].push_back(a);
   else HIPCHECK(sicp::launch_cov(a, stream));
@@ -630,8 +632,7 @@ int run_correspondences(sicp_context* h, const double* qt, int K, bool weights) 
     sicp::WeightArgs a;
     a.n_s = S.n; a.K = K; a.C = P.num_classes;
     a.idx = h->idx.p;
-    a.sx = S.x.p; a.sy = S.y.p; a.sz = S.z.p; a.tx = T.x.p; a.ty = T.y.p; a.tz = T.z.p;
-    a.snx = S.nx.p; a.sny = S.ny.p; a.snz = S.nz.p; a.tnx = T.nx.p; a.tny = T.ny.p; a.tnz = T.nz.p;
+    a.srec = S.rec.p; a.trec = T.rec.p;
     SICPCHECK(ensure_proj(h, S));
     SICPCHECK(ensure_proj(h, T));
     a.s_proj = S.proj.p; a.t_proj = T.proj.p;
@@ -659,9 +660,9 @@ void fill_acc(sicp_context* h, sicp::AccArgs& a) {
   a.n_s = h->corr_n; a.K = h->corr_K;
   a.idx = h->idx.p;
   a.w = h->corr_weighted ? h->w.p : nullptr;
-  a.sx = S.x.p; a.sy = S.y.p; a.sz = S.z.p; a.tx = T.x.p; a.ty = T.y.p; a.tz = T.z.p;
-  a.snx = S.nx.p; a.sny = S.ny.p; a.snz = S.nz.p; a.tnx = T.nx.p; a.tny = T.ny.p; a.tnz = T.nz.p;
+  a.srec = S.rec.p; a.trec = T.rec.p;
   a.lm = nullptr;
+  a.lm_step = nullptr;
   a.one_m_eps = 1.0 - P.epsilon;
   a.loss.cauchy_a = P.cauchy_a;
   a.loss.use_sqloss = P.use_sqloss;
@@ -669,7 +670,7 @@ void fill_acc(sicp_context* h, sicp::AccArgs& a) {
 }
 
 int eval28(sicp_context* h, const double* qt, double* out28) {
-  const int nb = sicp::accumulate_blocks(h->corr_n * h->corr_K);
+  const int nb = sicp::accumulate_blocks(h->corr_n * h->corr_K, h->corr_K);
   HIPCHECK(h->partials.reserve((size_t)nb * 28));
   HIPCHECK(h->out28.reserve(28));
   sicp::AccArgs a;
@@ -728,52 +729,27 @@ int run_solve(sicp_context* h, const double* init_qt, double* out_qt, SolveResul
     return SICP_OK;
   }
   // device-resident: the trust-region state stays in HBM; every evaluation is an accumulate kernel
-  // followed by a one-block kernel that feeds the same LM machine; the host polls the status once
+  // followed by a one-wave kernel that feeds the same LM machine; the host polls the status once
   // per batch.  Launches queued behind a finished solve exit at their first instruction.
-  // lm_on_device: 1 = accumulate kernel + one-wave step kernel; 2 = step fused into the last block
-  // of the accumulate kernel; 3 = chained (every launch finishes the previous evaluation in its
-  // prologue; state and partials double buffered, so a batch has an even number of launches).
-  // 2 and 3 keep the solver state in registers (one wave per SIMD): they are used while one round
-  // of blocks covers the launch, the two-kernel form beyond (the boundary is then noise).
-  const int nb = sicp::accumulate_blocks(h->corr_n * h->corr_K);
-  const bool chain = P.lm_on_device >= 3 && nb <= 256;
-  const bool fused = P.lm_on_device == 2 && nb <= 256;
-  int batch = P.lm_batch > 0 ? P.lm_batch : 12;
-  if (chain) batch += batch & 1;
-  HIPCHECK(h->partials.reserve((size_t)nb * 28 * (chain ? 2 : 1)));
-  HIPCHECK(h->d_lm.reserve(chain ? 2 : 1));
+  // (Round 1 also carried a form with the step fused into the accumulate kernel's last block and a
+  // chained form; neither measured faster and both are gone: lm_on_device > 1 means 1.)
+  const int nb = sicp::accumulate_blocks(h->corr_n * h->corr_K, h->corr_K);
+  const int batch = std::min(P.lm_batch > 0 ? P.lm_batch : 12, sicp::kMaxBatchLen);
+  HIPCHECK(h->partials.reserve((size_t)nb * 28));
+  HIPCHECK(h->d_lm.reserve(1));
   sicp::lm_init(*h->h_lm, lm_options(P), init_qt);
   HIPCHECK(hipMemcpyAsync(h->d_lm.p, h->h_lm, sizeof(sicp::LmState), hipMemcpyHostToDevice, h->stream));
   sicp::AccArgs a;
   std::memset(&a, 0, sizeof a);  // padding bytes take part in the graph-cache comparison
   fill_acc(h, a);
   a.lm = h->d_lm.p;
-  if (fused) {
-    if (!h->d_ticket.p) {
-      HIPCHECK(h->d_ticket.reserve(1));
-      HIPCHECK(hipMemsetAsync(h->d_ticket.p, 0, sizeof(unsigned), h->stream));
-    }
-    a.lm_step = h->d_lm.p;
-    a.ticket = h->d_ticket.p;
-  }
-  if (!h->lm_graph || h->lm_graph_batch != batch || h->lm_graph_chain != (int)chain || std::memcmp(&h->lm_graph_args, &a, sizeof a) != 0) {
+  if (!h->lm_graph || h->lm_graph_batch != batch || std::memcmp(&h->lm_graph_args, &a, sizeof a) != 0) {
     // (re)capture: the arguments only change when a buffer was reallocated or the mode changed
     if (h->lm_graph) { (void)hipGraphExecDestroy(h->lm_graph); h->lm_graph = nullptr; }
     hipGraph_t g = nullptr;
     HIPCHECK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
     hipError_t ce = hipSuccess;
-    for (int b = 0; b < batch && ce == hipSuccess; ++b) {
-      if (chain) {
-        sicp::AccArgs c = a;
-        c.lm = h->d_lm.p + (b & 1);
-        c.lm_step = h->d_lm.p + ((b + 1) & 1);
-        c.partials_in = h->partials.p + (size_t)(b & 1) * nb * 28;
-        c.partials = h->partials.p + (size_t)((b + 1) & 1) * nb * 28;
-        ce = sicp::launch_accumulate_chain(c, h->stream);
-      } else {
-        ce = fused ? sicp::launch_accumulate_fused(a, h->stream) : sicp::launch_accumulate_lm(a, h->d_lm.p, h->stream);
-      }
-    }
+    for (int b = 0; b < batch && ce == hipSuccess; ++b) ce = sicp::launch_accumulate_lm(a, h->d_lm.p, h->stream);
     hipError_t ee = hipStreamEndCapture(h->stream, &g);
     HIPCHECK(ce);
     HIPCHECK(ee);
@@ -783,7 +759,6 @@ int run_solve(sicp_context* h, const double* init_qt, double* out_qt, SolveResul
     h->st.graph_builds += 1;
     std::memcpy(&h->lm_graph_args, &a, sizeof a);
     h->lm_graph_batch = batch;
-    h->lm_graph_chain = (int)chain;
   }
   static const bool dbg_timing = std::getenv("SICP_DEBUG_TIMING") != nullptr;  // developer aid
   double t_launch = 0, t_copy = 0, t_sync = 0; int n_batches = 0;
@@ -897,7 +872,10 @@ bool same_solver(const sicp_params& a, const sicp_params& b) {
 }
 
 int batch_reserve(sicp_context* h, int n) {
+  n = std::max(32, (n + 31) / 32 * 32);  // capacity in steps of 32: the batch graph is keyed on it
   HIPCHECK(h->d_batch.reserve(n));
+  HIPCHECK(h->d_bhdr.reserve(1));
+  if (!h->h_bhdr) HIPCHECK(hipHostMalloc((void**)&h->h_bhdr, sizeof(sicp::BatchHeader), hipHostMallocDefault));
   HIPCHECK(h->d_bstates.reserve(n));
   HIPCHECK(h->d_bout28.reserve((size_t)28 * n));
   if (h->h_batch_cap < n) {
@@ -921,7 +899,8 @@ int batch_slice(int p, int n) {
 }
 
 // launches what the pairs' stages collected: searches, then the kernels that consume them
-int flush_jobs(sicp_context* h, JobCollector& jc) {
+int flush_jobs(sicp_context* h, JobCollector& jc, hipStream_t base = nullptr) {
+  if (!base) base = h->stream;
   // The slices of the batch run their stage sequences (searches -> covariances -> projections ->
   // weights -> counts) on their own streams: the small kernels and the search tails of one slice
   // overlap the searches of the others.
@@ -939,11 +918,11 @@ int flush_jobs(sicp_context* h, JobCollector& jc) {
         HIPCHECK(hipEventCreateWithFlags(&h->part_done[s], hipEventDisableTiming));
       }
     if (!h->part_fork) HIPCHECK(hipEventCreateWithFlags(&h->part_fork, hipEventDisableTiming));
-    HIPCHECK(hipEventRecord(h->part_fork, h->stream));
+    HIPCHECK(hipEventRecord(h->part_fork, base));
   }
   for (int s = 0; s < kParts; ++s) {
     if (!used[s]) continue;
-    hipStream_t st = s ? h->part_stream[s] : h->stream;
+    hipStream_t st = s ? h->part_stream[s] : base;
     if (s) HIPCHECK(hipStreamWaitEvent(st, h->part_fork, 0));
     if (!jc.knn[s].empty()) HIPCHECK(sicp::launch_bvh_knn_packet_jobs(jc.knn_K, jc.knn[s].data(), (int)jc.knn[s].size(), st));
     if (!jc.cov[s].empty()) HIPCHECK(sicp::launch_cov_jobs(jc.cov[s].data(), (int)jc.cov[s].size(), st));
@@ -953,7 +932,7 @@ int flush_jobs(sicp_context* h, JobCollector& jc) {
     jc.knn[s].clear(); jc.cov[s].clear(); jc.proj[s].clear(); jc.weight[s].clear(); jc.count[s].clear();
     if (s) {
       HIPCHECK(hipEventRecord(h->part_done[s], st));
-      HIPCHECK(hipStreamWaitEvent(h->stream, h->part_done[s], 0));
+      HIPCHECK(hipStreamWaitEvent(base, h->part_done[s], 0));
     }
   }
   return SICP_OK;
@@ -969,70 +948,56 @@ struct BatchGuard {
       if (jc) { hs[p]->collect = jc; hs[p]->stream = stream; hs[p]->stream2 = stream; }
     }
   }
+  // from here on the pairs' own launches (memsets, searches outside the job lists) go to `stream`
+  void retarget(hipStream_t stream) {
+    for (int p = 0; p < n; ++p) { hs[p]->stream = stream; hs[p]->stream2 = stream; }
+  }
   ~BatchGuard() {
     for (int p = 0; p < n; ++p) { hs[p]->collect = nullptr; hs[p]->stream = s1[p]; hs[p]->stream2 = s2[p]; }
   }
 };
 
-// The inner solves of all active pairs, in lock step: one accumulate launch evaluates every pair's
-// current LM pose, one step launch advances every pair's trust-region machine (csrc/lm.hpp, the
-// same code and the same bits as the single-pair solve).  A pair that has finished idles (its
-// blocks exit on the first instruction) until the slowest pair is done.
-int run_solve_batch(sicp_context* h, sicp_handle* hs, int n, const char* active, OuterState* o, SolveResult* res) {
-  const sicp_params& P = h->params;
-  SICPCHECK(batch_reserve(h, n));
-  // The argument array only holds the pairs that still iterate (compacted: grid.y = their number);
-  // the LM states stay indexed by pair.
-  int max_nb = 0, n_act = 0;
-  for (int p = 0; p < n; ++p) {
+// One TICK of a batch: `len` LM evaluations of every pair in `act` (pair indices), in one graph launch:
+// accumulate_stream_kernel evaluates all of them at their current LM poses, lm_step_batch_kernel
+// advances every pair's trust-region machine (csrc/lm.hpp, the same code and the same bits as the
+// single-pair solve).  `joining` pairs start their inner solve with this tick (their LM state is
+// initialised and uploaded first).  On return h_bstates holds every pair's state.
+constexpr int kMaxActivePairs = 128;  // per-pair constants of the batched kernel live in LDS
+
+int run_tick(sicp_context* h, hipStream_t M, sicp_handle* hs, int n, const std::vector<int>& act, const std::vector<int>& joining,
+             const OuterState* o, int len) {
+  for (int p : joining) {
+    sicp::lm_init(h->h_bstates[p], lm_options(hs[p]->params), o[p].est);
+    HIPCHECK(hipMemcpyAsync(h->d_bstates.p + p, h->h_bstates + p, sizeof(sicp::LmState), hipMemcpyHostToDevice, M));
+  }
+  int n_items = 0, k = 0;
+  for (int p : act) {
     sicp_context* g = hs[p];
-    sicp::lm_init(h->h_bstates[p], lm_options(g->params), o[p].est);
-    if (!active[p]) { h->h_bstates[p].status = sicp::LM_CONVERGED; continue; }
-    sicp::BatchArgs& B = h->h_batch[n_act++];
+    sicp::BatchArgs& B = h->h_batch[k++];
     std::memset(&B, 0, sizeof B);
-    const int nb = sicp::accumulate_blocks(g->corr_n * g->corr_K);
+    const int nb = sicp::accumulate_blocks(g->corr_n * g->corr_K, g->corr_K);
     if (g->partials.reserve((size_t)nb * 28) != hipSuccess) return SICP_ERR_OUT_OF_MEMORY;
     fill_acc(g, B.a);
     B.a.lm = B.a.lm_step = h->d_bstates.p + p;
     B.nb = nb;
-    max_nb = std::max(max_nb, nb);
-    // the batched kernels (leader stream) read what the pair's stream is still producing
-    if (g != h && g->stream != h->stream) {
-      HIPCHECK(hipEventRecord(g->ev_join, g->stream));
-      HIPCHECK(hipStreamWaitEvent(h->stream, g->ev_join, 0));
-    }
+    B.item_begin = n_items;
+    n_items += nb;
   }
-  if (n_act == 0) return SICP_OK;
-  HIPCHECK(hipMemcpyAsync(h->d_batch.p, h->h_batch, sizeof(sicp::BatchArgs) * n_act, hipMemcpyHostToDevice, h->stream));
-  HIPCHECK(hipMemcpyAsync(h->d_bstates.p, h->h_bstates, sizeof(sicp::LmState) * n, hipMemcpyHostToDevice, h->stream));
-  const int len = std::min(P.lm_batch > 0 ? P.lm_batch : 12, sicp::kMaxBatchLen);
-  const int K = hs[0]->corr_K;
-  // [accumulate_batch, lm_step_batch] x len as an explicit graph: it only depends on the grids and on
-  // the address of the argument array, and when the number of active pairs or the largest pair
-  // changes the grids of the instantiated graph are updated in place (no re-instantiation).
+  h->h_bhdr->n_pairs = (int)act.size(); h->h_bhdr->n_items = n_items; h->h_bhdr->pad_[0] = h->h_bhdr->pad_[1] = 0;
+  HIPCHECK(hipMemcpyAsync(h->d_bhdr.p, h->h_bhdr, sizeof(sicp::BatchHeader), hipMemcpyHostToDevice, M));
+  HIPCHECK(hipMemcpyAsync(h->d_batch.p, h->h_batch, sizeof(sicp::BatchArgs) * act.size(), hipMemcpyHostToDevice, M));
+  // [accumulate_stream, lm_step_batch] x len as an explicit graph with fixed grids: the kernels read the
+  // number of active pairs and chunks from the header, so the graph is instantiated once per batch
+  // context (buffer addresses) and never touched when pairs come and go or batches differ in size.
   {
     int built = 0;
-    HIPCHECK(sicp::batch_graph_prepare(h->b_graph, K, h->d_batch.p, n_act, max_nb, len, &built));
+    HIPCHECK(sicp::batch_graph_prepare(h->b_graph, hs[0]->params.knn, h->params.use_sqloss, h->d_bhdr.p, h->d_batch.p,
+                                       std::min(h->h_batch_cap, kMaxActivePairs), len, &built));
     h->st.graph_builds += built;
   }
-  for (;;) {
-    HIPCHECK(hipGraphLaunch(h->b_graph.exec, h->stream));
-    for (int p = 0; p < n; ++p) {
-      hs[p]->st.lockstep_slots += len;  // every pair of the batch waits for this launch, iterating or not
-      if (active[p]) hs[p]->st.acc_launches += len;
-    }
-    HIPCHECK(hipMemcpyAsync(h->h_bstates, h->d_bstates.p, sizeof(sicp::LmState) * n, hipMemcpyDeviceToHost, h->stream));
-    HIPCHECK(hipStreamSynchronize(h->stream));
-    bool running = false;
-    for (int p = 0; p < n; ++p) running = running || h->h_bstates[p].status == sicp::LM_RUNNING;
-    if (!running) break;
-  }
-  for (int p = 0; p < n; ++p) {
-    if (!active[p]) continue;
-    const sicp::LmState& s = h->h_bstates[p];
-    std::memcpy(o[p].est, s.x, sizeof s.x);
-    res[p].status = s.status; res[p].iterations = s.iterations; res[p].evaluations = s.evaluations; res[p].cost = s.cost;
-  }
+  HIPCHECK(hipGraphLaunch(h->b_graph.exec, M));
+  HIPCHECK(hipMemcpyAsync(h->h_bstates, h->d_bstates.p, sizeof(sicp::LmState) * n, hipMemcpyDeviceToHost, M));
+  HIPCHECK(hipStreamSynchronize(M));
   return SICP_OK;
 }
 
@@ -1154,6 +1119,7 @@ int sicp_destroy(sicp_handle h) {
   if (h->h_count) (void)hipHostFree(h->h_count);
   if (h->h_lm) (void)hipHostFree(h->h_lm);
   if (h->h_batch) (void)hipHostFree(h->h_batch);
+  if (h->h_bhdr) (void)hipHostFree(h->h_bhdr);
   if (h->h_bstates) (void)hipHostFree(h->h_bstates);
   if (h->h_bout28) (void)hipHostFree(h->h_bout28);
   sicp::batch_graph_destroy(h->b_graph);
@@ -1161,6 +1127,9 @@ int sicp_destroy(sicp_handle h) {
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->lm_graph) (void)hipGraphExecDestroy(h->lm_graph);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+  if (h->side_done) (void)hipEventDestroy(h->side_done);
+  if (h->main_done) (void)hipEventDestroy(h->main_done);
+  if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
   if (h->part_fork) (void)hipEventDestroy(h->part_fork);
   for (int s = 1; s < kParts; ++s) {
     if (h->part_done[s]) (void)hipEventDestroy(h->part_done[s]);
@@ -1364,41 +1333,112 @@ int sicp_align_batch(sicp_handle* hs, int32_t n, const double* init_qt, double* 
       HIPCHECK(hipStreamSynchronize(h->stream));
     }
   }
+  // ---- the outer loops of all pairs, CONTINUOUSLY batched.  Every pair runs its own sequence
+  //   search (transform + kNN + weights) -> inner solve -> convergence test -> search -> ...
+  // and the batch advances in ticks of lm_batch LM evaluations: one graph launch evaluates every pair
+  // that is inside an inner solve, while the searches of the pairs that have just finished one run
+  // on a second stream beside it; those pairs rejoin at the next tick.  No pair waits for another
+  // pair's solve or outer loop -- only for the end of the current tick.
+  {
+    sicp_context* h = L;
+    SICPCHECK(batch_reserve(h, n));
+    if (!h->side_stream) {
+      HIPCHECK(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+      HIPCHECK(hipEventCreateWithFlags(&h->side_done, hipEventDisableTiming));
+      HIPCHECK(hipEventCreateWithFlags(&h->main_done, hipEventDisableTiming));
+    }
+  }
+  enum { NEED_SEARCH, JOINING, SOLVING, DONE };
   std::vector<OuterState> o(n);
+  std::vector<int> phase(n, NEED_SEARCH);
   for (int p = 0; p < n; ++p) std::memcpy(o[p].cur, init_qt + 7 * p, sizeof o[p].cur);
-  std::vector<SolveResult> res(n);
-  std::vector<char> active(n, 1);
-  for (;;) {
-    int n_active = 0;
+  const int len = std::min(P.lm_batch > 0 ? P.lm_batch : 12, sicp::kMaxBatchLen);
+  const hipStream_t M = guard.s1[0];  // the leader's own stream: the ticks
+  const hipStream_t side = one_launch ? L->side_stream : M;
+  {  // the side stream starts after everything queued so far (features)
+    sicp_context* h = L;
+    HIPCHECK(hipEventRecord(h->main_done, M));
+    HIPCHECK(hipStreamWaitEvent(side, h->main_done, 0));
+  }
+  if (one_launch) guard.retarget(side);
+  std::vector<int> act, joining, finished, search_round(n, 0);
+  int n_done = 0, round = 0;
+  while (n_done < n) {
+    sicp_context* h = L;
+    ++round;
+    // (1) searches of the pairs between two inner solves -> side stream
+    bool any_search = false;
     for (int p = 0; p < n; ++p) {
-      active[p] = !o[p].converged;
-      if (!active[p]) continue;
-      ++n_active;
+      if (phase[p] != NEED_SEARCH) continue;
       std::memcpy(o[p].est, o[p].cur, sizeof o[p].est);
       if (P.mode == SICP_MODE_SEMANTIC) o[p].count++;
       jc.slice = batch_slice(p, n);
       SICPCHECK(run_correspondences(hs[p], o[p].cur, P.knn, true));
+      phase[p] = JOINING;
+      search_round[p] = round;
+      any_search = true;
     }
-    if (n_active == 0) break;
-    if (one_launch) SICPCHECK(flush_jobs(L, jc));
+    // (2) the tick: pairs inside a solve, plus (up to the capacity) the pairs whose search was queued
+    // during the previous tick.  When nobody is inside a solve there is nothing for the fresh
+    // searches to run beside: they are queued first and their pairs join at once.
+    act.clear(); joining.clear();
+    for (int p = 0; p < n; ++p)
+      if (phase[p] == SOLVING) act.push_back(p);
+    const bool join_fresh = act.empty() || !one_launch;
+    if (any_search && one_launch && join_fresh) {
+      SICPCHECK(flush_jobs(h, jc, side));
+      HIPCHECK(hipEventRecord(h->side_done, side));
+      any_search = false;
+    }
+    bool waited = false;
+    for (int p = 0; p < n && (int)act.size() < kMaxActivePairs; ++p) {
+      if (phase[p] != JOINING || (search_round[p] == round && !join_fresh)) continue;
+      joining.push_back(p); act.push_back(p);
+      if (!waited && one_launch) { HIPCHECK(hipStreamWaitEvent(M, h->side_done, 0)); waited = true; }
+      if (!one_launch && hs[p]->stream != M) {  // the pair's own stream produced its correspondences
+        HIPCHECK(hipEventRecord(hs[p]->ev_join, hs[p]->stream));
+        HIPCHECK(hipStreamWaitEvent(M, hs[p]->ev_join, 0));
+      }
+    }
+    // this round's searches run beside the tick
+    if (any_search && one_launch) {
+      SICPCHECK(flush_jobs(h, jc, side));
+      HIPCHECK(hipEventRecord(h->side_done, side));
+    }
+    if (act.empty()) continue;
+    for (int p : joining) phase[p] = SOLVING;
     const double t0 = now_ms();
     {
-      int rc = run_solve_batch(L, hs, n, active.data(), o.data(), res.data());
+      int rc = run_tick(h, M, hs, n, act, joining, o.data(), len);
       if (rc != SICP_OK) return rc;
     }
     const double dt = now_ms() - t0;
-    for (int p = 0; p < n; ++p) {
-      if (!active[p]) continue;
-      sicp_context* h = hs[p];
-      h->st.total_lm_iters += res[p].iterations;
-      h->st.final_cost = res[p].cost;
-      h->st.t_solve_ms += dt;
-      h->st.total_evals += res[p].evaluations;
-      jc.slice = batch_slice(p, n);
-      if (stats) SICPCHECK(count_active(h));
-      outer_finish(P, o[p]);
+    // (3) pairs whose inner solve has ended: outer convergence test
+    finished.clear();
+    for (int p : act) {
+      sicp_context* g = hs[p];
+      g->st.lockstep_slots += len;
+      g->st.acc_launches += len;
+      g->st.t_solve_ms += dt;
+      const sicp::LmState& st = h->h_bstates[p];
+      if (st.status == sicp::LM_RUNNING) continue;
+      std::memcpy(o[p].est, st.x, sizeof st.x);
+      g->st.total_lm_iters += st.iterations;
+      g->st.final_cost = st.cost;
+      g->st.total_evals += st.evaluations;
+      finished.push_back(p);
     }
-    if (one_launch) SICPCHECK(flush_jobs(L, jc));  // the counts: before the next searches overwrite idx
+    for (int p : finished) {
+      jc.slice = 0;
+      if (stats) SICPCHECK(count_active(hs[p]));  // before the pair's next search overwrites idx
+      outer_finish(P, o[p]);
+      if (o[p].converged) { phase[p] = DONE; ++n_done; } else phase[p] = NEED_SEARCH;
+    }
+    if (stats && one_launch && !finished.empty()) SICPCHECK(flush_jobs(h, jc, side));  // counts: same stream, ahead of the searches
+  }
+  {
+    sicp_context* h = L;
+    if (one_launch) HIPCHECK(hipStreamSynchronize(side));
   }
   for (int p = 0; p < n; ++p) {
     std::memcpy(out_qt + 7 * p, o[p].cur, sizeof o[p].cur);
@@ -1412,24 +1452,30 @@ int sicp_accumulate_batch(sicp_handle* hs, int32_t n, const double* qt, double* 
   for (int p = 0; p < n; ++p)
     if (!hs[p] || !hs[p]->corr_valid || hs[p]->device != hs[0]->device || hs[p]->corr_K != hs[0]->corr_K) return SICP_ERR_NOT_READY;
   sicp_context* h = hs[0];
+  if (n > kMaxActivePairs) return SICP_ERR_INVALID_ARGUMENT;  // one launch holds at most this many pairs
   SICPCHECK(set_device(h));
   SICPCHECK(batch_reserve(h, n));
-  int max_nb = 0;
+  int n_items = 0;
   for (int p = 0; p < n; ++p) {
     sicp_context* g = hs[p];
-    const int nb = sicp::accumulate_blocks(g->corr_n * g->corr_K);
+    const int nb = sicp::accumulate_blocks(g->corr_n * g->corr_K, g->corr_K);
     if (g->partials.reserve((size_t)nb * 28) != hipSuccess) return SICP_ERR_OUT_OF_MEMORY;
     std::memset(&h->h_batch[p], 0, sizeof(sicp::BatchArgs));
     fill_acc(g, h->h_batch[p].a);
     fill_pose(qt + 7 * p, h->h_batch[p].a.pose);
     h->h_batch[p].nb = nb;
-    max_nb = std::max(max_nb, nb);
+    h->h_batch[p].item_begin = n_items;
+    n_items += nb;
     HIPCHECK(hipStreamSynchronize(g->stream));  // the pair's correspondences are complete
   }
+  h->h_bhdr->n_pairs = n; h->h_bhdr->n_items = n_items; h->h_bhdr->pad_[0] = h->h_bhdr->pad_[1] = 0;
+  HIPCHECK(hipMemcpyAsync(h->d_bhdr.p, h->h_bhdr, sizeof(sicp::BatchHeader), hipMemcpyHostToDevice, h->stream));
   HIPCHECK(hipMemcpyAsync(h->d_batch.p, h->h_batch, sizeof(sicp::BatchArgs) * n, hipMemcpyHostToDevice, h->stream));
   if (repeat < 1) repeat = 1;
   HIPCHECK(hipEventRecord(h->ev0, h->stream));
-  for (int r = 0; r < repeat; ++r) HIPCHECK(sicp::launch_accumulate_batch(h->corr_K, h->d_batch.p, n, max_nb, h->stream));
+  for (int r = 0; r < repeat; ++r)
+    HIPCHECK(sicp::launch_accumulate_batch(h->corr_K, h->params.use_sqloss, h->d_bhdr.p, h->d_batch.p, std::min(h->h_batch_cap, kMaxActivePairs),
+                                           h->stream));
   HIPCHECK(hipEventRecord(h->ev1, h->stream));
   HIPCHECK(sicp::launch_finalize_batch(h->d_batch.p, n, h->d_bout28.p, h->stream));
   HIPCHECK(hipMemcpyAsync(h->h_bout28, h->d_bout28.p, sizeof(double) * 28 * n, hipMemcpyDeviceToHost, h->stream));
@@ -1484,12 +1530,8 @@ int sicp_covariances(sicp_handle h, int which, double* cov9, double* normal3, ui
   // what align() left behind is returned as it is (getSourceCovariances(), gicp.h:72-90)
   if (!features_current(h, c, with_hist) || (nn_idx && !c.nn.p)) SICPCHECK(compute_features(h, c, with_hist));
   const int n = c.n, k = P.k_cov;
-  std::vector<double> nx(n), ny(n), nz(n);
-  if (n > 0) {
-    HIPCHECK(hipMemcpyAsync(nx.data(), c.nx.p, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
-    HIPCHECK(hipMemcpyAsync(ny.data(), c.ny.p, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
-    HIPCHECK(hipMemcpyAsync(nz.data(), c.nz.p, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
-  }
+  std::vector<sicp::PointRec> rec(n);
+  if (n > 0) HIPCHECK(hipMemcpyAsync(rec.data(), c.rec.p, sizeof(sicp::PointRec) * n, hipMemcpyDeviceToHost, h->stream));
   std::vector<uint8_t> hh;
   std::vector<int> nn;
   if (hist && n > 0) {
@@ -1504,7 +1546,7 @@ int sicp_covariances(sicp_handle h, int which, double* cov9, double* normal3, ui
   const double ome = 1.0 - P.epsilon;
   for (int d = 0; d < n; ++d) {
     const int i = c.caller_index(d);
-    const double v[3] = {nx[d], ny[d], nz[d]};
+    const double v[3] = {rec[d].nx, rec[d].ny, rec[d].nz};
     if (normal3) { normal3[3 * (size_t)i] = v[0]; normal3[3 * (size_t)i + 1] = v[1]; normal3[3 * (size_t)i + 2] = v[2]; }
     if (cov9)  // the covariance the kernels use: C = I - (1-eps) n n^T  (== em_icp.hpp:331-338)
       for (int a = 0; a < 3; ++a)
@@ -1594,8 +1636,7 @@ int sicp_fused_labels(sicp_handle h, const double qt[7], uint32_t* out_labels) {
   sicp::WeightArgs a;
   a.n_s = S.n; a.K = 4; a.C = P.num_classes;
   a.idx = h->idx.p;
-  a.sx = S.x.p; a.sy = S.y.p; a.sz = S.z.p; a.tx = T.x.p; a.ty = T.y.p; a.tz = T.z.p;
-  a.snx = S.nx.p; a.sny = S.ny.p; a.snz = S.nz.p; a.tnx = T.nx.p; a.tny = T.ny.p; a.tnz = T.nz.p;
+  a.srec = S.rec.p; a.trec = T.rec.p;
   SICPCHECK(ensure_proj(h, S));
   SICPCHECK(ensure_proj(h, T));
   a.s_proj = S.proj.p; a.t_proj = T.proj.p;

@@ -6,12 +6,17 @@
 //                                                              gicp_cost_function.h:27-73
 //   lm_step*     : ceres::Solve's trust-region step (csrc/lm.hpp) em_icp.hpp:162-177
 //
-// Design notes (MI355X): clouds live in HBM in Hilbert-curve order (SoA float32 + a packed float4
-// x,y,z,caller-index copy for the search kernels).  Top-K lists are 64-bit (distance, caller index)
-// keys in statically indexed VGPRs.  No floating-point atomics anywhere, so every result is
-// run-to-run reproducible.  Nothing here is GEMM shaped: no MFMA.  All three kernel files are
-// compiled with -ffp-contract=off; fused multiply-adds are re-enabled per function where the float64
-// algebra only needs tolerance-level parity.
+// Design notes (MI355X).  The correspondence slots of a pair are cut into CHUNKS of 512 m groups of
+// SG slots (SG = 4 slots of one source point for K = 4 / 20, 2 source points for K = 1; m = 1 up to
+// 2M slots): a chunk is what one 256-lane workgroup sums -- every lane takes 2 m groups, 256 apart, in
+// ascending order, then the 28 sums go through an LDS transpose and DPP row reductions into
+// partials[28][n_chunks].  The chunk is the unit of reproducibility: whoever evaluates it (one
+// workgroup per chunk for a pair alone, a persistent workgroup walking over the chunks of all pairs
+// of a lock-step batch) performs the same additions in the same order, so a pair gets the same bits
+// alone and in a batch, run after run.  No floating-point atomics.  Points are read as 48-byte
+// records {x, y, z f32 | nx, ny, nz f64} -- one gather per target instead of six.  Nothing here is
+// GEMM shaped: no MFMA.  The file is compiled with -ffp-contract=off; fused multiply-adds are
+// re-enabled per function where the float64 algebra only needs tolerance-level parity.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -30,8 +35,8 @@ __device__ __forceinline__ double rcp_newton(double d) {
   return r;
 }
 
-// The accumulate kernels' form of corr_eval<true>: everything that only depends on the SOURCE point
-// (shared by the K = 4 or 20 slots of one source point) is computed once per group of four slots.
+// Everything that only depends on the SOURCE point (shared by the slots of one source point) is
+// computed once per group.
 struct SrcTerms {
   double qx, qy, qz;                      // R p_s + t
   double mx, my, mz;                      // m = R n_s
@@ -100,7 +105,7 @@ __device__ __forceinline__ void corr_eval_src(const Pose& P, double one_m_eps, c
 // The classic argument-reduction + odd-polynomial scheme of fdlibm's e_log.c (x = 2^k m,
 // f = m - 1, s = f / (2 + f), log(1+f) = 2s + s R(s^2) ...), < 1 ulp, with the division replaced by
 // v_rcp_f64 + two Newton steps and none of the library routine's special cases: ~35 instructions
-// instead of ~80.  The logarithm was 40 % of the accumulate kernel's instructions.
+// instead of ~80.
 __device__ __forceinline__ double log_ge1(double x) {
 #pragma clang fp contract(fast)
   double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
@@ -120,11 +125,11 @@ __device__ __forceinline__ double log_ge1(double x) {
 // rho0 / rho1 of the reference's loss stacks at s = r^2 (em_icp.hpp:109-117, gicp.hpp:98-104,
 // semantic_icp.hpp:96; Ceres CauchyLoss/ScaledLoss/ComposedLoss, sqloss.h); b = a^2, c = 1/b.  rho2 < 0
 // for all of them, so Ceres' Corrector scales residual and Jacobian by sqrt(rho1).  g0 = sqrt(v) and
-// g1 = 1 / (2 g0) both come from one reciprocal square root (a square root and a division less per
-// correspondence; ~1 ulp), the logarithm is log_ge1.
-__device__ __forceinline__ void loss_eval_acc(const LossArgs& L, double b, double c, double s, double w, double& rho0, double& rho1) {
+// g1 = 1 / (2 g0) both come from one reciprocal square root, the logarithm is log_ge1.
+template <bool SQLOSS>
+__device__ __forceinline__ void loss_eval_acc(double b, double c, double s, double w, double& rho0, double& rho1) {
 #pragma clang fp contract(fast)
-  if (L.use_sqloss) {
+  if (SQLOSS) {
     const double v = s + 2.220446049250313e-16;  // std::numeric_limits<double>::epsilon()
     const double y = rsqrt(v);
     const double g0 = v * y, g1 = 0.5 * y;
@@ -165,334 +170,144 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 #define SICP_GLOBAL __attribute__((address_space(1)))
 
-// the per-lane part of one evaluation: groups of 4 slots, loads first (see accumulate_kernel)
-// the pose is the same in every lane: held in scalar registers it costs no VGPRs (24 otherwise)
+// a value every lane holds identically -> scalar registers (it costs no VGPRs and feeds the scalar
+// operand of the vector instructions that use it)
+__device__ __forceinline__ double uniform_f64(double v) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+__device__ __forceinline__ int uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <class T>
+__device__ __forceinline__ T* uniform_ptr(T* p) {
+  const unsigned long long u = (unsigned long long)p;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
+  return (T*)(((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ void pose_to_sgprs(Pose& P) {
 #pragma unroll
-  for (int k = 0; k < 9; ++k) P.R[k] = readlane_f64(P.R[k], 0);
+  for (int k = 0; k < 9; ++k) P.R[k] = uniform_f64(P.R[k]);
 #pragma unroll
-  for (int k = 0; k < 3; ++k) P.t[k] = readlane_f64(P.t[k], 0);
+  for (int k = 0; k < 3; ++k) P.t[k] = uniform_f64(P.t[k]);
 }
 
-// One group = 4 consecutive slots.  A lane issues the loads of TWO groups (its grid-stride
-// neighbours) before it computes the first: the kernel runs at two waves per SIMD with ~70 spare
-// VGPRs, and an index -> gather chain from HBM is ~2 us, about the time one group takes to compute.
-// PF (prefetch depth inside a group) is kept for the chained kernel experiments; the slots are always
-// accumulated in ascending order, so every variant produces the same bits.
+// ---- one group of SG consecutive slots: what a lane loads, and what it computes from it -----------
 template <int K>
-struct SlotGroup {
-  int j[4];
-  double w[4];
-  float sx[4], sy[4], sz[4], tx[4], ty[4], tz[4];
-  double snx[4], sny[4], snz[4], tnx[4], tny[4], tnz[4];
+struct GroupShape {
+  static constexpr int SG = (K % 4 == 0) ? 4 : 2;   // slots per group
+  static constexpr int NS = (K % 4 == 0) ? 1 : 2;   // source points per group
 };
 
-template <int K, int BS, int PF = 4>
-__device__ __forceinline__ void accumulate_groups(const AccArgs& a, const Pose& P, int block, int nb, double (&acc)[28]) {
-#pragma unroll
-  for (int k = 0; k < 28; ++k) acc[k] = 0.0;
-  // every array is HBM: typed as such, the loads are global_load even when the pointers themselves
-  // were fetched from memory (batch form), where the compiler would otherwise emit flat_load
-  const SICP_GLOBAL int* idx = (const SICP_GLOBAL int*)a.idx;
-  const SICP_GLOBAL double* wgt = (const SICP_GLOBAL double*)a.w;
-  const SICP_GLOBAL float *sx = (const SICP_GLOBAL float*)a.sx, *sy = (const SICP_GLOBAL float*)a.sy, *sz = (const SICP_GLOBAL float*)a.sz;
-  const SICP_GLOBAL float *tx = (const SICP_GLOBAL float*)a.tx, *ty = (const SICP_GLOBAL float*)a.ty, *tz = (const SICP_GLOBAL float*)a.tz;
-  const SICP_GLOBAL double *g_snx = (const SICP_GLOBAL double*)a.snx, *g_sny = (const SICP_GLOBAL double*)a.sny, *g_snz = (const SICP_GLOBAL double*)a.snz;
-  const SICP_GLOBAL double *g_tnx = (const SICP_GLOBAL double*)a.tnx, *g_tny = (const SICP_GLOBAL double*)a.tny, *g_tnz = (const SICP_GLOBAL double*)a.tnz;
-  const int total = a.n_s * K;
-  const int n_groups = (total + 3) >> 2;
-  const double loss_b = a.loss.cauchy_a * a.loss.cauchy_a, loss_c = 1.0 / loss_b;
+template <int K>
+struct Group {
+  static constexpr int SG = GroupShape<K>::SG, NS = GroupShape<K>::NS;
+  int j[SG];
+  double w[SG];
+  float sx[NS], sy[NS], sz[NS], tx[SG], ty[SG], tz[SG];
+  double snx[NS], sny[NS], snz[NS], tnx[SG], tny[SG], tnz[SG];
+};
 
-  auto load = [&](int g, SlotGroup<K>& G) {
-    const int e0 = g << 2;
-    if (e0 + 3 < total) {
-      typedef int v4i __attribute__((ext_vector_type(4)));
-      const v4i jv = *(const SICP_GLOBAL v4i*)(idx + e0);
-      G.j[0] = jv.x; G.j[1] = jv.y; G.j[2] = jv.z; G.j[3] = jv.w;
+// uniform (per pair) inputs of the loads and of the arithmetic
+struct LoadCtx {
+  const SICP_GLOBAL int* idx;
+  const SICP_GLOBAL double* w;       // nullable: weight 1
+  const SICP_GLOBAL PointRec* srec;
+  const SICP_GLOBAL PointRec* trec;
+  int n_s, total;
+};
+struct MathCtx {
+  Pose P;
+  double one_m_eps, loss_b, loss_c;
+};
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void load_rec(const SICP_GLOBAL PointRec* r, float& x, float& y, float& z, double& nx, double& ny, double& nz) {
+  const SICP_GLOBAL char* p = (const SICP_GLOBAL char*)r;
+  const v4f a = *(const SICP_GLOBAL v4f*)p;          // x y z .
+  const v2d b = *(const SICP_GLOBAL v2d*)(p + 16);   // nx ny
+  const double c = *(const SICP_GLOBAL double*)(p + 32);
+  x = a.x; y = a.y; z = a.z; nx = b.x; ny = b.y; nz = c;
+}
+
+// the indices of group g (issued one pipeline stage before the gathers that need their values)
+template <int K>
+__device__ __forceinline__ void load_idx(const LoadCtx& L, int g, int (&j)[GroupShape<K>::SG]) {
+  constexpr int SG = GroupShape<K>::SG;
+  const int e0 = g * SG;
+  if (e0 + SG - 1 < L.total) {
+    if (SG == 4) {
+      const v4i v = *(const SICP_GLOBAL v4i*)(L.idx + e0);
+      j[0] = v.x; j[1] = v.y; j[SG - 2] = v.z; j[SG - 1] = v.w;
     } else {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) G.j[c] = e0 + c < total ? idx[e0 + c] : -1;
+      const v2i v = *(const SICP_GLOBAL v2i*)(L.idx + e0);
+      j[0] = v.x; j[SG - 1] = v.y;
     }
+  } else {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int e = e0 + c;
-      const int i = min(e / K, a.n_s - 1);
-      const int jj = max(G.j[c], 0);
-      G.w[c] = wgt ? wgt[min(e, total - 1)] : 1.0;
-      if (K % 4 != 0 || c == 0) {
-        G.sx[c] = sx[i]; G.sy[c] = sy[i]; G.sz[c] = sz[i];
-        G.snx[c] = g_snx[i]; G.sny[c] = g_sny[i]; G.snz[c] = g_snz[i];
-      } else {  // K a multiple of 4: the four slots of a group share one source point
-        G.sx[c] = G.sx[0]; G.sy[c] = G.sy[0]; G.sz[c] = G.sz[0];
-        G.snx[c] = G.snx[0]; G.sny[c] = G.sny[0]; G.snz[c] = G.snz[0];
-      }
-      G.tx[c] = tx[jj]; G.ty[c] = ty[jj]; G.tz[c] = tz[jj];
-      G.tnx[c] = g_tnx[jj]; G.tny[c] = g_tny[jj]; G.tnz[c] = g_tnz[jj];
-    }
-  };
-  auto compute = [&](const SlotGroup<K>& G) {
-    SrcTerms st;
+    for (int c = 0; c < SG; ++c) j[c] = e0 + c < L.total ? L.idx[e0 + c] : -1;  // ragged tail / past the end: weight 0
+  }
+}
+
+template <int K>
+__device__ __forceinline__ void load_data(const LoadCtx& L, int g, Group<K>& G) {
+  constexpr int SG = GroupShape<K>::SG, NS = GroupShape<K>::NS;
+  const int e0 = g * SG;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+  for (int c = 0; c < SG; ++c) G.w[c] = L.w ? L.w[max(min(e0 + c, L.total - 1), 0)] : 1.0;
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int i = max(min((e0 + s * (SG / NS)) / K, L.n_s - 1), 0);
+    load_rec(L.srec + i, G.sx[s], G.sy[s], G.sz[s], G.snx[s], G.sny[s], G.snz[s]);
+  }
+#pragma unroll
+  for (int c = 0; c < SG; ++c) load_rec(L.trec + max(G.j[c], 0), G.tx[c], G.ty[c], G.tz[c], G.tnx[c], G.tny[c], G.tnz[c]);
+}
+
+template <int K, bool SQLOSS>
+__device__ __forceinline__ void compute_group(const MathCtx& M, const Group<K>& G, double (&acc)[28]) {
+  constexpr int SG = GroupShape<K>::SG, NS = GroupShape<K>::NS;
+  SrcTerms st;
+#pragma unroll
+  for (int c = 0; c < SG; ++c) {
 #pragma clang fp contract(fast)
-      if (K % 4 != 0 || c == 0) src_terms(P, a.one_m_eps, G.sx[c], G.sy[c], G.sz[c], G.snx[c], G.sny[c], G.snz[c], st);
-      // A gated-out slot (index -1) is evaluated on target 0 and weighted by exactly zero instead of
-      // being branched around: x + (+-0 * finite) == x bit for bit, and a divergent skip makes the
-      // compiler copy all 28 accumulators at the join (10 % of the kernel's instructions).
-      Corr cr;
-      corr_eval_src(P, a.one_m_eps, st, G.sx[c], G.sy[c], G.sz[c], G.snx[c], G.sny[c], G.snz[c], G.tx[c], G.ty[c], G.tz[c], G.tnx[c],
-                    G.tny[c], G.tnz[c], cr);
-      double rho0, rho1;
-      loss_eval_acc(a.loss, loss_b, loss_c, cr.r * cr.r, G.w[c], rho0, rho1);
-      if (G.j[c] < 0) { rho0 = 0.0; rho1 = 0.0; }
-      // cr.J is J/2:  rho1 J J^T = (4 rho1) (J/2)(J/2)^T,  rho1 r J = (4 rho1) (J/2) (r/2)
-      const double rho4 = 4.0 * rho1, rh = 0.5 * cr.r;
-      int o = 0;
+    const int s = NS == 1 ? 0 : c / (SG / NS);
+    if (c % (SG / NS) == 0) src_terms(M.P, M.one_m_eps, G.sx[s], G.sy[s], G.sz[s], G.snx[s], G.sny[s], G.snz[s], st);
+    // A gated-out slot (index -1) is evaluated on target 0 and weighted by exactly zero instead of
+    // being branched around: x + (+-0 * finite) == x bit for bit, and a divergent skip makes the
+    // compiler copy all 28 accumulators at the join.
+    Corr cr;
+    corr_eval_src(M.P, M.one_m_eps, st, G.sx[s], G.sy[s], G.sz[s], G.snx[s], G.sny[s], G.snz[s], G.tx[c], G.ty[c], G.tz[c], G.tnx[c],
+                  G.tny[c], G.tnz[c], cr);
+    double rho0, rho1;
+    loss_eval_acc<SQLOSS>(M.loss_b, M.loss_c, cr.r * cr.r, G.w[c], rho0, rho1);
+    if (G.j[c] < 0) { rho0 = 0.0; rho1 = 0.0; }
+    // cr.J is J/2:  rho1 J J^T = (4 rho1) (J/2)(J/2)^T,  rho1 r J = (4 rho1) (J/2) (r/2)
+    const double rho4 = 4.0 * rho1, rh = 0.5 * cr.r;
+    int o = 0;
 #pragma unroll
-      for (int p = 0; p < 6; ++p) {
-        const double jp = rho4 * cr.J[p];
+    for (int p = 0; p < 6; ++p) {
+      const double jp = rho4 * cr.J[p];
 #pragma unroll
-        for (int q = p; q < 6; ++q) acc[o++] += jp * cr.J[q];
-        acc[21 + p] += jp * rh;
-      }
-      acc[27] += 0.5 * rho0;
+      for (int q = p; q < 6; ++q) acc[o++] += jp * cr.J[q];
+      acc[21 + p] += jp * rh;
     }
-  };
-
-  const int stride = nb * BS;
-  for (int g = block * BS + threadIdx.x; g < n_groups; g += (PF == 8 ? 2 : 1) * stride) {
-    SlotGroup<K> A;
-    load(g, A);
-    if (PF == 8) {
-      SlotGroup<K> B;
-      const bool two = g + stride < n_groups;
-      load(two ? g + stride : g, B);  // a lane without a second group re-reads its first, with zero weight:
-      if (!two) { B.j[0] = -1; B.j[1] = -1; B.j[2] = -1; B.j[3] = -1; }  // no branch around loads or sums
-      compute(A);
-      compute(B);
-    } else {
-      compute(A);
-    }
+    acc[27] += 0.5 * rho0;
   }
 }
 
-// One lane handles groups of 4 consecutive slots: all index / weight / point / normal loads of the
-// group are issued before the first residual is computed (4 independent gather chains in flight
-// per lane instead of one), then the 28 partial sums are combined across the block through an
-// LDS transpose so that each wave only performs 7 cross-lane reductions.
-//
-// FUSED (device-resident solve): the last block to finish -- decided by an arrival ticket -- also
-// sums the per-block partials (four waves, seven rows each, same fixed order as reduce_partials)
-// and advances the LM machine (lm.hpp: lm_feed) in its lane 0, so one LM evaluation is ONE kernel
-// and one launch boundary instead of two.
-template <int K, int BS, bool FUSED>
-__global__ __launch_bounds__(BS) void accumulate_kernel(AccArgs a) {
-  __shared__ double red[28][BS];
-  Pose P;
-  if (a.lm) {
-    // device-resident solve: the pose to evaluate lives in the LM state; once the solve has
-    // finished, the launches still queued behind it do nothing (uniform exit)
-    if (a.lm->status != LM_RUNNING) return;
-    se3::rotation(a.lm->pose, P.R);
-    P.t[0] = a.lm->pose[4]; P.t[1] = a.lm->pose[5]; P.t[2] = a.lm->pose[6];
-  } else {
-    P = a.pose;
-  }
-  pose_to_sgprs(P);
-  double acc[28];
-  accumulate_groups<K, BS>(a, P, (int)blockIdx.x, (int)gridDim.x, acc);
-  // block reduction: transpose through LDS, then wave w owns outputs w, w + BS/64, ...
-#pragma unroll
-  for (int k = 0; k < 28; ++k) red[k][threadIdx.x] = acc[k];
-  __syncthreads();
+// The 28 sums of a workgroup -> partials[k][chunk]: transpose through LDS, RED_ROWS rows at a time
+// (28 rows at once would be 56 KB), wave w sums rows w, w + 4, ... with DPP.  Fixed order.
+constexpr int RED_ROWS = 14;
+template <int BS>
+__device__ __forceinline__ void block_reduce_store(const double (&acc)[28], double (&red)[RED_ROWS][BS], SICP_GLOBAL double* partials,
+                                                   int n_chunks, int chunk) {
   constexpr int NW = BS / 64;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int k = wave; k < 28; k += NW) {
-    double sum = 0.0;
-#pragma unroll
-    for (int t = 0; t < NW; ++t) sum += red[k][lane + 64 * t];
-    sum = wave_sum(sum);
-    if (lane == 0) {  // [28][blocks]: coalesced for the reducer
-      double* dst = a.partials + (size_t)k * gridDim.x + blockIdx.x;
-      if constexpr (FUSED)  // device-scope store: written through to where every XCD sees it
-        __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst), (unsigned long long)__double_as_longlong(sum), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-      else
-        *dst = sum;
-    }
-  }
-  if constexpr (FUSED) {
-    // Arrival ticket WITHOUT fences: a release/acquire fence at device scope writes back and
-    // invalidates the XCD's whole L2 (measured: 2x slower, the other blocks lose the cloud).  The
-    // partials are device-scope atomic stores and loads (sc1: coherent across XCDs by themselves),
-    // so it is enough that a block's stores have completed (vmcnt(0)) before it takes its ticket.
-    __shared__ unsigned s_ticket;
-    __shared__ double s_out[28];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    if (s_ticket != gridDim.x - 1) return;
-    const int nb = (int)gridDim.x;
-    for (int k = wave; k < 28; k += NW) {
-      const unsigned long long* __restrict__ row = reinterpret_cast<const unsigned long long*>(a.partials) + (size_t)k * nb;
-      double s = 0.0;
-      for (int b0 = lane; b0 < nb; b0 += 64 * 8) {  // 8 trips of loads in flight, summed in trip order
-        double v[8];
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          const int b = b0 + 64 * t;
-          v[t] = b < nb ? __longlong_as_double((long long)__hip_atomic_load(row + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0.0;
-        }
-        asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
-#pragma unroll
-        for (int t = 0; t < 8; ++t)
-          if (b0 + 64 * t < nb) s += v[t];
-      }
-      s = wave_sum(s);
-      if (lane == 0) s_out[k] = s;
-    }
-    // the 0.8 KB state goes HBM -> LDS (all lanes, one round trip) -> lane 0's registers, and back
-    // the same way.  Lane 0 needs it in registers: it runs alone, so every LDS or HBM access
-    // inside lm_feed would be an exposed latency (measured: +5 us with the state left in LDS).
-    __shared__ double s_state[(sizeof(LmState) + 7) / 8];
-    constexpr int NSTATE = (int)((sizeof(LmState) + 7) / 8);
-    static_assert(sizeof(LmState) % 8 == 0, "LmState is copied as doubles");
-    double* g_state = reinterpret_cast<double*>(a.lm_step);
-    for (int i = threadIdx.x; i < NSTATE; i += BS) s_state[i] = g_state[i];
-    __syncthreads();
-    if (wave == 0) {
-      if (lane == 0) {
-        double o[28];
-#pragma unroll
-        for (int k = 0; k < 28; ++k) o[k] = s_out[k];
-        LmState st = *reinterpret_cast<const LmState*>(s_state);
-        lm_feed(st, o);
-        *reinterpret_cast<LmState*>(s_state) = st;
-      }
-      // same wave: lane 0's LDS writes are ordered before these reads
-      for (int i = lane; i < NSTATE; i += 64) g_state[i] = s_state[i];
-      if (lane == 0) *a.ticket = 0u;  // the next launch starts counting from zero
-    }
-  }
-}
-
-// Chained device-resident solve: one kernel per LM evaluation and nothing in between.
-//
-// Launch n reads state[n & 1] and the partials of launch n-1, and EVERY block first finishes that
-// previous evaluation itself: it sums the partials (four waves, seven rows each, the fixed order of
-// reduce_partials) and runs lm_feed in its lane 0 -- all blocks compute the same bits, so all of
-// them know the next pose without a second kernel, a grid barrier or a fence ("combine in the next
-// kernel's prologue").  Then the block accumulates its share of the new evaluation into
-// partials[(n+1) & 1]; block 0 also publishes the advanced state as state[(n+1) & 1] (double
-// buffering: other blocks of this launch may still be reading state[n & 1]).  The loads of the
-// block's first slots do not depend on the pose and are in flight while lane 0 steps the solver.
-template <int K, int BS>
-__global__ __launch_bounds__(BS) void accumulate_chain_kernel(AccArgs a) {
-  __shared__ double red[28][BS];
-  constexpr int NSTATE = (int)(sizeof(LmState) / 8);
-  static_assert(sizeof(LmState) % 8 == 0, "LmState is copied as doubles");
-  __shared__ double s_state[NSTATE];
-  __shared__ double s_out[28];
-  constexpr int NW = BS / 64;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nb = (int)gridDim.x;
-  const double* __restrict__ g_in = reinterpret_cast<const double*>(a.lm);
-  for (int i = threadIdx.x; i < NSTATE; i += BS) s_state[i] = g_in[i];
-  // the previous launch's partials: issued before anybody looks at the state (one round trip
-  // for both); harmless when there is nothing pending
-  {
-    for (int k = wave; k < 28; k += NW) {
-      const double* __restrict__ row = a.partials_in + (size_t)k * nb;
-      double s = 0.0;
-      for (int b0 = lane; b0 < nb; b0 += 64 * 4) {
-        double v[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) v[t] = b0 + 64 * t < nb ? row[b0 + 64 * t] : 0.0;
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-          if (b0 + 64 * t < nb) s += v[t];
-      }
-      s = wave_sum(s);
-      if (lane == 0) s_out[k] = s;
-    }
-  }
-  __syncthreads();
-  LmState* S = reinterpret_cast<LmState*>(s_state);
-  if (S->status == LM_RUNNING && S->pending) {
-    if (threadIdx.x == 0) {
-      double o[28];
-#pragma unroll
-      for (int k = 0; k < 28; ++k) o[k] = s_out[k];
-      LmState st = *S;
-      lm_feed(st, o);
-      st.pending = 0;
-      *S = st;
-    }
-    __syncthreads();
-  }
-  double* g_out = reinterpret_cast<double*>(a.lm_step);
-  if (S->status != LM_RUNNING) {  // finished (now or earlier): hand the state on, nothing to evaluate
-    if (blockIdx.x == 0)
-      for (int i = threadIdx.x; i < NSTATE; i += BS) g_out[i] = s_state[i];
-    return;
-  }
-  Pose P;
-  se3::rotation(S->pose, P.R);
-  P.t[0] = S->pose[4]; P.t[1] = S->pose[5]; P.t[2] = S->pose[6];
-  pose_to_sgprs(P);
-  double acc[28];
-  accumulate_groups<K, BS>(a, P, (int)blockIdx.x, nb, acc);
-#pragma unroll
-  for (int k = 0; k < 28; ++k) red[k][threadIdx.x] = acc[k];
-  __syncthreads();
-  for (int k = wave; k < 28; k += NW) {
-    double sum = 0.0;
-#pragma unroll
-    for (int t = 0; t < NW; ++t) sum += red[k][lane + 64 * t];
-    sum = wave_sum(sum);
-    if (lane == 0) a.partials[(size_t)k * nb + blockIdx.x] = sum;
-  }
-  if (blockIdx.x == 0) {
-    if (threadIdx.x == 0) S->pending = 1;
-    __syncthreads();
-    for (int i = threadIdx.x; i < NSTATE; i += BS) g_out[i] = s_state[i];
-  }
-}
-
-// Lock-step batch of independent pairs (sicp_align_batch): blockIdx.y selects the pair, whose
-// arguments live in HBM (one BatchArgs per pair, read through scalar loads).  One launch evaluates
-// the current LM pose of EVERY pair of the batch: P times fewer launches, launch boundaries and L2
-// invalidations than P pairs solving side by side on their own streams, and P x 15 MB of
-// algorithmic traffic behind one ~10 us launch floor.  Per pair the arithmetic, the block
-// decomposition and therefore the bits are those of accumulate_kernel.
-template <int K, int BS, int PF>
-__global__ __launch_bounds__(BS) void accumulate_batch_kernel(const BatchArgs* __restrict__ batch) {
-  constexpr int RED_ROWS = 14;
-  __shared__ double red[RED_ROWS][BS];
-  const BatchArgs& B = batch[blockIdx.y];
-  const int nb = B.nb, block = (int)blockIdx.x;
-  if (block >= nb) return;
-  const AccArgs& a = B.a;
-  Pose P;
-  if (a.lm) {
-    if (a.lm->status != LM_RUNNING) return;
-    se3::rotation(a.lm->pose, P.R);
-    P.t[0] = a.lm->pose[4]; P.t[1] = a.lm->pose[5]; P.t[2] = a.lm->pose[6];
-  } else {
-    P = a.pose;
-  }
-  pose_to_sgprs(P);
-  double acc[28];
-  accumulate_groups<K, BS, PF>(a, P, block, nb, acc);
-  // the same transpose reduction as accumulate_kernel, RED_ROWS rows at a time (same additions in
-  // the same order, so the same bits): 28 rows at once are 56 KB of LDS, i.e. two workgroups per CU
-  constexpr int NW = BS / 64;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  SICP_GLOBAL double* partials = (SICP_GLOBAL double*)a.partials;
 #pragma unroll
   for (int p0 = 0; p0 < 28; p0 += RED_ROWS) {
-    if (p0) __syncthreads();
+    __syncthreads();  // the previous round's (or the previous chunk's) reads are done
 #pragma unroll
     for (int k = 0; k < RED_ROWS; ++k) red[k][threadIdx.x] = acc[p0 + k];
     __syncthreads();
@@ -501,12 +316,162 @@ __global__ __launch_bounds__(BS) void accumulate_batch_kernel(const BatchArgs* _
 #pragma unroll
       for (int t = 0; t < NW; ++t) sum += red[kk][lane + 64 * t];
       sum = wave_sum(sum);
-      if (lane == 0) partials[(size_t)(p0 + kk) * nb + block] = sum;
+      if (lane == 0) partials[(size_t)(p0 + kk) * n_chunks + chunk] = sum;
     }
   }
 }
 
-// fixed-order sum of the block partials (layout [28][n_blocks]) by one wave: every lane owns rows
+__device__ __forceinline__ void load_ctx_from_args(const AccArgs& a, LoadCtx& L, MathCtx& M) {
+  L.idx = (const SICP_GLOBAL int*)a.idx;
+  L.w = (const SICP_GLOBAL double*)a.w;
+  L.srec = (const SICP_GLOBAL PointRec*)a.srec;
+  L.trec = (const SICP_GLOBAL PointRec*)a.trec;
+  L.n_s = a.n_s;
+  L.total = a.n_s * a.K;
+  M.one_m_eps = a.one_m_eps;
+  M.loss_b = a.loss.cauchy_a * a.loss.cauchy_a;
+  M.loss_c = 1.0 / M.loss_b;
+}
+
+// One pair alone: one workgroup per chunk.  The loads of a lane's two groups share the memory
+// latency (both are in flight before the first is computed).
+template <int K, bool SQLOSS, int BS>
+__global__ __launch_bounds__(BS) void accumulate_kernel(AccArgs a) {
+  __shared__ double red[RED_ROWS][BS];
+  LoadCtx L;
+  MathCtx M;
+  if (a.lm) {
+    // device-resident solve: the pose to evaluate lives in the LM state; once the solve has
+    // finished, the launches still queued behind it do nothing (uniform exit)
+    if (a.lm->status != LM_RUNNING) return;
+    se3::rotation(a.lm->pose, M.P.R);
+    M.P.t[0] = a.lm->pose[4]; M.P.t[1] = a.lm->pose[5]; M.P.t[2] = a.lm->pose[6];
+  } else {
+    M.P = a.pose;
+  }
+  pose_to_sgprs(M.P);
+  load_ctx_from_args(a, L, M);
+  const AccGeometry geo = acc_geometry(L.total, GroupShape<K>::SG);
+  const int chunk = (int)blockIdx.x;
+  const int g0 = chunk * geo.chunk_groups + (int)threadIdx.x;
+  double acc[28];
+#pragma unroll
+  for (int k = 0; k < 28; ++k) acc[k] = 0.0;
+  for (int s = 0; s < 2 * geo.m; s += 2) {
+    Group<K> A, B;
+    load_idx<K>(L, g0 + s * BS, A.j);
+    load_idx<K>(L, g0 + (s + 1) * BS, B.j);
+    load_data<K>(L, g0 + s * BS, A);
+    load_data<K>(L, g0 + (s + 1) * BS, B);
+    compute_group<K, SQLOSS>(M, A, acc);
+    compute_group<K, SQLOSS>(M, B, acc);
+  }
+  block_reduce_store<BS>(acc, red, (SICP_GLOBAL double*)a.partials, geo.n_chunks, chunk);
+}
+
+// ------------------------------------------------------------------------------------------
+// Lock-step batch (sicp_align_batch): ONE launch evaluates the current LM pose of every pair that
+// still iterates.  Persistent workgroups (2 per CU) walk over the flattened list of (pair, chunk)
+// items, item = blockIdx.x, + gridDim.x, ...; the per-pair constants (pointers, rotation of the
+// current LM pose, loss) are staged in LDS once per workgroup.
+// ------------------------------------------------------------------------------------------
+struct PairCtx {
+  const int* idx;
+  const double* w;
+  const PointRec* srec;
+  const PointRec* trec;
+  double* partials;
+  int n_s, total, m, chunk_groups, n_chunks, item_begin, running, pad_;
+  double R[9], t[3];
+  double one_m_eps, loss_b, loss_c;
+};
+
+template <int K, bool SQLOSS, int BS>
+__global__ __launch_bounds__(BS, 2) void accumulate_stream_kernel(const BatchHeader* __restrict__ hdr, const BatchArgs* __restrict__ batch) {
+  extern __shared__ double smem[];
+  double (&red)[RED_ROWS][BS] = *reinterpret_cast<double (*)[RED_ROWS][BS]>(smem);
+  PairCtx* ctx = reinterpret_cast<PairCtx*>(smem + RED_ROWS * BS);
+  const int n_pairs = hdr->n_pairs, n_items = hdr->n_items;
+  if ((int)blockIdx.x >= n_items) return;
+  // ---- stage the per-pair constants (lane p: pair p)
+  for (int p = threadIdx.x; p < n_pairs; p += BS) {
+    const BatchArgs& B = batch[p];
+    const AccArgs& a = B.a;
+    PairCtx c;
+    c.idx = a.idx; c.w = a.w; c.srec = a.srec; c.trec = a.trec; c.partials = a.partials;
+    c.n_s = a.n_s; c.total = a.n_s * a.K;
+    const AccGeometry geo = acc_geometry(c.total, GroupShape<K>::SG);
+    c.m = geo.m; c.chunk_groups = geo.chunk_groups; c.n_chunks = geo.n_chunks;
+    c.item_begin = B.item_begin;
+    c.pad_ = 0;
+    Pose P;
+    if (a.lm) {
+      c.running = a.lm->status == LM_RUNNING;
+      se3::rotation(a.lm->pose, P.R);
+      P.t[0] = a.lm->pose[4]; P.t[1] = a.lm->pose[5]; P.t[2] = a.lm->pose[6];
+    } else {
+      c.running = 1;
+      P = a.pose;
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) c.R[k] = P.R[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) c.t[k] = P.t[k];
+    c.one_m_eps = a.one_m_eps;
+    c.loss_b = a.loss.cauchy_a * a.loss.cauchy_a;
+    c.loss_c = 1.0 / c.loss_b;
+    ctx[p] = c;
+  }
+  __syncthreads();
+
+  const int G = (int)gridDim.x;
+  MathCtx M;
+  LoadCtx L;
+  int cur_pair = -1;
+  for (int item = (int)blockIdx.x; item < n_items; item += G) {
+    // item -> pair: last pair whose first item is <= item (uniform binary search in LDS)
+    int lo = 0, hi = n_pairs - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (ctx[mid].item_begin <= item) lo = mid; else hi = mid - 1;
+    }
+    const int pair = uniform_i32(lo);
+    const PairCtx& p = ctx[pair];
+    if (!p.running) continue;  // the pair's solve has finished: its chunks are stepped over
+    if (pair != cur_pair) {
+      L.idx = (const SICP_GLOBAL int*)uniform_ptr(p.idx);
+      L.w = (const SICP_GLOBAL double*)uniform_ptr(p.w);
+      L.srec = (const SICP_GLOBAL PointRec*)uniform_ptr(p.srec);
+      L.trec = (const SICP_GLOBAL PointRec*)uniform_ptr(p.trec);
+      L.n_s = uniform_i32(p.n_s);
+      L.total = uniform_i32(p.total);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) M.P.R[k] = uniform_f64(p.R[k]);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) M.P.t[k] = uniform_f64(p.t[k]);
+      M.one_m_eps = uniform_f64(p.one_m_eps); M.loss_b = uniform_f64(p.loss_b); M.loss_c = uniform_f64(p.loss_c);
+      cur_pair = pair;
+    }
+    const int chunk = uniform_i32(item - p.item_begin);
+    const int g0 = chunk * uniform_i32(p.chunk_groups) + (int)threadIdx.x;
+    const int two_m = uniform_i32(2 * p.m);
+    double acc[28];
+#pragma unroll
+    for (int k = 0; k < 28; ++k) acc[k] = 0.0;
+    for (int s = 0; s < two_m; s += 2) {
+      Group<K> A, B;
+      load_idx<K>(L, g0 + s * BS, A.j);
+      load_idx<K>(L, g0 + (s + 1) * BS, B.j);
+      load_data<K>(L, g0 + s * BS, A);
+      load_data<K>(L, g0 + (s + 1) * BS, B);
+      compute_group<K, SQLOSS>(M, A, acc);
+      compute_group<K, SQLOSS>(M, B, acc);
+    }
+    block_reduce_store<BS>(acc, red, (SICP_GLOBAL double*)uniform_ptr(p.partials), uniform_i32(p.n_chunks), chunk);
+  }
+}
+
+// fixed-order sum of the chunk partials (layout [28][n_chunks]) by one wave: every lane owns chunks
 // lane, lane+64, ... ; the 28 loads of one trip are independent and coalesced
 __device__ __forceinline__ void reduce_partials(const double* __restrict__ partials, int n_blocks, int lane, double (&o)[28]) {
   double s[28];
@@ -532,7 +497,7 @@ __device__ __forceinline__ void reduce_partials(const double* __restrict__ parti
   for (int k = 0; k < 28; ++k) o[k] = wave_sum(s[k]);
 }
 
-// host-loop solve: sum the per-block partials in a fixed order
+// host-loop solve: sum the per-chunk partials in a fixed order
 __global__ __launch_bounds__(64) void finalize_kernel(const double* partials, int n_blocks, double* out28) {
   double o[28];
   reduce_partials(partials, n_blocks, threadIdx.x, o);
@@ -544,7 +509,7 @@ __global__ __launch_bounds__(64) void finalize_kernel(const double* partials, in
   }
 }
 
-// device-resident solve: reduce the block partials and advance the LM machine by one evaluation
+// device-resident solve: reduce the chunk partials and advance the LM machine by one evaluation
 // (lm.hpp: the same lm_feed the host loop runs).  One wave: 512 VGPRs are available to it, so the
 // whole 6x6 trust-region step stays in registers; lane 0 does the serial part.
 __global__ __launch_bounds__(64) void lm_step_kernel(LmState* lm, const double* partials, int n_blocks) {
@@ -559,8 +524,10 @@ __global__ __launch_bounds__(64) void lm_step_kernel(LmState* lm, const double* 
   }
 }
 
-// batch forms: one block (one wave) per pair
-__global__ __launch_bounds__(64) void lm_step_batch_kernel(const BatchArgs* __restrict__ batch) {
+// batch forms: one block (one wave) per pair; the grid is the capacity of the batch buffers, the
+// blocks beyond the number of active pairs leave at once
+__global__ __launch_bounds__(64) void lm_step_batch_kernel(const BatchHeader* __restrict__ hdr, const BatchArgs* __restrict__ batch) {
+  if ((int)blockIdx.x >= hdr->n_pairs) return;
   const BatchArgs& B = batch[blockIdx.x];
   LmState* lm = B.a.lm_step;
   if (lm->status != LM_RUNNING) return;
@@ -586,153 +553,6 @@ __global__ __launch_bounds__(64) void finalize_batch_kernel(const BatchArgs* __r
   }
 }
 
-// final_cloud = float(matrix) * source, the float overload of pcl::transformPointCloud
-// (em_icp.hpp:192-198): float matrix, float arithmetic, row by row
-
-int accumulate_blocks(int total) {
-  // each lane sums several slots in registers before the (LDS-bound) wave reduction; the grid
-  // still covers every CU.  SICP_ACC_SLOTS_PER_LANE is a tuning aid.
-  static const int per_lane = [] { const char* e = getenv("SICP_ACC_SLOTS_PER_LANE"); return e ? atoi(e) : 8; }();
-  const int bs = 256;
-  int nb = (total + bs * per_lane - 1) / (bs * per_lane);
-  if (nb > 1024) nb = 1024;
-  if (nb < 1) nb = 1;
-  return nb;
-}
-
-static hipError_t launch_accumulate_only(const AccArgs& a, int nb, hipStream_t st) {
-  switch (a.K) {
-    case 1: hipLaunchKernelGGL((accumulate_kernel<1, 256, false>), dim3(nb), dim3(256), 0, st, a); break;
-    case 4: hipLaunchKernelGGL((accumulate_kernel<4, 256, false>), dim3(nb), dim3(256), 0, st, a); break;
-    case 20: hipLaunchKernelGGL((accumulate_kernel<20, 256, false>), dim3(nb), dim3(256), 0, st, a); break;
-    default: return hipErrorInvalidValue;
-  }
-  return hipGetLastError();
-}
-
-// batched evaluation: `batch` holds n BatchArgs in HBM, max_nb = largest block count among them
-hipError_t launch_accumulate_batch(int K, const BatchArgs* batch, int n, int max_nb, hipStream_t st) {
-  if (n <= 0) return hipSuccess;
-  const dim3 grid(max_nb, n);
-  static const int pf = [] { const char* e = getenv("SICP_ACC_BATCH_PF"); return e ? atoi(e) : 4; }();  // tuning aid
-#define SICP_AB(KK) \
-  do { \
-    if (pf == 8) hipLaunchKernelGGL((accumulate_batch_kernel<KK, 256, 8>), grid, dim3(256), 0, st, batch); \
-    else hipLaunchKernelGGL((accumulate_batch_kernel<KK, 256, 4>), grid, dim3(256), 0, st, batch); \
-  } while (0)
-  switch (K) {
-    case 1: SICP_AB(1); break;
-    case 4: SICP_AB(4); break;
-    case 20: SICP_AB(20); break;
-    default: return hipErrorInvalidValue;
-  }
-#undef SICP_AB
-  return hipGetLastError();
-}
-
-// ---- the batched inner solve as a graph with explicit nodes --------------------------------------
-static void* accumulate_batch_fn(int K) {
-  static const int pf = [] { const char* e = getenv("SICP_ACC_BATCH_PF"); return e ? atoi(e) : 4; }();  // tuning aid
-  switch (K) {
-    case 1: return pf == 8 ? (void*)accumulate_batch_kernel<1, 256, 8> : (void*)accumulate_batch_kernel<1, 256, 4>;
-    case 4: return pf == 8 ? (void*)accumulate_batch_kernel<4, 256, 8> : (void*)accumulate_batch_kernel<4, 256, 4>;
-    case 20: return pf == 8 ? (void*)accumulate_batch_kernel<20, 256, 8> : (void*)accumulate_batch_kernel<20, 256, 4>;
-    default: return nullptr;
-  }
-}
-
-static void batch_node_params(int K, const BatchArgs** arg, void** slot, int n, int max_nb, hipKernelNodeParams& acc, hipKernelNodeParams& step) {
-  slot[0] = (void*)arg;
-  memset(&acc, 0, sizeof acc);
-  acc.func = accumulate_batch_fn(K);
-  acc.gridDim = dim3(max_nb, n);
-  acc.blockDim = dim3(256);
-  acc.kernelParams = slot;
-  memset(&step, 0, sizeof step);
-  step.func = (void*)lm_step_batch_kernel;
-  step.gridDim = dim3(n);
-  step.blockDim = dim3(64);
-  step.kernelParams = slot;
-}
-
-void batch_graph_destroy(BatchGraph& g) {
-  if (g.exec) (void)hipGraphExecDestroy(g.exec);
-  if (g.graph) (void)hipGraphDestroy(g.graph);
-  g.exec = nullptr; g.graph = nullptr; g.len = 0;
-}
-
-hipError_t batch_graph_prepare(BatchGraph& g, int K, const BatchArgs* batch, int n, int max_nb, int len, int* built) {
-  *built = 0;
-  if (n <= 0 || max_nb <= 0 || len < 1 || len > kMaxBatchLen || !accumulate_batch_fn(K)) return hipErrorInvalidValue;
-  const BatchArgs* arg = batch;
-  void* slot[1];
-  hipKernelNodeParams pa, ps;
-  batch_node_params(K, &arg, slot, n, max_nb, pa, ps);
-  if (g.exec && g.K == K && g.len == len && g.batch == batch) {
-    if (g.n == n && g.max_nb == max_nb) return hipSuccess;
-    hipError_t e = hipSuccess;
-    for (int b = 0; b < len && e == hipSuccess; ++b) {
-      e = hipGraphExecKernelNodeSetParams(g.exec, g.acc[b], &pa);
-      if (e == hipSuccess) e = hipGraphExecKernelNodeSetParams(g.exec, g.step[b], &ps);
-    }
-    if (e == hipSuccess) { g.n = n; g.max_nb = max_nb; return hipSuccess; }
-    (void)hipGetLastError();  // fall through: rebuild
-  }
-  batch_graph_destroy(g);
-  hipError_t e = hipGraphCreate(&g.graph, 0);
-  if (e != hipSuccess) return e;
-  hipGraphNode_t prev = nullptr;
-  for (int b = 0; b < len; ++b) {
-    e = hipGraphAddKernelNode(&g.acc[b], g.graph, prev ? &prev : nullptr, prev ? 1 : 0, &pa);
-    if (e != hipSuccess) return e;
-    e = hipGraphAddKernelNode(&g.step[b], g.graph, &g.acc[b], 1, &ps);
-    if (e != hipSuccess) return e;
-    prev = g.step[b];
-  }
-  e = hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0);
-  if (e != hipSuccess) return e;
-  g.K = K; g.len = len; g.n = n; g.max_nb = max_nb; g.batch = batch;
-  *built = 1;
-  return hipSuccess;
-}
-
-hipError_t launch_lm_step_batch(const BatchArgs* batch, int n, hipStream_t st) {
-  if (n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(lm_step_batch_kernel, dim3(n), dim3(64), 0, st, batch);
-  return hipGetLastError();
-}
-
-hipError_t launch_finalize_batch(const BatchArgs* batch, int n, double* out28, hipStream_t st) {
-  if (n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(finalize_batch_kernel, dim3(n), dim3(64), 0, st, batch, out28);
-  return hipGetLastError();
-}
-
-// chained solve: a.lm = state in, a.lm_step = state out, a.partials_in / a.partials = previous / this
-// evaluation's partials (same grid for every launch of a solve)
-hipError_t launch_accumulate_chain(const AccArgs& a, hipStream_t st) {
-  const int nb = accumulate_blocks(a.n_s * a.K);
-  switch (a.K) {
-    case 1: hipLaunchKernelGGL((accumulate_chain_kernel<1, 256>), dim3(nb), dim3(256), 0, st, a); break;
-    case 4: hipLaunchKernelGGL((accumulate_chain_kernel<4, 256>), dim3(nb), dim3(256), 0, st, a); break;
-    case 20: hipLaunchKernelGGL((accumulate_chain_kernel<20, 256>), dim3(nb), dim3(256), 0, st, a); break;
-    default: return hipErrorInvalidValue;
-  }
-  return hipGetLastError();
-}
-
-// one LM evaluation as one kernel (a.lm, a.lm_step, a.ticket set)
-hipError_t launch_accumulate_fused(const AccArgs& a, hipStream_t st) {
-  const int nb = accumulate_blocks(a.n_s * a.K);
-  switch (a.K) {
-    case 1: hipLaunchKernelGGL((accumulate_kernel<1, 256, true>), dim3(nb), dim3(256), 0, st, a); break;
-    case 4: hipLaunchKernelGGL((accumulate_kernel<4, 256, true>), dim3(nb), dim3(256), 0, st, a); break;
-    case 20: hipLaunchKernelGGL((accumulate_kernel<20, 256, true>), dim3(nb), dim3(256), 0, st, a); break;
-    default: return hipErrorInvalidValue;
-  }
-  return hipGetLastError();
-}
-
 // test hook (sicp_se3_device): the SE(3) code of the device-resident solve, one lane per item
 __global__ __launch_bounds__(64) void se3_ops_kernel(int op, int n, const double* __restrict__ in, double* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -756,20 +576,127 @@ hipError_t launch_se3_ops(int op, int n, const double* in, double* out, hipStrea
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// launch wrappers
+// ------------------------------------------------------------------------------------------
+int accumulate_blocks(int total, int K) { return acc_geometry(total, K % 4 == 0 ? 4 : 2).n_chunks; }
+
 hipError_t launch_accumulate_kernel(const AccArgs& a, hipStream_t st) {
-  return launch_accumulate_only(a, accumulate_blocks(a.n_s * a.K), st);
+  const int nb = accumulate_blocks(a.n_s * a.K, a.K);
+#define SICP_ACC(KK) \
+  do { \
+    if (a.loss.use_sqloss) hipLaunchKernelGGL((accumulate_kernel<KK, true, 256>), dim3(nb), dim3(256), 0, st, a); \
+    else hipLaunchKernelGGL((accumulate_kernel<KK, false, 256>), dim3(nb), dim3(256), 0, st, a); \
+  } while (0)
+  switch (a.K) {
+    case 1: SICP_ACC(1); break;
+    case 4: SICP_ACC(4); break;
+    case 20: SICP_ACC(20); break;
+    default: return hipErrorInvalidValue;
+  }
+#undef SICP_ACC
+  return hipGetLastError();
+}
+
+// ---- the batched evaluation --------------------------------------------------------------------
+static void* accumulate_stream_fn(int K, int use_sqloss) {
+  switch (K) {
+    case 1: return use_sqloss ? (void*)accumulate_stream_kernel<1, true, 256> : (void*)accumulate_stream_kernel<1, false, 256>;
+    case 4: return use_sqloss ? (void*)accumulate_stream_kernel<4, true, 256> : (void*)accumulate_stream_kernel<4, false, 256>;
+    case 20: return use_sqloss ? (void*)accumulate_stream_kernel<20, true, 256> : (void*)accumulate_stream_kernel<20, false, 256>;
+    default: return nullptr;
+  }
+}
+
+int accumulate_stream_grid() {
+  // persistent workgroups: two per CU (two waves per SIMD).  SICP_ACC_GRID is a tuning aid.
+  static const int grid = [] {
+    const char* e = getenv("SICP_ACC_GRID");
+    if (e && atoi(e) > 0) return atoi(e);
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return 2 * (cus > 0 ? cus : 256);
+  }();
+  return grid;
+}
+
+static size_t stream_smem_bytes(int capacity) { return sizeof(double) * RED_ROWS * 256 + sizeof(PairCtx) * (size_t)capacity; }
+
+hipError_t launch_accumulate_batch(int K, int use_sqloss, const BatchHeader* hdr, const BatchArgs* batch, int capacity, hipStream_t st) {
+  void* fn = accumulate_stream_fn(K, use_sqloss);
+  if (!fn) return hipErrorInvalidValue;
+  void* args[] = {(void*)&hdr, (void*)&batch};
+  return hipLaunchKernel(fn, dim3(accumulate_stream_grid()), dim3(256), args, stream_smem_bytes(capacity), st);
+}
+
+hipError_t launch_lm_step_batch(const BatchHeader* hdr, const BatchArgs* batch, int capacity, hipStream_t st) {
+  if (capacity <= 0) return hipSuccess;
+  hipLaunchKernelGGL(lm_step_batch_kernel, dim3(capacity), dim3(64), 0, st, hdr, batch);
+  return hipGetLastError();
+}
+
+hipError_t launch_finalize_batch(const BatchArgs* batch, int n, double* out28, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(finalize_batch_kernel, dim3(n), dim3(64), 0, st, batch, out28);
+  return hipGetLastError();
+}
+
+// [accumulate_stream, lm_step_batch] x len as an instantiated graph with explicit kernel nodes.  Both
+// grids are fixed (persistent workgroups; one step block per slot of the batch buffers) and the
+// kernels read the number of active pairs / items from the header in HBM, so the graph only depends
+// on the buffers' addresses: it is built once per batch context.
+void batch_graph_destroy(BatchGraph& g) {
+  if (g.exec) (void)hipGraphExecDestroy(g.exec);
+  if (g.graph) (void)hipGraphDestroy(g.graph);
+  g.exec = nullptr; g.graph = nullptr; g.len = 0;
+}
+
+hipError_t batch_graph_prepare(BatchGraph& g, int K, int use_sqloss, const BatchHeader* hdr, const BatchArgs* batch, int capacity, int len,
+                               int* built) {
+  *built = 0;
+  void* fn = accumulate_stream_fn(K, use_sqloss);
+  if (capacity <= 0 || len < 1 || len > kMaxBatchLen || !fn) return hipErrorInvalidValue;
+  if (g.exec && g.K == K && g.sqloss == use_sqloss && g.len == len && g.batch == batch && g.hdr == hdr && g.capacity == capacity) return hipSuccess;
+  batch_graph_destroy(g);
+  void* args[] = {(void*)&hdr, (void*)&batch};
+  hipKernelNodeParams pa, ps;
+  memset(&pa, 0, sizeof pa);
+  pa.func = fn;
+  pa.gridDim = dim3(accumulate_stream_grid());
+  pa.blockDim = dim3(256);
+  pa.sharedMemBytes = (unsigned)stream_smem_bytes(capacity);
+  pa.kernelParams = args;
+  memset(&ps, 0, sizeof ps);
+  ps.func = (void*)lm_step_batch_kernel;
+  ps.gridDim = dim3(capacity);
+  ps.blockDim = dim3(64);
+  ps.kernelParams = args;
+  hipError_t e = hipGraphCreate(&g.graph, 0);
+  if (e != hipSuccess) return e;
+  hipGraphNode_t prev = nullptr, acc = nullptr, step = nullptr;
+  for (int b = 0; b < len; ++b) {
+    e = hipGraphAddKernelNode(&acc, g.graph, prev ? &prev : nullptr, prev ? 1 : 0, &pa);
+    if (e != hipSuccess) return e;
+    e = hipGraphAddKernelNode(&step, g.graph, &acc, 1, &ps);
+    if (e != hipSuccess) return e;
+    prev = step;
+  }
+  e = hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0);
+  if (e != hipSuccess) return e;
+  g.K = K; g.sqloss = use_sqloss; g.len = len; g.batch = batch; g.hdr = hdr; g.capacity = capacity;
+  *built = 1;
+  return hipSuccess;
 }
 
 hipError_t launch_finalize(const AccArgs& a, double* out28, hipStream_t st) {
-  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, st, a.partials, accumulate_blocks(a.n_s * a.K), out28);
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, st, a.partials, accumulate_blocks(a.n_s * a.K, a.K), out28);
   return hipGetLastError();
 }
 
 hipError_t launch_accumulate_lm(const AccArgs& a, LmState* lm, hipStream_t st) {
-  const int nb = accumulate_blocks(a.n_s * a.K);
-  hipError_t e = launch_accumulate_only(a, nb, st);
+  hipError_t e = launch_accumulate_kernel(a, st);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(lm_step_kernel, dim3(1), dim3(64), 0, st, lm, a.partials, nb);
+  hipLaunchKernelGGL(lm_step_kernel, dim3(1), dim3(64), 0, st, lm, a.partials, accumulate_blocks(a.n_s * a.K, a.K));
   return hipGetLastError();
 }
 

@@ -64,7 +64,7 @@ def nn(request):
     return request.param
 
 
-@pytest.fixture(params=[0, 1, 2, 3], ids=["hostlm", "devicelm", "fusedlm", "chainlm"])
+@pytest.fixture(params=[0, 1], ids=["hostlm", "devicelm"])
 def lm(request):
     """Host-loop and device-resident inner solve run the same LM machine (csrc/lm.hpp)."""
     return request.param
