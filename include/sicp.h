@@ -142,9 +142,9 @@ typedef struct sicp_stats {
   double weight_kernel_ms;  /* EM weight kernel launches                             */
   double acc_kernel_ms;     /* accumulate + finalize pairs                           */
   int32_t cov_launches, nn_launches, weight_launches, acc_launches; /* timed launches */
-  /* lock-step batches (sicp_align_batch): LM evaluation launches this pair was part of,
-   * including those it sat through after its own inner solve had finished (idle slots =
-   * lockstep_slots - total_evals); 0 for a lone sicp_align */
+  /* LM evaluation launches this pair was part of (ticks of lm_batch evaluations, one graph launch
+   * each, shared by all pairs of a sicp_align_batch), including the tail of a tick it sat through
+   * after its own inner solve had finished: idle slots = lockstep_slots - total_evals */
   int32_t lockstep_slots;
   int32_t graph_builds;     /* hipGraph instantiations during this align (leader handle of a batch) */
 } sicp_stats;

@@ -877,11 +877,16 @@ static double gradient_max_norm(const double x[7], const double g[6]) {
   return m;
 }
 
-int orc_solve(const orc_params* p, int n_s, const float* sx, const float* sy, const float* sz,
+/* trace of the trust-region loop, one record per step attempt (tests compare it with an independently
+ * written loop, tests/lm_ref.py): cost at the accepted iterate before the step, radius used for the
+ * step, candidate cost, and whether the step was accepted (1), rejected (0) or invalid (-1) */
+typedef struct { int max, n; double *cost, *radius, *cand_cost; int* accepted; } lm_trace;
+
+static int solve_impl(const orc_params* p, int n_s, const float* sx, const float* sy, const float* sz,
               const double* scov9, const float* tx, const float* ty, const float* tz,
               const double* tcov9, int K, const int* idx, const double* w,
               const double init_qt[7], double out_qt[7], int* lm_iters, int* evals,
-              double* final_cost) {
+              double* final_cost, lm_trace* tr) {
   double x[7], o[28], H[36], g[6], cost;
   memcpy(x, init_qt, sizeof x);
   int n_eval = 0, iter = 0, status = 0;
@@ -932,6 +937,7 @@ int orc_solve(const orc_params* p, int n_s, const float* sx, const float* sy, co
       model_change = -(sg + 0.5 * sHs);
     }
     if (!ok || !(model_change > 0.0)) {
+      if (tr && tr->n < tr->max) { tr->cost[tr->n] = cost; tr->radius[tr->n] = radius; tr->cand_cost[tr->n] = cost; tr->accepted[tr->n] = -1; tr->n++; }
       if (++invalid >= p->max_consecutive_invalid_steps) { status = 2; break; }
       radius *= 0.5;
       reuse_diagonal = 1;
@@ -944,6 +950,7 @@ int orc_solve(const orc_params* p, int n_s, const float* sx, const float* sy, co
     accumulate_mt(p, cand, n_s, sx, sy, sz, scov9, tx, ty, tz, tcov9, K, idx, w, 0, oc);
     n_eval++;
     double cand_cost = oc[27];
+    if (tr && tr->n < tr->max) { tr->cost[tr->n] = cost; tr->radius[tr->n] = radius; tr->cand_cost[tr->n] = cand_cost; tr->accepted[tr->n] = 0; tr->n++; }
     double diff[7];
     for (int i = 0; i < 7; i++) diff[i] = x[i] - cand[i];
     double step_norm = norm7(diff);
@@ -952,6 +959,7 @@ int orc_solve(const orc_params* p, int n_s, const float* sx, const float* sy, co
     if (fabs(cost_change) <= p->function_tolerance * cost) break;
     double rel = cost_change / model_change;
     if (rel > p->min_relative_decrease) {
+      if (tr && tr->n > 0) tr->accepted[tr->n - 1] = 1;
       memcpy(x, cand, sizeof x);
       x_norm = norm7(x);
       accumulate_mt(p, x, n_s, sx, sy, sz, scov9, tx, ty, tz, tcov9, K, idx, w, 1, o);
@@ -975,6 +983,27 @@ int orc_solve(const orc_params* p, int n_s, const float* sx, const float* sy, co
   if (evals) *evals = n_eval;
   if (final_cost) *final_cost = cost;
   return status;
+}
+
+int orc_solve(const orc_params* p, int n_s, const float* sx, const float* sy, const float* sz,
+              const double* scov9, const float* tx, const float* ty, const float* tz,
+              const double* tcov9, int K, const int* idx, const double* w,
+              const double init_qt[7], double out_qt[7], int* lm_iters, int* evals,
+              double* final_cost) {
+  return solve_impl(p, n_s, sx, sy, sz, scov9, tx, ty, tz, tcov9, K, idx, w, init_qt, out_qt, lm_iters, evals, final_cost, NULL);
+}
+
+int orc_solve_trace(const orc_params* p, int n_s, const float* sx, const float* sy, const float* sz,
+                    const double* scov9, const float* tx, const float* ty, const float* tz,
+                    const double* tcov9, int K, const int* idx, const double* w,
+                    const double init_qt[7], double out_qt[7], int max_trace, double* trace_cost,
+                    double* trace_radius, double* trace_cand_cost, int* trace_accepted, int* n_trace) {
+  lm_trace tr = {max_trace, 0, trace_cost, trace_radius, trace_cand_cost, trace_accepted};
+  int it = 0, ev = 0;
+  double fc = 0;
+  int st = solve_impl(p, n_s, sx, sy, sz, scov9, tx, ty, tz, tcov9, K, idx, w, init_qt, out_qt, &it, &ev, &fc, &tr);
+  *n_trace = tr.n;
+  return st;
 }
 
 /* ------------------------------------------------------------------------- */

@@ -169,6 +169,13 @@ int orc_solve(const orc_params* p, int n_s, const float* sx, const float* sy, co
               const double* tcov9, int K, const int* idx, const double* w,
               const double init_qt[7], double out_qt[7], int* lm_iters, int* evals,
               double* final_cost);
+/* the same solve, recording every step attempt: cost before the step, trust-region radius of the
+ * step, candidate cost, accepted (1) / rejected (0) / invalid (-1) */
+int orc_solve_trace(const orc_params* p, int n_s, const float* sx, const float* sy, const float* sz,
+                    const double* scov9, const float* tx, const float* ty, const float* tz,
+                    const double* tcov9, int K, const int* idx, const double* w,
+                    const double init_qt[7], double out_qt[7], int max_trace, double* trace_cost,
+                    double* trace_radius, double* trace_cand_cost, int* trace_accepted, int* n_trace);
 
 #ifdef __cplusplus
 }

@@ -107,8 +107,9 @@ __device__ __forceinline__ void cov_body(const CovArgs& a) {
   double nz = col == 0 ? V[2][0] : (col == 1 ? V[2][1] : V[2][2]);
   {
     PointRec r;
-    r.x = a.x[i]; r.y = a.y[i]; r.z = a.z[i]; r.pad0 = 0u;
-    r.nx = nx; r.ny = ny; r.nz = nz; r.pad1 = 0.0;
+    r.x = a.x[i]; r.y = a.y[i]; r.z = a.z[i];
+    r.nx = nx; r.ny = ny; r.nz = nz;
+    r.pad_[0] = r.pad_[1] = r.pad_[2] = 0u;
     a.rec[i] = r;
   }
   if (a.hist) {

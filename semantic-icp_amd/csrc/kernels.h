@@ -25,12 +25,15 @@ struct Mat4f {
 
 // One point as the weight / accumulate kernels gather it: position (the float32 the search ran on) and
 // the unit normal of its k-neighbourhood in double (its covariance is I - (1-eps) n n^T), 48 bytes =
-// three 16-byte loads instead of one load from each of six arrays.  Written by cov_kernel.
+// three loads instead of one load from each of six arrays.  Written by cov_kernel.
+// Field order: the batched accumulate kernel moves a record into LDS with three LDS-DMA loads of
+// 16 + 16 + 4 bytes (the 36 bytes that carry data).
 struct alignas(16) PointRec {
-  float x, y, z;
-  uint32_t pad0;
-  double nx, ny, nz;
-  double pad1;
+  double nx, ny;
+  double nz;
+  float x, y;
+  float z;
+  uint32_t pad_[3];
 };
 static_assert(sizeof(PointRec) == 48, "PointRec is read with three dwordx4 / dwordx2 loads");
 
@@ -218,10 +221,6 @@ hipError_t launch_proj_jobs(const ProjArgs* jobs, int n, hipStream_t st);
 hipError_t launch_em_weight_jobs(const WeightArgs* jobs, int n, hipStream_t st);
 hipError_t launch_count_active_jobs(const CountJob* jobs, int n, hipStream_t st);
 int accumulate_blocks(int total, int K);  // chunks of a pair with `total` slots, K correspondences per source point
-hipError_t launch_accumulate_kernel(const AccArgs& a, hipStream_t st);
-hipError_t launch_finalize(const AccArgs& a, double* out28, hipStream_t st);
-// one evaluation of the device-resident solve: accumulate at lm->pose, then feed the LM machine
-hipError_t launch_accumulate_lm(const AccArgs& a, LmState* lm, hipStream_t st);
 // every pair of the batch in one launch: hdr / batch in HBM, capacity = slots of the batch buffers
 hipError_t launch_accumulate_batch(int K, int use_sqloss, const BatchHeader* hdr, const BatchArgs* batch, int capacity, hipStream_t st);
 hipError_t launch_lm_step_batch(const BatchHeader* hdr, const BatchArgs* batch, int capacity, hipStream_t st);

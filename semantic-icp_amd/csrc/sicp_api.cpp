@@ -220,9 +220,6 @@ struct sicp_context {
   DevBuf<sicp::LmState> d_lm;
   // one batch of the device-resident solve ([accumulate, lm_step] x lm_batch) captured as a graph:
   // a single launch call per batch instead of 2 x lm_batch trips through the runtime's launch path
-  hipGraphExec_t lm_graph = nullptr;
-  sicp::AccArgs lm_graph_args;
-  int lm_graph_batch = 0;
   sicp::LmState* h_lm = nullptr;  // pinned mirror of the device-resident LM state
   double* h_out28 = nullptr;      // pinned, 28 doubles
   long long* h_count = nullptr;   // pinned
@@ -669,23 +666,36 @@ void fill_acc(sicp_context* h, sicp::AccArgs& a) {
   a.partials = h->partials.p;
 }
 
+constexpr int kMaxActivePairs = 128;  // per-pair constants of the batched kernel live in LDS
+int batch_reserve(sicp_context* h, int n);
+int run_tick(sicp_context* h, hipStream_t M, sicp_handle* hs, int n, const std::vector<int>& act, const std::vector<int>& joining,
+             const double (*start)[7], int len);
+
+// One evaluation sweep at pose qt: the batched kernel on a batch of one (every path -- a pair alone, a
+// lock-step batch, the host-loop solve, this hook -- runs the SAME accumulate kernel, so they agree bit
+// for bit), then the fixed-order sum of the chunk partials.
 int eval28(sicp_context* h, const double* qt, double* out28) {
+  SICPCHECK(batch_reserve(h, 1));
   const int nb = sicp::accumulate_blocks(h->corr_n * h->corr_K, h->corr_K);
   HIPCHECK(h->partials.reserve((size_t)nb * 28));
-  HIPCHECK(h->out28.reserve(28));
-  sicp::AccArgs a;
-  fill_acc(h, a);
-  fill_pose(qt, a.pose);
+  sicp::BatchArgs& B = h->h_batch[0];
+  std::memset(&B, 0, sizeof B);
+  fill_acc(h, B.a);
+  fill_pose(qt, B.a.pose);
+  B.nb = nb; B.item_begin = 0;
+  h->h_bhdr->n_pairs = 1; h->h_bhdr->n_items = nb; h->h_bhdr->pad_[0] = h->h_bhdr->pad_[1] = 0;
+  HIPCHECK(hipMemcpyAsync(h->d_bhdr.p, h->h_bhdr, sizeof(sicp::BatchHeader), hipMemcpyHostToDevice, h->stream));
+  HIPCHECK(hipMemcpyAsync(h->d_batch.p, h->h_batch, sizeof(sicp::BatchArgs), hipMemcpyHostToDevice, h->stream));
   {
     KernelTimer kt(h, SICP_PROFILE_ACC);  // the accumulate kernel alone
-    HIPCHECK(sicp::launch_accumulate_kernel(a, h->stream));
+    HIPCHECK(sicp::launch_accumulate_batch(h->corr_K, h->params.use_sqloss, h->d_bhdr.p, h->d_batch.p, std::min(h->h_batch_cap, kMaxActivePairs), h->stream));
     h->st.acc_launches += 1;
     h->st.acc_kernel_ms += kt.stop();
   }
-  HIPCHECK(sicp::launch_finalize(a, h->out28.p, h->stream));
-  HIPCHECK(hipMemcpyAsync(h->h_out28, h->out28.p, sizeof(double) * 28, hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(sicp::launch_finalize_batch(h->d_batch.p, 1, h->d_bout28.p, h->stream));
+  HIPCHECK(hipMemcpyAsync(h->h_bout28, h->d_bout28.p, sizeof(double) * 28, hipMemcpyDeviceToHost, h->stream));
   HIPCHECK(hipStreamSynchronize(h->stream));
-  std::memcpy(out28, h->h_out28, sizeof(double) * 28);
+  std::memcpy(out28, h->h_bout28, sizeof(double) * 28);
   h->st.total_evals++;
   return SICP_OK;
 }
@@ -728,57 +738,22 @@ int run_solve(sicp_context* h, const double* init_qt, double* out_qt, SolveResul
     res->status = s.status; res->iterations = s.iterations; res->evaluations = s.evaluations; res->cost = s.cost;
     return SICP_OK;
   }
-  // device-resident: the trust-region state stays in HBM; every evaluation is an accumulate kernel
-  // followed by a one-wave kernel that feeds the same LM machine; the host polls the status once
-  // per batch.  Launches queued behind a finished solve exit at their first instruction.
-  // (Round 1 also carried a form with the step fused into the accumulate kernel's last block and a
-  // chained form; neither measured faster and both are gone: lm_on_device > 1 means 1.)
-  const int nb = sicp::accumulate_blocks(h->corr_n * h->corr_K, h->corr_K);
-  const int batch = std::min(P.lm_batch > 0 ? P.lm_batch : 12, sicp::kMaxBatchLen);
-  HIPCHECK(h->partials.reserve((size_t)nb * 28));
-  HIPCHECK(h->d_lm.reserve(1));
-  sicp::lm_init(*h->h_lm, lm_options(P), init_qt);
-  HIPCHECK(hipMemcpyAsync(h->d_lm.p, h->h_lm, sizeof(sicp::LmState), hipMemcpyHostToDevice, h->stream));
-  sicp::AccArgs a;
-  std::memset(&a, 0, sizeof a);  // padding bytes take part in the graph-cache comparison
-  fill_acc(h, a);
-  a.lm = h->d_lm.p;
-  if (!h->lm_graph || h->lm_graph_batch != batch || std::memcmp(&h->lm_graph_args, &a, sizeof a) != 0) {
-    // (re)capture: the arguments only change when a buffer was reallocated or the mode changed
-    if (h->lm_graph) { (void)hipGraphExecDestroy(h->lm_graph); h->lm_graph = nullptr; }
-    hipGraph_t g = nullptr;
-    HIPCHECK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-    hipError_t ce = hipSuccess;
-    for (int b = 0; b < batch && ce == hipSuccess; ++b) ce = sicp::launch_accumulate_lm(a, h->d_lm.p, h->stream);
-    hipError_t ee = hipStreamEndCapture(h->stream, &g);
-    HIPCHECK(ce);
-    HIPCHECK(ee);
-    hipError_t ie = hipGraphInstantiate(&h->lm_graph, g, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(g);
-    HIPCHECK(ie);
-    h->st.graph_builds += 1;
-    std::memcpy(&h->lm_graph_args, &a, sizeof a);
-    h->lm_graph_batch = batch;
-  }
-  static const bool dbg_timing = std::getenv("SICP_DEBUG_TIMING") != nullptr;  // developer aid
-  double t_launch = 0, t_copy = 0, t_sync = 0; int n_batches = 0;
+  // device-resident: the trust-region state stays in HBM; ticks of lm_batch evaluations (accumulate
+  // kernel + one-wave LM step each) as ONE graph launch; the host looks at the state once per tick.
+  // The very machinery of sicp_align_batch, with a batch of one.
+  SICPCHECK(batch_reserve(h, 1));
+  const int len = std::min(P.lm_batch > 0 ? P.lm_batch : 12, sicp::kMaxBatchLen);
+  sicp_handle self = h;
+  double start[1][7];
+  std::memcpy(start[0], init_qt, sizeof start[0]);
+  std::vector<int> act(1, 0), joining(1, 0);
   for (;;) {
-    KernelTimer kt(h, SICP_PROFILE_ACC);
-    const double ta = dbg_timing ? now_ms() : 0;
-    HIPCHECK(hipGraphLaunch(h->lm_graph, h->stream));
-    const double tb = dbg_timing ? now_ms() : 0;
-    h->st.acc_launches += batch;
-    h->st.acc_kernel_ms += kt.stop();
-    HIPCHECK(hipMemcpyAsync(h->h_lm, h->d_lm.p, sizeof(sicp::LmState), hipMemcpyDeviceToHost, h->stream));
-    const double tc = dbg_timing ? now_ms() : 0;
-    HIPCHECK(hipStreamSynchronize(h->stream));
-    if (dbg_timing) { const double td = now_ms(); t_launch += tb - ta; t_copy += tc - tb; t_sync += td - tc; ++n_batches; }
-    if (h->h_lm->status != sicp::LM_RUNNING) break;
+    SICPCHECK(run_tick(h, h->stream, &self, 1, act, joining, start, len));
+    joining.clear();
+    h->st.acc_launches += len;
+    if (h->h_bstates[0].status != sicp::LM_RUNNING) break;
   }
-  if (dbg_timing)
-    std::fprintf(stderr, "[sicp solve] batches %d: graph launch %.1f us, copy enqueue %.1f us, sync wait %.1f us (per batch)\n", n_batches,
-                 1e3 * t_launch / n_batches, 1e3 * t_copy / n_batches, 1e3 * t_sync / n_batches);
-  const sicp::LmState& s = *h->h_lm;
+  const sicp::LmState& s = h->h_bstates[0];
   std::memcpy(out_qt, s.x, sizeof s.x);
   res->status = s.status; res->iterations = s.iterations; res->evaluations = s.evaluations; res->cost = s.cost;
   h->st.total_evals += s.evaluations;
@@ -962,12 +937,10 @@ struct BatchGuard {
 // advances every pair's trust-region machine (csrc/lm.hpp, the same code and the same bits as the
 // single-pair solve).  `joining` pairs start their inner solve with this tick (their LM state is
 // initialised and uploaded first).  On return h_bstates holds every pair's state.
-constexpr int kMaxActivePairs = 128;  // per-pair constants of the batched kernel live in LDS
-
 int run_tick(sicp_context* h, hipStream_t M, sicp_handle* hs, int n, const std::vector<int>& act, const std::vector<int>& joining,
-             const OuterState* o, int len) {
+             const double (*start)[7], int len) {
   for (int p : joining) {
-    sicp::lm_init(h->h_bstates[p], lm_options(hs[p]->params), o[p].est);
+    sicp::lm_init(h->h_bstates[p], lm_options(hs[p]->params), start[p]);
     HIPCHECK(hipMemcpyAsync(h->d_bstates.p + p, h->h_bstates + p, sizeof(sicp::LmState), hipMemcpyHostToDevice, M));
   }
   int n_items = 0, k = 0;
@@ -991,7 +964,7 @@ int run_tick(sicp_context* h, hipStream_t M, sicp_handle* hs, int n, const std::
   // context (buffer addresses) and never touched when pairs come and go or batches differ in size.
   {
     int built = 0;
-    HIPCHECK(sicp::batch_graph_prepare(h->b_graph, hs[0]->params.knn, h->params.use_sqloss, h->d_bhdr.p, h->d_batch.p,
+    HIPCHECK(sicp::batch_graph_prepare(h->b_graph, hs[act[0]]->corr_K, h->params.use_sqloss, h->d_bhdr.p, h->d_batch.p,
                                        std::min(h->h_batch_cap, kMaxActivePairs), len, &built));
     h->st.graph_builds += built;
   }
@@ -1125,7 +1098,6 @@ int sicp_destroy(sicp_handle h) {
   sicp::batch_graph_destroy(h->b_graph);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
-  if (h->lm_graph) (void)hipGraphExecDestroy(h->lm_graph);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->side_done) (void)hipEventDestroy(h->side_done);
   if (h->main_done) (void)hipEventDestroy(h->main_done);
@@ -1259,6 +1231,8 @@ int sicp_align(sicp_handle h, const double init_qt[7], double out_qt[7], int32_t
   SICPCHECK(set_device(h));
   SICPCHECK(check_ready(h, false));
   const sicp_params& P = h->params;
+  // device-resident solve: a lock-step batch of one (the same kernels, hence the same bits, as any batch)
+  if (P.lm_on_device) return sicp_align_batch(&h, 1, init_qt, out_qt, outer_iters, stats);
   const double t_begin = now_ms();
   h->epoch = next_epoch();
   SICPCHECK(align_begin(h, stats != nullptr));
@@ -1361,6 +1335,8 @@ int sicp_align_batch(sicp_handle* hs, int32_t n, const double* init_qt, double* 
     HIPCHECK(hipStreamWaitEvent(side, h->main_done, 0));
   }
   if (one_launch) guard.retarget(side);
+  struct Start { double q[7]; };
+  std::vector<Start> starts(n);
   std::vector<int> act, joining, finished, search_round(n, 0);
   int n_done = 0, round = 0;
   while (n_done < n) {
@@ -1409,7 +1385,8 @@ int sicp_align_batch(sicp_handle* hs, int32_t n, const double* init_qt, double* 
     for (int p : joining) phase[p] = SOLVING;
     const double t0 = now_ms();
     {
-      int rc = run_tick(h, M, hs, n, act, joining, o.data(), len);
+      for (int p : joining) std::memcpy(starts[p].q, o[p].est, sizeof starts[p].q);
+      int rc = run_tick(h, M, hs, n, act, joining, reinterpret_cast<const double(*)[7]>(starts.data()), len);
       if (rc != SICP_OK) return rc;
     }
     const double dt = now_ms() - t0;

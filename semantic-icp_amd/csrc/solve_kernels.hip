@@ -223,12 +223,15 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v2i __attribute__((ext_vector_type(2)));
 
+struct RecMid { double nz; float x, y; };
 __device__ __forceinline__ void load_rec(const SICP_GLOBAL PointRec* r, float& x, float& y, float& z, double& nx, double& ny, double& nz) {
   const SICP_GLOBAL char* p = (const SICP_GLOBAL char*)r;
-  const v4f a = *(const SICP_GLOBAL v4f*)p;          // x y z .
-  const v2d b = *(const SICP_GLOBAL v2d*)(p + 16);   // nx ny
-  const double c = *(const SICP_GLOBAL double*)(p + 32);
-  x = a.x; y = a.y; z = a.z; nx = b.x; ny = b.y; nz = c;
+  const v2d a = *(const SICP_GLOBAL v2d*)p;          // nx ny
+  const v4f b = *(const SICP_GLOBAL v4f*)(p + 16);   // nz (two floats) x y
+  const float c = *(const SICP_GLOBAL float*)(p + 32);
+  nx = a.x; ny = a.y;
+  nz = __hiloint2double(__float_as_int(b.y), __float_as_int(b.x));
+  x = b.z; y = b.w; z = c;
 }
 
 // the indices of group g (issued one pipeline stage before the gathers that need their values)
@@ -248,6 +251,30 @@ __device__ __forceinline__ void load_idx(const LoadCtx& L, int g, int (&j)[Group
 #pragma unroll
     for (int c = 0; c < SG; ++c) j[c] = e0 + c < L.total ? L.idx[e0 + c] : -1;  // ragged tail / past the end: weight 0
   }
+}
+
+// Unconditional form for the pipelined kernel: always one vector load (from the last group when g lies
+// past the end; the index buffer is allocated with slack, so the SG - 1 entries a ragged last group
+// reads beyond `total` exist), and the "past the end -> -1" fix-up is applied where the values are
+// consumed (fix_idx) -- a select here would be a use of the load and make the compiler wait for it.
+template <int K>
+__device__ __forceinline__ void load_idx_raw(const LoadCtx& L, int g, int (&j)[GroupShape<K>::SG]) {
+  constexpr int SG = GroupShape<K>::SG;
+  const int last = ((L.total - 1) / SG) * SG;
+  const int e0 = max(min(g * SG, last), 0);
+  if (SG == 4) {
+    const v4i v = *(const SICP_GLOBAL v4i*)(L.idx + e0);
+    j[0] = v.x; j[1] = v.y; j[SG - 2] = v.z; j[SG - 1] = v.w;
+  } else {
+    const v2i v = *(const SICP_GLOBAL v2i*)(L.idx + e0);
+    j[0] = v.x; j[SG - 1] = v.y;
+  }
+}
+template <int K>
+__device__ __forceinline__ void fix_idx(int total, int g, int (&j)[GroupShape<K>::SG]) {
+  constexpr int SG = GroupShape<K>::SG;
+#pragma unroll
+  for (int c = 0; c < SG; ++c) j[c] = g * SG + c < total ? j[c] : -1;
 }
 
 template <int K>
@@ -333,42 +360,6 @@ __device__ __forceinline__ void load_ctx_from_args(const AccArgs& a, LoadCtx& L,
   M.loss_c = 1.0 / M.loss_b;
 }
 
-// One pair alone: one workgroup per chunk.  The loads of a lane's two groups share the memory
-// latency (both are in flight before the first is computed).
-template <int K, bool SQLOSS, int BS>
-__global__ __launch_bounds__(BS) void accumulate_kernel(AccArgs a) {
-  __shared__ double red[RED_ROWS][BS];
-  LoadCtx L;
-  MathCtx M;
-  if (a.lm) {
-    // device-resident solve: the pose to evaluate lives in the LM state; once the solve has
-    // finished, the launches still queued behind it do nothing (uniform exit)
-    if (a.lm->status != LM_RUNNING) return;
-    se3::rotation(a.lm->pose, M.P.R);
-    M.P.t[0] = a.lm->pose[4]; M.P.t[1] = a.lm->pose[5]; M.P.t[2] = a.lm->pose[6];
-  } else {
-    M.P = a.pose;
-  }
-  pose_to_sgprs(M.P);
-  load_ctx_from_args(a, L, M);
-  const AccGeometry geo = acc_geometry(L.total, GroupShape<K>::SG);
-  const int chunk = (int)blockIdx.x;
-  const int g0 = chunk * geo.chunk_groups + (int)threadIdx.x;
-  double acc[28];
-#pragma unroll
-  for (int k = 0; k < 28; ++k) acc[k] = 0.0;
-  for (int s = 0; s < 2 * geo.m; s += 2) {
-    Group<K> A, B;
-    load_idx<K>(L, g0 + s * BS, A.j);
-    load_idx<K>(L, g0 + (s + 1) * BS, B.j);
-    load_data<K>(L, g0 + s * BS, A);
-    load_data<K>(L, g0 + (s + 1) * BS, B);
-    compute_group<K, SQLOSS>(M, A, acc);
-    compute_group<K, SQLOSS>(M, B, acc);
-  }
-  block_reduce_store<BS>(acc, red, (SICP_GLOBAL double*)a.partials, geo.n_chunks, chunk);
-}
-
 // ------------------------------------------------------------------------------------------
 // Lock-step batch (sicp_align_batch): ONE launch evaluates the current LM pose of every pair that
 // still iterates.  Persistent workgroups (2 per CU) walk over the flattened list of (pair, chunk)
@@ -386,14 +377,9 @@ struct PairCtx {
   double one_m_eps, loss_b, loss_c;
 };
 
-template <int K, bool SQLOSS, int BS>
-__global__ __launch_bounds__(BS, 2) void accumulate_stream_kernel(const BatchHeader* __restrict__ hdr, const BatchArgs* __restrict__ batch) {
-  extern __shared__ double smem[];
-  double (&red)[RED_ROWS][BS] = *reinterpret_cast<double (*)[RED_ROWS][BS]>(smem);
-  PairCtx* ctx = reinterpret_cast<PairCtx*>(smem + RED_ROWS * BS);
-  const int n_pairs = hdr->n_pairs, n_items = hdr->n_items;
-  if ((int)blockIdx.x >= n_items) return;
-  // ---- stage the per-pair constants (lane p: pair p)
+// the per-pair constants of a batched launch -> LDS (lane p: pair p)
+template <int K, int BS>
+__device__ __forceinline__ void stage_pair_constants(const BatchArgs* __restrict__ batch, int n_pairs, PairCtx* ctx) {
   for (int p = threadIdx.x; p < n_pairs; p += BS) {
     const BatchArgs& B = batch[p];
     const AccArgs& a = B.a;
@@ -422,6 +408,16 @@ __global__ __launch_bounds__(BS, 2) void accumulate_stream_kernel(const BatchHea
     c.loss_c = 1.0 / c.loss_b;
     ctx[p] = c;
   }
+}
+
+template <int K, bool SQLOSS, int BS>
+__global__ __launch_bounds__(BS, 2) void accumulate_stream_kernel(const BatchHeader* __restrict__ hdr, const BatchArgs* __restrict__ batch) {
+  extern __shared__ double smem[];
+  double (&red)[RED_ROWS][BS] = *reinterpret_cast<double (*)[RED_ROWS][BS]>(smem);
+  PairCtx* ctx = reinterpret_cast<PairCtx*>(smem + RED_ROWS * BS);
+  const int n_pairs = hdr->n_pairs, n_items = hdr->n_items;
+  if ((int)blockIdx.x >= n_items) return;
+  stage_pair_constants<K, BS>(batch, n_pairs, ctx);
   __syncthreads();
 
   const int G = (int)gridDim.x;
@@ -471,6 +467,237 @@ __global__ __launch_bounds__(BS, 2) void accumulate_stream_kernel(const BatchHea
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// The same walk, software pipelined through LDS.  At two waves per SIMD plain wave interleaving
+// hides about half of an index -> gather chain, and a second register set for the next group does
+// not fit beside the 28 accumulators.  So the next group's TARGET records (the 36 gathered bytes x SG
+// per lane) are fetched by LDS-DMA (global_load_lds: no destination registers) into a wave-private
+// staging area while the current group is computed from registers; only the next group's indices,
+// weights and source record travel through registers.  Per lane and step:
+//     wait for everything issued a step ago | staging area -> registers | issue: LDS-DMA of group
+//     t+1's targets, loads of its weights / source, indices of group t+2 | compute group t
+// The chunk-end reduction uses raw s_barrier + lgkmcnt waits, so the DMA stays in flight across it.
+// ------------------------------------------------------------------------------------------
+#define SICP_LDS __attribute__((address_space(3)))
+constexpr int STAGE_SLOT_BYTES = 64 * 36;  // one target record of every lane of a wave: 1024 + 1024 + 256
+
+__device__ __forceinline__ void lds_dma_rec(const SICP_GLOBAL PointRec* r, SICP_LDS char* slot) {
+  const SICP_GLOBAL char* p = (const SICP_GLOBAL char*)r;
+  __builtin_amdgcn_global_load_lds((const SICP_GLOBAL void*)p, (SICP_LDS void*)slot, 16, 0, 0);
+  __builtin_amdgcn_global_load_lds((const SICP_GLOBAL void*)(p + 16), (SICP_LDS void*)(slot + 1024), 16, 0, 0);
+  __builtin_amdgcn_global_load_lds((const SICP_GLOBAL void*)(p + 32), (SICP_LDS void*)(slot + 2048), 4, 0, 0);
+}
+
+__device__ __forceinline__ void lds_read_rec(const SICP_LDS char* slot, int lane, float& x, float& y, float& z, double& nx, double& ny, double& nz) {
+  const v2d a = *(const SICP_LDS v2d*)(slot + 16 * lane);
+  const v4f b = *(const SICP_LDS v4f*)(slot + 1024 + 16 * lane);
+  const float c = *(const SICP_LDS float*)(slot + 2048 + 4 * lane);
+  nx = a.x; ny = a.y;
+  nz = __hiloint2double(__float_as_int(b.y), __float_as_int(b.x));
+  x = b.z; y = b.w; z = c;
+}
+
+// the part of a group that travels through registers
+template <int K>
+struct GroupRegs {
+  static constexpr int SG = GroupShape<K>::SG, NS = GroupShape<K>::NS;
+  int j[SG];
+  double w[SG];
+  float sx[NS], sy[NS], sz[NS];
+  double snx[NS], sny[NS], snz[NS];
+};
+
+template <int K>
+__device__ __forceinline__ void load_regs(const LoadCtx& L, int g, GroupRegs<K>& G) {
+  constexpr int SG = GroupShape<K>::SG, NS = GroupShape<K>::NS;
+  const int e0 = g * SG;
+#pragma unroll
+  for (int c = 0; c < SG; ++c) G.w[c] = L.w ? L.w[max(min(e0 + c, L.total - 1), 0)] : 1.0;
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int i = max(min((e0 + s * (SG / NS)) / K, L.n_s - 1), 0);
+    load_rec(L.srec + i, G.sx[s], G.sy[s], G.sz[s], G.snx[s], G.sny[s], G.snz[s]);
+  }
+}
+
+// block reduction with raw barriers (a __syncthreads would drain the LDS-DMA queue)
+template <int BS>
+__device__ __forceinline__ void block_reduce_store_raw(const double (&acc)[28], double (&red)[RED_ROWS][BS], SICP_GLOBAL double* partials,
+                                                       int n_chunks, int chunk) {
+  constexpr int NW = BS / 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int p0 = 0; p0 < 28; p0 += RED_ROWS) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int k = 0; k < RED_ROWS; ++k) red[k][threadIdx.x] = acc[p0 + k];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int kk = wave; kk < RED_ROWS; kk += NW) {
+      double sum = 0.0;
+#pragma unroll
+      for (int t = 0; t < NW; ++t) sum += red[kk][lane + 64 * t];
+      sum = wave_sum(sum);
+      if (lane == 0) partials[(size_t)(p0 + kk) * n_chunks + chunk] = sum;
+    }
+  }
+}
+
+// position of a workgroup's walk: item (workgroup-uniform), sub-group s inside the chunk
+struct Cursor {
+  int item, s, pair, chunk, two_m;
+  bool valid;
+};
+
+template <int K, bool SQLOSS, int BS>
+__global__ __launch_bounds__(BS, 2) void accumulate_staged_kernel(const BatchHeader* __restrict__ hdr, const BatchArgs* __restrict__ batch) {
+  constexpr int SG = GroupShape<K>::SG, NS = GroupShape<K>::NS, NW = BS / 64;
+  extern __shared__ double smem[];  // ONE shared object: [reduction rows | staging | per-pair constants]
+  double (&red)[RED_ROWS][BS] = *reinterpret_cast<double (*)[RED_ROWS][BS]>(smem);
+  char* stage_all = reinterpret_cast<char*>(smem + RED_ROWS * BS);
+  PairCtx* ctx = reinterpret_cast<PairCtx*>(stage_all + NW * SG * STAGE_SLOT_BYTES);
+  const int n_pairs = hdr->n_pairs, n_items = hdr->n_items;
+  if ((int)blockIdx.x >= n_items) return;
+  stage_pair_constants<K, BS>(batch, n_pairs, ctx);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = uniform_i32((int)(threadIdx.x >> 6));
+  SICP_LDS char* stage = (SICP_LDS char*)stage_all + wave * (SG * STAGE_SLOT_BYTES);
+
+  const int G = (int)gridDim.x;
+  auto locate = [&](Cursor& c) {
+    c.valid = c.item < n_items;
+    if (!c.valid) return;
+    int lo = 0, hi = n_pairs - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (ctx[mid].item_begin <= c.item) lo = mid; else hi = mid - 1;
+    }
+    c.pair = uniform_i32(lo);
+    c.chunk = uniform_i32(c.item - ctx[lo].item_begin);
+    c.two_m = uniform_i32(2 * ctx[lo].m);
+  };
+  auto advance = [&](Cursor& c) {  // next group of the walk; chunks of finished pairs are stepped over
+    if (++c.s < c.two_m) return;
+    c.s = 0;
+    for (;;) {
+      c.item += G;
+      locate(c);
+      if (!c.valid || ctx[c.pair].running) return;
+    }
+  };
+  auto load_ctx = [&](const Cursor& c, LoadCtx& L) {
+    const PairCtx& p = ctx[c.pair];
+    L.idx = (const SICP_GLOBAL int*)uniform_ptr(p.idx);
+    L.w = (const SICP_GLOBAL double*)uniform_ptr(p.w);
+    L.srec = (const SICP_GLOBAL PointRec*)uniform_ptr(p.srec);
+    L.trec = (const SICP_GLOBAL PointRec*)uniform_ptr(p.trec);
+    L.n_s = uniform_i32(p.n_s);
+    L.total = uniform_i32(p.total);
+  };
+  auto group_of = [&](const Cursor& c) { return c.chunk * uniform_i32(ctx[c.pair].chunk_groups) + c.s * BS + (int)threadIdx.x; };
+  auto issue_targets = [&](const LoadCtx& L, const int (&j)[SG]) {
+#pragma unroll
+    for (int c = 0; c < SG; ++c) lds_dma_rec(L.trec + max(j[c], 0), stage + c * STAGE_SLOT_BYTES);
+  };
+
+  Cursor cC;  // the group being computed
+  cC.item = (int)blockIdx.x; cC.s = 0;
+  locate(cC);
+  while (cC.valid && !ctx[cC.pair].running) { cC.item += G; locate(cC); }
+  if (!cC.valid) return;
+  Cursor cN = cC;  // the group whose targets are fetched next
+  advance(cN);
+  Cursor cN2 = cN;  // the group whose indices are fetched next
+  if (cN.valid) advance(cN2);
+
+  // Two sets of the register-borne part alternate as "current" and "next" (the step below is
+  // instantiated twice with the roles swapped): a copy `current = next` would be scheduled into the
+  // arithmetic and wait there for the very loads it is meant to overlap.
+  GroupRegs<K> R0, R1;
+  {
+    LoadCtx L;
+    load_ctx(cC, L);
+    load_idx_raw<K>(L, group_of(cC), R0.j);
+    {
+      const Cursor eN = cN.valid ? cN : cC;
+      LoadCtx Ln;
+      load_ctx(eN, Ln);
+      load_idx_raw<K>(Ln, group_of(eN), R1.j);
+    }
+    fix_idx<K>(L.total, group_of(cC), R0.j);
+    issue_targets(L, R0.j);
+    load_regs<K>(L, group_of(cC), R0);
+  }
+  MathCtx M;
+  int math_pair = -1;
+  double acc[28];
+#pragma unroll
+  for (int k = 0; k < 28; ++k) acc[k] = 0.0;
+
+  auto step = [&](GroupRegs<K>& cur, GroupRegs<K>& nxt) -> bool {
+    // (A) everything issued a step ago has landed.  The empty asm statements "use" every register a
+    // load of the previous step wrote: hipcc places its own (conservative, vmcnt(0)) wait for them
+    // here, where nothing is in flight, instead of at their first arithmetic use below -- where it
+    // would drain the loads issued in (B).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int c = 0; c < SG; ++c) { asm volatile("" : "+v"(cur.w[c]), "+v"(nxt.j[c])); }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      asm volatile("" : "+v"(cur.sx[s]), "+v"(cur.sy[s]), "+v"(cur.sz[s]), "+v"(cur.snx[s]), "+v"(cur.sny[s]), "+v"(cur.snz[s]));
+    }
+    Group<K> Gc;
+#pragma unroll
+    for (int c = 0; c < SG; ++c) {
+      Gc.j[c] = cur.j[c]; Gc.w[c] = cur.w[c];
+      lds_read_rec(stage + c * STAGE_SLOT_BYTES, lane, Gc.tx[c], Gc.ty[c], Gc.tz[c], Gc.tnx[c], Gc.tny[c], Gc.tnz[c]);
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { Gc.sx[s] = cur.sx[s]; Gc.sy[s] = cur.sy[s]; Gc.sz[s] = cur.sz[s]; Gc.snx[s] = cur.snx[s]; Gc.sny[s] = cur.sny[s]; Gc.snz[s] = cur.snz[s]; }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the staging area may be overwritten
+    // (B) the next group's traffic; the indices of the group after it replace the current ones.
+    // Unconditional: a load under a branch merges with the "not taken" value in a register copy,
+    // which is a use of the load -- the compiler would wait for it right here.  Past the end of the
+    // walk the current group is simply fetched again (with indices -1) and never computed.
+    {
+      const Cursor eN = cN.valid ? cN : cC, eN2 = cN2.valid ? cN2 : cC;
+      LoadCtx L, L2;
+      load_ctx(eN, L);
+      load_ctx(eN2, L2);
+      fix_idx<K>(cN.valid ? L.total : 0, group_of(eN), nxt.j);
+      issue_targets(L, nxt.j);
+      load_regs<K>(L, group_of(eN), nxt);
+      load_idx_raw<K>(L2, group_of(eN2), cur.j);
+    }
+    // (C) the arithmetic of the current group
+    if (cC.pair != math_pair) {
+      const PairCtx& p = ctx[cC.pair];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) M.P.R[k] = uniform_f64(p.R[k]);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) M.P.t[k] = uniform_f64(p.t[k]);
+      M.one_m_eps = uniform_f64(p.one_m_eps); M.loss_b = uniform_f64(p.loss_b); M.loss_c = uniform_f64(p.loss_c);
+      math_pair = cC.pair;
+    }
+    compute_group<K, SQLOSS>(M, Gc, acc);
+    if (cC.s == cC.two_m - 1) {  // the chunk is complete
+      const PairCtx& p = ctx[cC.pair];
+      block_reduce_store_raw<BS>(acc, red, (SICP_GLOBAL double*)uniform_ptr(p.partials), uniform_i32(p.n_chunks), cC.chunk);
+#pragma unroll
+      for (int k = 0; k < 28; ++k) acc[k] = 0.0;
+    }
+    if (!cN.valid) return false;
+    cC = cN; cN = cN2;
+    if (cN2.valid) advance(cN2);
+    return true;
+  };
+  for (;;) {
+    if (!step(R0, R1)) break;
+    if (!step(R1, R0)) break;
+  }
+}
+
 // fixed-order sum of the chunk partials (layout [28][n_chunks]) by one wave: every lane owns chunks
 // lane, lane+64, ... ; the 28 loads of one trip are independent and coalesced
 __device__ __forceinline__ void reduce_partials(const double* __restrict__ partials, int n_blocks, int lane, double (&o)[28]) {
@@ -497,33 +724,9 @@ __device__ __forceinline__ void reduce_partials(const double* __restrict__ parti
   for (int k = 0; k < 28; ++k) o[k] = wave_sum(s[k]);
 }
 
-// host-loop solve: sum the per-chunk partials in a fixed order
-__global__ __launch_bounds__(64) void finalize_kernel(const double* partials, int n_blocks, double* out28) {
-  double o[28];
-  reduce_partials(partials, n_blocks, threadIdx.x, o);
-  if (threadIdx.x < 28) {
-    double v = 0.0;
-#pragma unroll
-    for (int k = 0; k < 28; ++k) v = (int)threadIdx.x == k ? o[k] : v;
-    out28[threadIdx.x] = v;
-  }
-}
-
 // device-resident solve: reduce the chunk partials and advance the LM machine by one evaluation
-// (lm.hpp: the same lm_feed the host loop runs).  One wave: 512 VGPRs are available to it, so the
-// whole 6x6 trust-region step stays in registers; lane 0 does the serial part.
-__global__ __launch_bounds__(64) void lm_step_kernel(LmState* lm, const double* partials, int n_blocks) {
-  if (lm->status != LM_RUNNING) return;
-  const int lane = threadIdx.x;
-  double o[28];
-  reduce_partials(partials, n_blocks, lane, o);
-  if (lane == 0) {
-    LmCore st = *lm;  // the options stay in memory: uniform, read with scalar loads
-    lm_feed(st, lm->opt, o);
-    *static_cast<LmCore*>(lm) = st;
-  }
-}
-
+// (lm.hpp: the same lm_feed the host loop runs).  One wave per pair: 512 VGPRs are available to it, so
+// the whole 6x6 trust-region step stays in registers; lane 0 does the serial part.
 // batch forms: one block (one wave) per pair; the grid is the capacity of the batch buffers, the
 // blocks beyond the number of active pairs leave at once
 __global__ __launch_bounds__(64) void lm_step_batch_kernel(const BatchHeader* __restrict__ hdr, const BatchArgs* __restrict__ batch) {
@@ -581,29 +784,27 @@ hipError_t launch_se3_ops(int op, int n, const double* in, double* out, hipStrea
 // ------------------------------------------------------------------------------------------
 int accumulate_blocks(int total, int K) { return acc_geometry(total, K % 4 == 0 ? 4 : 2).n_chunks; }
 
-hipError_t launch_accumulate_kernel(const AccArgs& a, hipStream_t st) {
-  const int nb = accumulate_blocks(a.n_s * a.K, a.K);
-#define SICP_ACC(KK) \
-  do { \
-    if (a.loss.use_sqloss) hipLaunchKernelGGL((accumulate_kernel<KK, true, 256>), dim3(nb), dim3(256), 0, st, a); \
-    else hipLaunchKernelGGL((accumulate_kernel<KK, false, 256>), dim3(nb), dim3(256), 0, st, a); \
-  } while (0)
-  switch (a.K) {
-    case 1: SICP_ACC(1); break;
-    case 4: SICP_ACC(4); break;
-    case 20: SICP_ACC(20); break;
-    default: return hipErrorInvalidValue;
-  }
-#undef SICP_ACC
-  return hipGetLastError();
+// ---- the batched evaluation --------------------------------------------------------------------
+// SICP_ACC_VARIANT (tuning aid): 1 = LDS-staged software pipeline (default), 0 = plain persistent walk.
+// Same chunks, same additions: the two produce the same bits.
+static int accumulate_variant() {
+  static const int v = [] { const char* e = getenv("SICP_ACC_VARIANT"); return e ? atoi(e) : 1; }();
+  return v;
 }
 
-// ---- the batched evaluation --------------------------------------------------------------------
 static void* accumulate_stream_fn(int K, int use_sqloss) {
+  if (accumulate_variant() == 0) {
+    switch (K) {
+      case 1: return use_sqloss ? (void*)accumulate_stream_kernel<1, true, 256> : (void*)accumulate_stream_kernel<1, false, 256>;
+      case 4: return use_sqloss ? (void*)accumulate_stream_kernel<4, true, 256> : (void*)accumulate_stream_kernel<4, false, 256>;
+      case 20: return use_sqloss ? (void*)accumulate_stream_kernel<20, true, 256> : (void*)accumulate_stream_kernel<20, false, 256>;
+      default: return nullptr;
+    }
+  }
   switch (K) {
-    case 1: return use_sqloss ? (void*)accumulate_stream_kernel<1, true, 256> : (void*)accumulate_stream_kernel<1, false, 256>;
-    case 4: return use_sqloss ? (void*)accumulate_stream_kernel<4, true, 256> : (void*)accumulate_stream_kernel<4, false, 256>;
-    case 20: return use_sqloss ? (void*)accumulate_stream_kernel<20, true, 256> : (void*)accumulate_stream_kernel<20, false, 256>;
+    case 1: return use_sqloss ? (void*)accumulate_staged_kernel<1, true, 256> : (void*)accumulate_staged_kernel<1, false, 256>;
+    case 4: return use_sqloss ? (void*)accumulate_staged_kernel<4, true, 256> : (void*)accumulate_staged_kernel<4, false, 256>;
+    case 20: return use_sqloss ? (void*)accumulate_staged_kernel<20, true, 256> : (void*)accumulate_staged_kernel<20, false, 256>;
     default: return nullptr;
   }
 }
@@ -620,13 +821,16 @@ int accumulate_stream_grid() {
   return grid;
 }
 
-static size_t stream_smem_bytes(int capacity) { return sizeof(double) * RED_ROWS * 256 + sizeof(PairCtx) * (size_t)capacity; }
+static size_t stream_smem_bytes(int capacity, int K) {
+  const size_t staging = accumulate_variant() == 0 ? 0 : (size_t)4 * (K % 4 == 0 ? 4 : 2) * STAGE_SLOT_BYTES;
+  return sizeof(double) * RED_ROWS * 256 + staging + sizeof(PairCtx) * (size_t)capacity;
+}
 
 hipError_t launch_accumulate_batch(int K, int use_sqloss, const BatchHeader* hdr, const BatchArgs* batch, int capacity, hipStream_t st) {
   void* fn = accumulate_stream_fn(K, use_sqloss);
   if (!fn) return hipErrorInvalidValue;
   void* args[] = {(void*)&hdr, (void*)&batch};
-  return hipLaunchKernel(fn, dim3(accumulate_stream_grid()), dim3(256), args, stream_smem_bytes(capacity), st);
+  return hipLaunchKernel(fn, dim3(accumulate_stream_grid()), dim3(256), args, stream_smem_bytes(capacity, K), st);
 }
 
 hipError_t launch_lm_step_batch(const BatchHeader* hdr, const BatchArgs* batch, int capacity, hipStream_t st) {
@@ -664,7 +868,7 @@ hipError_t batch_graph_prepare(BatchGraph& g, int K, int use_sqloss, const Batch
   pa.func = fn;
   pa.gridDim = dim3(accumulate_stream_grid());
   pa.blockDim = dim3(256);
-  pa.sharedMemBytes = (unsigned)stream_smem_bytes(capacity);
+  pa.sharedMemBytes = (unsigned)stream_smem_bytes(capacity, K);
   pa.kernelParams = args;
   memset(&ps, 0, sizeof ps);
   ps.func = (void*)lm_step_batch_kernel;
@@ -686,18 +890,6 @@ hipError_t batch_graph_prepare(BatchGraph& g, int K, int use_sqloss, const Batch
   g.K = K; g.sqloss = use_sqloss; g.len = len; g.batch = batch; g.hdr = hdr; g.capacity = capacity;
   *built = 1;
   return hipSuccess;
-}
-
-hipError_t launch_finalize(const AccArgs& a, double* out28, hipStream_t st) {
-  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, st, a.partials, accumulate_blocks(a.n_s * a.K, a.K), out28);
-  return hipGetLastError();
-}
-
-hipError_t launch_accumulate_lm(const AccArgs& a, LmState* lm, hipStream_t st) {
-  hipError_t e = launch_accumulate_kernel(a, st);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(lm_step_kernel, dim3(1), dim3(64), 0, st, lm, a.partials, accumulate_blocks(a.n_s * a.K, a.K));
-  return hipGetLastError();
 }
 
 }  // namespace sicp

@@ -91,7 +91,7 @@ def lib():
         _lib = C.CDLL(build())
         _lib.orc_em_prob.restype = C.c_double
         _lib.orc_gicp_probability.restype = C.c_int
-        for name in ("orc_align", "orc_fused_labels", "orc_solve"):
+        for name in ("orc_align", "orc_fused_labels", "orc_solve", "orc_solve_trace"):
             getattr(_lib, name).restype = C.c_int
     return _lib
 
@@ -285,6 +285,28 @@ def solve(params, src, scov, tgt, tcov, idx, w, init_qt):
         C.byref(ev), C.byref(fc),
     )
     return out, dict(status=st, lm_iters=it.value, evals=ev.value, cost=fc.value)
+
+
+def solve_trace(params, src, scov, tgt, tcov, idx, w, init_qt, max_trace=1000):
+    """orc_solve with a record of every step attempt: (cost, radius, candidate cost, accepted)."""
+    sx, sy, sz = (_f(src[:, i]) for i in range(3))
+    tx, ty, tz = (_f(tgt[:, i]) for i in range(3))
+    scov, tcov = _d(scov).reshape(-1), _d(tcov).reshape(-1)
+    idx = _i(idx)
+    K = idx.shape[1]
+    w = None if w is None else _d(w)
+    init_qt = _d(init_qt)
+    out = np.empty(7)
+    tc, trd, tcc = np.empty(max_trace), np.empty(max_trace), np.empty(max_trace)
+    ta = np.empty(max_trace, dtype=np.int32)
+    n = C.c_int(0)
+    st = lib().orc_solve_trace(
+        C.byref(params), sx.shape[0], _p(sx, _fp), _p(sy, _fp), _p(sz, _fp), _p(scov, _dp), _p(tx, _fp), _p(ty, _fp),
+        _p(tz, _fp), _p(tcov, _dp), K, _p(idx, _ip), _p(w, _dp), _p(init_qt, _dp), _p(out, _dp), max_trace,
+        _p(tc, _dp), _p(trd, _dp), _p(tcc, _dp), _p(ta, _ip), C.byref(n),
+    )
+    k = n.value
+    return out, dict(status=st, cost=tc[:k], radius=trd[:k], cand_cost=tcc[:k], accepted=ta[:k])
 
 
 def align(params, src, slabels, tgt, tlabels, cm, init_qt):

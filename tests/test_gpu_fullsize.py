@@ -283,9 +283,10 @@ def test_heterogeneous_batch_equals_lone_aligns(mode):
                 assert sb[key] == s1[key], (k, key)
             rot, tr = pose_err_to_matrix(qb, pairs[k][4])
             assert rot < 3e-3 and tr < 3e-2, (k, rot, tr)
-        # idle accounting: a pair sits through every launch of the batch, its own evaluations are fewer
-        slots = [s["lockstep_slots"] for _, s in res]
-        assert len(set(slots)) == 1 and slots[0] >= max(evals)
+        # idle accounting: a pair only sits through the ticks it takes part in -- its own evaluations plus
+        # at most one partial tick (lm_batch = 8 evaluations) per inner solve
+        for _, sb in res:
+            assert sb["total_evals"] <= sb["lockstep_slots"] <= sb["total_evals"] + 8 * sb["outer_iters"]
         assert sum(s["graph_builds"] for _, s in res) <= 1
         # a different sub-batch (other leader, other sizes) and the first batch again: same bits,
         # and the instantiated graph is updated in place rather than rebuilt

@@ -170,3 +170,52 @@ def test_fused_labels_shape_and_range():
     lab = O.fused_labels(p, g["src"], g["sl"], g["tgt"], g["tl"], g["cm"], qt)
     assert lab.shape == g["sl"].shape and lab.min() >= 1 and lab.max() <= 4
     assert (lab == g["sl"]).mean() > 0.95
+
+
+@pytest.mark.parametrize("mode", ["gicp", "em", "semantic"])
+def test_lm_step_control_against_an_independent_loop(mode):
+    """The oracle's trust-region loop, step attempt by step attempt, against tests/lm_ref.py: a loop
+    written from the Ceres documentation on the explicit Jacobian, with a stacked least-squares
+    (DENSE_QR-style) step instead of Cholesky on the normal equations and scipy's expm for the
+    pose update.  Same accept / reject sequence, same radii, same costs."""
+    import lm_ref
+
+    g = load("align.npz")
+    src, sl, tgt, tl, cm = g["src"], g["sl"], g["tgt"], g["tl"], g["cm"]
+    C = cm.shape[0]
+    omode = {"gicp": O.MODE_GICP, "em": O.MODE_EM, "semantic": O.MODE_SEMANTIC}[mode]
+    p = O.default_params(omode)
+    p.num_classes = C
+    K = 4 if mode == "em" else 1
+    ident = np.array([0, 0, 0, 1, 0, 0, 0.0])
+    scov, sn, sh = O.covariances(src, sl if mode == "em" else None, 20, p.epsilon, C)
+    tcov, tn, th = O.covariances(tgt, tl if mode == "em" else None, 20, p.epsilon, C)
+    idx, d2 = O.knn(src, tgt, K)
+    idx[~(d2 < np.float32(p.gate_sq))] = -1
+    w = np.zeros(idx.shape)
+    for i in range(len(src)):
+        for c in range(K):
+            j = idx[i, c]
+            if j < 0:
+                continue
+            if mode == "em":
+                b, _ = O.gicp_probability(ident, src[i].astype(np.float64), tgt[j].astype(np.float64), scov[i], tcov[j])
+                w[i, c] = O.em_prob(cm, th[j], sh[i]) * float(b)
+            else:
+                w[i, c] = 1.0
+    oq, tr = O.solve_trace(p, src, scov, tgt, tcov, idx, w, ident)
+    live = idx >= 0
+    pairs = np.stack([np.nonzero(live)[0], idx[live]], axis=1)
+    rq, rtr = lm_ref.solve(mode, p.cauchy_a, src.astype(np.float64), sn, tgt.astype(np.float64), tn, pairs, w[live], p.epsilon, ident,
+                           gradient_tolerance=p.gradient_tolerance, function_tolerance=p.function_tolerance)
+    assert len(rtr) == len(tr["cost"]) and len(rtr) > 5
+    ref = np.array(rtr)
+    assert np.array_equal(ref[:, 3].astype(int), tr["accepted"])           # same accept / reject / invalid sequence
+    assert np.allclose(ref[:, 0], tr["cost"], rtol=1e-9, atol=0)            # cost at every accepted iterate
+    assert np.allclose(ref[:, 2], tr["cand_cost"], rtol=1e-9, atol=0)       # cost at every candidate
+    # trust-region radius of every step (near convergence rho is a ratio of differences of nearly equal
+    # costs, so the two float64 implementations drift apart in the 5th digit there)
+    assert np.allclose(ref[:, 1], tr["radius"], rtol=2e-4, atol=0)
+    assert np.allclose(ref[:6, 1], tr["radius"][:6], rtol=1e-9, atol=0)
+    D = np.linalg.inv(O.se3_matrix(oq)) @ O.se3_matrix(rq)
+    assert np.linalg.norm(Rotation.from_matrix(D[:3, :3]).as_rotvec()) < 1e-9 and np.linalg.norm(D[:3, 3]) < 1e-9

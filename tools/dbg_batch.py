@@ -1,19 +1,26 @@
-import importlib, sys, os, time
+"""Debug aid: lone align() vs sicp_align_batch on the same handles -- counters and pose deltas."""
+import importlib, sys, os
 import numpy as np
-sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import synth
 sicp = importlib.import_module("semantic-icp_amd")
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
-ps, ls, pt, lt, T, cm = synth.lidar_pair(seed=2, n_points=n)
-p = sicp.default_params(sicp.MODE_EM); p.num_classes = 11
-es = []
-for k in range(2):
-    e = sicp.Engine(0, p); e.set_confusion(cm); e.set_source(ps, ls); e.set_target(pt, lt); es.append(e)
-q1, s1 = es[0].align()
-print("single", q1, {k: s1[k] for k in ("outer_iters", "total_lm_iters", "total_evals", "total_corr", "t_total_ms", "t_solve_ms", "t_cov_ms")})
-for rep in range(2):
-    t0 = time.perf_counter()
-    res = sicp.align_batch(es)
-    dt = time.perf_counter() - t0
-    for q, s in res:
-        print("batch", dt * 1e3, q, {k: s[k] for k in ("outer_iters", "total_lm_iters", "total_evals", "total_corr", "t_total_ms", "t_solve_ms", "t_cov_ms")})
+mode = sicp.MODE_GICP
+pairs = [synth.lidar_pair(seed=s, n_points=n) for s, n in ((2, 6000), (3, 2500), (5, 9000))]
+engines = []
+for ps, ls, pt, lt, T, cm in pairs:
+    p = sicp.default_params(mode)
+    e = sicp.Engine(0, p)
+    e.set_source(ps); e.set_target(pt)
+    engines.append(e)
+singles = [e.align() for e in engines]
+singles2 = [e.align() for e in engines]
+batch = sicp.align_batch(engines)
+batch1 = [sicp.align_batch([e])[0] for e in engines]
+keys = ("outer_iters", "total_lm_iters", "total_evals", "total_corr", "total_active", "final_cost")
+for k, ((qs, ss), (q2, s2), (qb, sb), (q1, s1)) in enumerate(zip(singles, singles2, batch, batch1)):
+    print("pair", k, "single==single2", np.array_equal(qs, q2), "batch==single", np.array_equal(qs, qb), "batch1==single", np.array_equal(qs, q1),
+          "max|dq|", np.abs(qs - qb).max(), np.abs(qs - q1).max())
+    print("   single", [ss[x] for x in keys])
+    print("   batch ", [sb[x] for x in keys], "slots", sb["lockstep_slots"])
+    print("   batch1", [s1[x] for x in keys])
