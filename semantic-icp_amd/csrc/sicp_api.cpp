@@ -130,6 +130,11 @@ struct Cloud {
   // one batch is only searched once per call), and which confusion matrix the projections belong to
   unsigned long long feat_epoch = 0;
   unsigned long long proj_cm_id = 0;
+  // the upload + tree build is left running on the uploading handle's stream: whoever uses the cloud
+  // next (any handle, any stream, or the host reading `perm`) waits for this event first
+  hipEvent_t ready_ev = nullptr;
+  bool pending = false;
+  ~Cloud() { if (ready_ev) (void)hipEventDestroy(ready_ev); }
   int n_seg() const { return (int)seg_label.size(); }
   int caller_index(int d) const { return perm[d]; }
 };
@@ -237,6 +242,8 @@ struct sicp_context {
   double* h_bout28 = nullptr;
   int h_batch_cap = 0;
   sicp::BatchGraph b_graph;
+  std::vector<int> tick_act;   // the pairs whose arguments d_batch currently holds (run_tick)
+  bool tick_valid = false;
   hipStream_t side_stream = nullptr;  // batch leader: searches of the pairs between two inner solves
   hipEvent_t side_done = nullptr, main_done = nullptr;
   hipStream_t part_stream[kParts] = {};
@@ -286,10 +293,19 @@ int set_device(sicp_context* h) {
 }
 
 // ---- cloud layout -----------------------------------------------------------------------------
+int cloud_wait(sicp_context* h, Cloud& c) {
+  if (c.pending) {
+    HIPCHECK(hipEventSynchronize(c.ready_ev));
+    c.pending = false;
+  }
+  return SICP_OK;
+}
+
 int prepare_cloud(sicp_context* h, Cloud& c) {
   const int want = h->params.mode == SICP_MODE_SEMANTIC ? 1 : 0;
   if (!c.is_set) return SICP_ERR_NOT_READY;
   if (want == 1 && !c.has_label) return SICP_ERR_NOT_READY;
+  SICPCHECK(cloud_wait(h, c));  // an upload still in flight (possibly queued by another handle or host thread)
   if (c.layout == want) return SICP_OK;
   const int n = c.n;
   // ---- host: segment membership and per-segment bounding boxes (one pass over the cloud)
@@ -376,7 +392,12 @@ int prepare_cloud(sicp_context* h, Cloud& c) {
   HIPCHECK(sicp::build_tree_device(b, segs.data(), n_seg, h->stream));
   HIPCHECK(c.perm.resize(n));  // device -> caller order, for returning results in the caller's order
   if (n > 0) HIPCHECK(hipMemcpyAsync(c.perm.data(), c.d_perm.p, sizeof(int) * n, hipMemcpyDeviceToHost, h->stream));
-  HIPCHECK(hipStreamSynchronize(h->stream));  // staging vectors go out of scope
+  // no synchronisation here: every staging buffer is pinned memory owned by the cloud, and the next
+  // user of the cloud waits for ready_ev (cloud_wait).  A sequence driver can therefore queue the
+  // uploads of a whole batch of scans back to back, beside the registrations of the previous batch.
+  if (!c.ready_ev) HIPCHECK(hipEventCreateWithFlags(&c.ready_ev, hipEventDisableTiming));
+  HIPCHECK(hipEventRecord(c.ready_ev, h->stream));
+  c.pending = true;
   c.layout = want;
   c.feat_valid = false;
   h->corr_valid = false;
@@ -678,6 +699,7 @@ int eval28(sicp_context* h, const double* qt, double* out28) {
   SICPCHECK(batch_reserve(h, 1));
   const int nb = sicp::accumulate_blocks(h->corr_n * h->corr_K, h->corr_K);
   HIPCHECK(h->partials.reserve((size_t)nb * 28));
+  h->tick_valid = false;
   sicp::BatchArgs& B = h->h_batch[0];
   std::memset(&B, 0, sizeof B);
   fill_acc(h, B.a);
@@ -742,6 +764,7 @@ int run_solve(sicp_context* h, const double* init_qt, double* out_qt, SolveResul
   // kernel + one-wave LM step each) as ONE graph launch; the host looks at the state once per tick.
   // The very machinery of sicp_align_batch, with a batch of one.
   SICPCHECK(batch_reserve(h, 1));
+  h->tick_valid = false;
   const int len = std::min(P.lm_batch > 0 ? P.lm_batch : 12, sicp::kMaxBatchLen);
   sicp_handle self = h;
   double start[1][7];
@@ -943,8 +966,11 @@ int run_tick(sicp_context* h, hipStream_t M, sicp_handle* hs, int n, const std::
     sicp::lm_init(h->h_bstates[p], lm_options(hs[p]->params), start[p]);
     HIPCHECK(hipMemcpyAsync(h->d_bstates.p + p, h->h_bstates + p, sizeof(sicp::LmState), hipMemcpyHostToDevice, M));
   }
+  // the argument array in HBM only changes when the set of pairs inside a solve does
+  const bool same_set = h->tick_valid && joining.empty() && h->tick_act == act;
   int n_items = 0, k = 0;
   for (int p : act) {
+    if (same_set) break;
     sicp_context* g = hs[p];
     sicp::BatchArgs& B = h->h_batch[k++];
     std::memset(&B, 0, sizeof B);
@@ -956,9 +982,13 @@ int run_tick(sicp_context* h, hipStream_t M, sicp_handle* hs, int n, const std::
     B.item_begin = n_items;
     n_items += nb;
   }
-  h->h_bhdr->n_pairs = (int)act.size(); h->h_bhdr->n_items = n_items; h->h_bhdr->pad_[0] = h->h_bhdr->pad_[1] = 0;
-  HIPCHECK(hipMemcpyAsync(h->d_bhdr.p, h->h_bhdr, sizeof(sicp::BatchHeader), hipMemcpyHostToDevice, M));
-  HIPCHECK(hipMemcpyAsync(h->d_batch.p, h->h_batch, sizeof(sicp::BatchArgs) * act.size(), hipMemcpyHostToDevice, M));
+  if (!same_set) {
+    h->h_bhdr->n_pairs = (int)act.size(); h->h_bhdr->n_items = n_items; h->h_bhdr->pad_[0] = h->h_bhdr->pad_[1] = 0;
+    HIPCHECK(hipMemcpyAsync(h->d_bhdr.p, h->h_bhdr, sizeof(sicp::BatchHeader), hipMemcpyHostToDevice, M));
+    HIPCHECK(hipMemcpyAsync(h->d_batch.p, h->h_batch, sizeof(sicp::BatchArgs) * act.size(), hipMemcpyHostToDevice, M));
+    h->tick_act = act;
+    h->tick_valid = true;
+  }
   // [accumulate_stream, lm_step_batch] x len as an explicit graph with fixed grids: the kernels read the
   // number of active pairs and chunks from the header, so the graph is instantiated once per batch
   // context (buffer addresses) and never touched when pairs come and go or batches differ in size.
@@ -1158,6 +1188,7 @@ int sicp_set_cloud(sicp_handle h, int which, int32_t n, const float* x, const fl
   SICPCHECK(set_device(h));
   if (h->cl[which].use_count() > 1) h->cl[which] = acquire_cloud(h->device);  // shared with another handle: leave theirs alone
   Cloud& c = h->cloud(which);
+  SICPCHECK(cloud_wait(h, c));  // a previous upload may still be reading the staging buffers
   c.n = n;
   HIPCHECK(c.hx.assign(x, n)); HIPCHECK(c.hy.assign(y, n)); HIPCHECK(c.hz.assign(z, n));
   c.has_label = label != nullptr;
@@ -1316,6 +1347,7 @@ int sicp_align_batch(sicp_handle* hs, int32_t n, const double* init_qt, double* 
   {
     sicp_context* h = L;
     SICPCHECK(batch_reserve(h, n));
+    h->tick_valid = false;
     if (!h->side_stream) {
       HIPCHECK(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
       HIPCHECK(hipEventCreateWithFlags(&h->side_done, hipEventDisableTiming));
@@ -1432,6 +1464,7 @@ int sicp_accumulate_batch(sicp_handle* hs, int32_t n, const double* qt, double* 
   if (n > kMaxActivePairs) return SICP_ERR_INVALID_ARGUMENT;  // one launch holds at most this many pairs
   SICPCHECK(set_device(h));
   SICPCHECK(batch_reserve(h, n));
+  h->tick_valid = false;
   int n_items = 0;
   for (int p = 0; p < n; ++p) {
     sicp_context* g = hs[p];

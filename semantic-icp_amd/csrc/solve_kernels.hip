@@ -729,16 +729,46 @@ __device__ __forceinline__ void reduce_partials(const double* __restrict__ parti
 // the whole 6x6 trust-region step stays in registers; lane 0 does the serial part.
 // batch forms: one block (one wave) per pair; the grid is the capacity of the batch buffers, the
 // blocks beyond the number of active pairs leave at once
-__global__ __launch_bounds__(64) void lm_step_batch_kernel(const BatchHeader* __restrict__ hdr, const BatchArgs* __restrict__ batch) {
+// Four waves share the reduction (wave w sums rows w, w + 4, ...: per row exactly the additions of
+// reduce_partials, so the 28 sums keep their bits), then lane 0 of wave 0 takes the trust-region step.
+__global__ __launch_bounds__(256) void lm_step_batch_kernel(const BatchHeader* __restrict__ hdr, const BatchArgs* __restrict__ batch) {
   if ((int)blockIdx.x >= hdr->n_pairs) return;
   const BatchArgs& B = batch[blockIdx.x];
   LmState* lm = B.a.lm_step;
   if (lm->status != LM_RUNNING) return;
-  const int lane = threadIdx.x;
-  double o[28];
-  reduce_partials(B.a.partials, B.nb, lane, o);
-  if (lane == 0) {
-    LmCore st = *lm;
+  __shared__ double s_out[28];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = B.nb;
+  const double* __restrict__ base = B.a.partials + (size_t)wave * n;  // row wave + 4 r lives at base + 4 r n
+  double s[7];
+#pragma unroll
+  for (int r = 0; r < 7; ++r) s[r] = 0.0;
+  for (int b0 = lane; b0 < n; b0 += 256) {
+    double v[4][7];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int b = min(b0 + 64 * t, n - 1);  // clamped: loaded unconditionally, added only when in range
+#pragma unroll
+      for (int r = 0; r < 7; ++r) v[t][r] = __builtin_nontemporal_load(base + (size_t)(4 * r) * n + b);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (b0 + 64 * t < n) {
+#pragma unroll
+        for (int r = 0; r < 7; ++r) s[r] += v[t][r];
+      }
+  }
+#pragma unroll
+  for (int r = 0; r < 7; ++r) {
+    const double sum = wave_sum(s[r]);
+    if (lane == 0) s_out[wave + 4 * r] = sum;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double o[28];
+#pragma unroll
+    for (int k = 0; k < 28; ++k) o[k] = s_out[k];
+    LmCore st = *lm;  // the options stay in memory: uniform, read with scalar loads
     lm_feed(st, lm->opt, o);
     *static_cast<LmCore*>(lm) = st;
   }
@@ -835,7 +865,7 @@ hipError_t launch_accumulate_batch(int K, int use_sqloss, const BatchHeader* hdr
 
 hipError_t launch_lm_step_batch(const BatchHeader* hdr, const BatchArgs* batch, int capacity, hipStream_t st) {
   if (capacity <= 0) return hipSuccess;
-  hipLaunchKernelGGL(lm_step_batch_kernel, dim3(capacity), dim3(64), 0, st, hdr, batch);
+  hipLaunchKernelGGL(lm_step_batch_kernel, dim3(capacity), dim3(256), 0, st, hdr, batch);
   return hipGetLastError();
 }
 
@@ -873,7 +903,7 @@ hipError_t batch_graph_prepare(BatchGraph& g, int K, int use_sqloss, const Batch
   memset(&ps, 0, sizeof ps);
   ps.func = (void*)lm_step_batch_kernel;
   ps.gridDim = dim3(capacity);
-  ps.blockDim = dim3(64);
+  ps.blockDim = dim3(256);
   ps.kernelParams = args;
   hipError_t e = hipGraphCreate(&g.graph, 0);
   if (e != hipSuccess) return e;
