@@ -11,10 +11,11 @@ A "step" registers one batch of independent scan pairs on each GPU: `--pairs-in-
 transform -> kNN -> EM weights -> inner LM solve) on its own handle, with all clouds already
 resident in HBM when the timed region starts.  Independent pairs are the reference's unit of work
 (exec/kitti_eval.cc:124-249 loops over them) and the north star shards them across GPUs.  The S
-pairs of a GPU advance in lock step through one sicp_align_batch call: every kernel launch of the
-path covers all pairs that still iterate, per pair bit-identical to a lone align().  Pairs need
-different numbers of outer iterations and LM evaluations, so some idle while the slowest finish:
-`lockstep.busy_fraction` reports it.
+pairs of a GPU go through one sicp_align_batch call: every launch of the solve evaluates all pairs
+that are inside an inner solve, while the searches of the pairs between two solves run beside it
+(continuous batching: no pair waits for another pair's solve or outer loop); per pair the result
+is bit-identical to a lone align().  `lockstep.busy_fraction` = the pairs' own LM evaluations / the
+evaluation launches they took part in.
 
 One correspondence = one (source, target) slot that went through kNN + weighting + accumulation
 in one outer iteration.
@@ -414,7 +415,7 @@ def main():
                 "points": n, "K": K, "classes": N_CLASSES if em else 0, "parallelism": f"pairs-sharded x{dist.world}",
                 "pairs_in_flight_per_gpu": S,
                 "step": f"{S} full align() calls per GPU (covariances of both clouds + all outer ICP iterations each), "
-                        "advanced in lock step by one sicp_align_batch call",
+                        "registered together by one sicp_align_batch call (continuous batching)",
             },
             "pairs_per_s": S * dist.world * steps / elapsed_max,
             "ms_per_icp_iter": 1e3 * elapsed_max * dist.world * S / max(1.0, outer_all),
@@ -426,7 +427,8 @@ def main():
                 "outer_iters_min_max": [int(min(outer_pp)), int(max(outer_pp))],
                 "evals_per_align_min_max": [int(min(evals_pp)), int(max(evals_pp))],
                 "graph_builds_in_timed_region": int(agg["graph_builds"]),
-                "note": "rank 0's batch; a pair whose inner solve or outer loop has finished idles until the slowest pair of the batch is done",
+                "note": "rank 0's batch, last step; a pair only takes part in the ticks (graph launches of lm_batch evaluations) it is inside an "
+                        "inner solve for, so the idle part is the tail of the tick in which its solve ends",
             },
         }
 
@@ -491,16 +493,22 @@ def main():
                 t = json.load(open(TRAFFIC_FILE))
                 key = f"accumulate_batch_K{K}_pairs{S}_n{n}"
                 if key in t:
-                    traffic, traffic_src = t[key]["bytes_per_launch"], f"profiles/r02/pmc_hbm_traffic.json:{key} (rocprofv3 --pmc passes of this command, not measured in this run)"
+                    traffic = t[key]["bytes_per_launch"]
+                    traffic_src = (f"profiles/r02/pmc_hbm_traffic.json:{key}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same launch "
+                                   "(tools/run_fetch_calibration.sh), FETCH_SIZE x2 as calibrated on this access pattern; from the committed profile, "
+                                   "not measured in this run")
             except Exception:
                 pass
         out["roofline"] = {
-            "kernel": f"accumulate_batch_kernel<K={K}> (Mahalanobis residual + 6-DoF Jacobian -> 28 doubles per pair; one launch per LM "
-                      f"evaluation covers the {S} pairs of the batch)",
+            "kernel": f"accumulate_staged_kernel<K={K}> (Mahalanobis residual + 6-DoF Jacobian + robust loss -> 28 sums per pair; persistent "
+                      f"workgroups, LDS-staged gathers; one launch per LM evaluation, timed here over all {S} pairs of the batch)",
             "bound": "hbm", "achieved": acc_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": acc_gbs / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": traffic_src,
             "avg_launch_us": acc_us, "launches_timed": 50 * len(acc_ms_l[2:]), "algorithmic_bytes_per_launch": acc_bytes,
             "pairs_per_launch": S,
+            "note": "not an HBM-bound kernel in practice: the memory side moves ~0.98x the algorithmic bytes (no re-reads) at ~3 TB/s; the launch is "
+                    "bound by FP64 issue (PMC: ~250 VALU instructions per correspondence = 83 us of pure issue at 2.4 GHz) plus the exposed part "
+                    "of the index -> gather latency (DESIGN.md section 3)",
         }
         pp = engine.get_params()
         pp.profile = 1  # SICP_PROFILE_NN: the correspondence-search kernel alone, 20 launches at the final pose
