@@ -118,7 +118,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return _load_build_module().build_lib(force=force, verbose=verbose)
 
 
-LIB_PATH = os.path.join(_PKG, "libsicp.so")
+LIB_PATH = os.environ.get("SICP_LIB") or os.path.join(_PKG, "libsicp.so")  # SICP_LIB: an experimental build (tuning aid)
 _lib = None
 
 _dp = C.POINTER(C.c_double)

@@ -23,15 +23,17 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_lib(force: bool = False, verbose: bool = False) -> str:
-    if not force and not _stale():
+def build_lib(force: bool = False, verbose: bool = False, out: str | None = None, extra_flags=()) -> str:
+    """`out` / `extra_flags` build an experimental variant next to the product library (tuning aid:
+    SICP_LIB=<path> makes the Python binding load it)."""
+    if out is None and not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [
-        hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+        hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", *extra_flags,
         "-I", os.path.join(ROOT, "include"), "-I", CSRC,
         *[os.path.join(CSRC, s) for s in SOURCES],
-        "-o", LIB, "-Wl,-rpath,/opt/rocm/lib",
+        "-o", out or LIB, "-Wl,-rpath,/opt/rocm/lib",
     ]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or r.returncode != 0:
@@ -40,7 +42,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
         print(r.stderr)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed:\n" + r.stderr)
-    return LIB
+    return out or LIB
 
 
 if __name__ == "__main__":

@@ -37,18 +37,33 @@ struct alignas(16) PointRec {
 };
 static_assert(sizeof(PointRec) == 48, "PointRec is read with three dwordx4 / dwordx2 loads");
 
+// Build-time shape of the accumulate kernels (tuning: see DESIGN.md section 3):
+//   SICP_SG4     slots per group when K is a multiple of 4 (4 = the K = 4 slots of one source point per
+//                step, 2 = half of them: fewer live registers per lane)
+//   SICP_ACC_OCC workgroups (of 4 waves) per CU the batched kernel is compiled for = waves per SIMD
+#ifndef SICP_SG4
+#define SICP_SG4 4
+#endif
+#ifndef SICP_ACC_OCC
+#define SICP_ACC_OCC 2
+#endif
+constexpr int acc_slots_per_group(int K) { return K % 4 == 0 ? SICP_SG4 : 2; }
+
 // Decomposition of a pair's correspondence slots into chunks (solve_kernels.hip): groups of
-// `slots_per_group` slots, chunks of 512 m groups (m = 1 up to 1024 chunks), one row of 28 partial
+// `slots_per_group` slots; a chunk = what one 256-lane workgroup sums = 2048 m slots (m = 1 up to 1024
+// chunks), every lane taking `steps` = 8 m / slots_per_group groups, 256 apart; one row of 28 partial
 // sums per chunk.  Host and device compute it from the slot count alone.
 struct AccGeometry {
-  int n_groups, m, chunk_groups, n_chunks;
+  int n_groups, steps, chunk_groups, n_chunks;
 };
 SICP_HD inline AccGeometry acc_geometry(int total_slots, int slots_per_group) {
   AccGeometry g;
+  const int per_lane = 8 / slots_per_group;  // groups per lane and chunk at m = 1
   g.n_groups = (total_slots + slots_per_group - 1) / slots_per_group;
-  g.m = (g.n_groups + 512 * 1024 - 1) / (512 * 1024);
-  if (g.m < 1) g.m = 1;
-  g.chunk_groups = 512 * g.m;
+  int m = (g.n_groups + 256 * per_lane * 1024 - 1) / (256 * per_lane * 1024);
+  if (m < 1) m = 1;
+  g.steps = per_lane * m;
+  g.chunk_groups = 256 * g.steps;
   g.n_chunks = (g.n_groups + g.chunk_groups - 1) / g.chunk_groups;
   if (g.n_chunks < 1) g.n_chunks = 1;
   return g;

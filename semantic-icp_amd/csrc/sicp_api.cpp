@@ -1556,6 +1556,10 @@ int sicp_accumulate_batch(sicp_handle* hs, int32_t n, const double* qt, double* 
     HIPCHECK(hipStreamSynchronize(g->stream));  // the pair's correspondences are complete
   }
   h->ts[0].h_bhdr->n_pairs = n; h->ts[0].h_bhdr->n_items = n_items; h->ts[0].h_bhdr->pad_[0] = h->ts[0].h_bhdr->pad_[1] = 0;
+  {  // developer aid (timing only, wrong sums): the launch without its gather traffic
+    static const bool no_gather = std::getenv("SICP_ACC_DEBUG_NOGATHER") != nullptr;
+    if (no_gather) h->ts[0].h_bhdr->pad_[0] = 1;
+  }
   HIPCHECK(hipMemcpyAsync(h->ts[0].d_bhdr.p, h->ts[0].h_bhdr, sizeof(sicp::BatchHeader), hipMemcpyHostToDevice, h->stream));
   HIPCHECK(hipMemcpyAsync(h->ts[0].d_batch.p, h->ts[0].h_batch, sizeof(sicp::BatchArgs) * n, hipMemcpyHostToDevice, h->stream));
   if (repeat < 1) repeat = 1;

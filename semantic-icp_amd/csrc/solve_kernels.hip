@@ -192,8 +192,8 @@ __device__ __forceinline__ void pose_to_sgprs(Pose& P) {
 // ---- one group of SG consecutive slots: what a lane loads, and what it computes from it -----------
 template <int K>
 struct GroupShape {
-  static constexpr int SG = (K % 4 == 0) ? 4 : 2;   // slots per group
-  static constexpr int NS = (K % 4 == 0) ? 1 : 2;   // source points per group
+  static constexpr int SG = acc_slots_per_group(K);  // slots per group
+  static constexpr int NS = (K % 4 == 0) ? 1 : 2;    // source points per group
 };
 
 template <int K>
@@ -326,7 +326,10 @@ __device__ __forceinline__ void compute_group(const MathCtx& M, const Group<K>& 
 
 // The 28 sums of a workgroup -> partials[k][chunk]: transpose through LDS, RED_ROWS rows at a time
 // (28 rows at once would be 56 KB), wave w sums rows w, w + 4, ... with DPP.  Fixed order.
-constexpr int RED_ROWS = 14;
+#ifndef SICP_RED_ROWS
+#define SICP_RED_ROWS 14
+#endif
+constexpr int RED_ROWS = SICP_RED_ROWS;  // divides 28
 template <int BS>
 __device__ __forceinline__ void block_reduce_store(const double (&acc)[28], double (&red)[RED_ROWS][BS], SICP_GLOBAL double* partials,
                                                    int n_chunks, int chunk) {
@@ -372,7 +375,7 @@ struct PairCtx {
   const PointRec* srec;
   const PointRec* trec;
   double* partials;
-  int n_s, total, m, chunk_groups, n_chunks, item_begin, running, pad_;
+  int n_s, total, steps, chunk_groups, n_chunks, item_begin, running, pad_;
   double R[9], t[3];
   double one_m_eps, loss_b, loss_c;
 };
@@ -387,7 +390,7 @@ __device__ __forceinline__ void stage_pair_constants(const BatchArgs* __restrict
     c.idx = a.idx; c.w = a.w; c.srec = a.srec; c.trec = a.trec; c.partials = a.partials;
     c.n_s = a.n_s; c.total = a.n_s * a.K;
     const AccGeometry geo = acc_geometry(c.total, GroupShape<K>::SG);
-    c.m = geo.m; c.chunk_groups = geo.chunk_groups; c.n_chunks = geo.n_chunks;
+    c.steps = geo.steps; c.chunk_groups = geo.chunk_groups; c.n_chunks = geo.n_chunks;
     c.item_begin = B.item_begin;
     c.pad_ = 0;
     Pose P;
@@ -450,7 +453,7 @@ __global__ __launch_bounds__(BS, 2) void accumulate_stream_kernel(const BatchHea
     }
     const int chunk = uniform_i32(item - p.item_begin);
     const int g0 = chunk * uniform_i32(p.chunk_groups) + (int)threadIdx.x;
-    const int two_m = uniform_i32(2 * p.m);
+    const int two_m = uniform_i32(p.steps);
     double acc[28];
 #pragma unroll
     for (int k = 0; k < 28; ++k) acc[k] = 0.0;
@@ -551,7 +554,7 @@ struct Cursor {
 };
 
 template <int K, bool SQLOSS, int BS>
-__global__ __launch_bounds__(BS, 2) void accumulate_staged_kernel(const BatchHeader* __restrict__ hdr, const BatchArgs* __restrict__ batch) {
+__global__ __launch_bounds__(BS, SICP_ACC_OCC) void accumulate_staged_kernel(const BatchHeader* __restrict__ hdr, const BatchArgs* __restrict__ batch) {
   constexpr int SG = GroupShape<K>::SG, NS = GroupShape<K>::NS, NW = BS / 64;
   extern __shared__ double smem[];  // ONE shared object: [reduction rows | staging | per-pair constants]
   double (&red)[RED_ROWS][BS] = *reinterpret_cast<double (*)[RED_ROWS][BS]>(smem);
@@ -575,7 +578,7 @@ __global__ __launch_bounds__(BS, 2) void accumulate_staged_kernel(const BatchHea
     }
     c.pair = uniform_i32(lo);
     c.chunk = uniform_i32(c.item - ctx[lo].item_begin);
-    c.two_m = uniform_i32(2 * ctx[lo].m);
+    c.two_m = uniform_i32(ctx[lo].steps);
   };
   auto advance = [&](Cursor& c) {  // next group of the walk; chunks of finished pairs are stepped over
     if (++c.s < c.two_m) return;
@@ -596,9 +599,12 @@ __global__ __launch_bounds__(BS, 2) void accumulate_staged_kernel(const BatchHea
     L.total = uniform_i32(p.total);
   };
   auto group_of = [&](const Cursor& c) { return c.chunk * uniform_i32(ctx[c.pair].chunk_groups) + c.s * BS + (int)threadIdx.x; };
+  // hdr->pad_[0] (developer aid, SICP_ACC_DEBUG_NOGATHER): every gather reads target 0, i.e. the launch
+  // without its memory traffic -- what is left is the arithmetic's own time.  Results are wrong.
+  const int gather_mask = uniform_i32(hdr->pad_[0]) ? 0 : -1;
   auto issue_targets = [&](const LoadCtx& L, const int (&j)[SG]) {
 #pragma unroll
-    for (int c = 0; c < SG; ++c) lds_dma_rec(L.trec + max(j[c], 0), stage + c * STAGE_SLOT_BYTES);
+    for (int c = 0; c < SG; ++c) lds_dma_rec(L.trec + (max(j[c], 0) & gather_mask), stage + c * STAGE_SLOT_BYTES);
   };
 
   Cursor cC;  // the group being computed
@@ -812,7 +818,7 @@ hipError_t launch_se3_ops(int op, int n, const double* in, double* out, hipStrea
 // ------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------
-int accumulate_blocks(int total, int K) { return acc_geometry(total, K % 4 == 0 ? 4 : 2).n_chunks; }
+int accumulate_blocks(int total, int K) { return acc_geometry(total, acc_slots_per_group(K)).n_chunks; }
 
 // ---- the batched evaluation --------------------------------------------------------------------
 // SICP_ACC_VARIANT (tuning aid): 1 = LDS-staged software pipeline (default), 0 = plain persistent walk.
@@ -846,13 +852,13 @@ int accumulate_stream_grid() {
     if (e && atoi(e) > 0) return atoi(e);
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    return 2 * (cus > 0 ? cus : 256);
+    return SICP_ACC_OCC * (cus > 0 ? cus : 256);
   }();
   return grid;
 }
 
 static size_t stream_smem_bytes(int capacity, int K) {
-  const size_t staging = accumulate_variant() == 0 ? 0 : (size_t)4 * (K % 4 == 0 ? 4 : 2) * STAGE_SLOT_BYTES;
+  const size_t staging = accumulate_variant() == 0 ? 0 : (size_t)4 * acc_slots_per_group(K) * STAGE_SLOT_BYTES;
   return sizeof(double) * RED_ROWS * 256 + staging + sizeof(PairCtx) * (size_t)capacity;
 }
 

@@ -23,7 +23,8 @@ def run(name, mode, src, sl, tgt, tl, T, cm, C, reps=3, **kw):
     for k, v in kw.items(): setattr(p, k, v)
     with sicp.Engine(0, p) as e:
         if cm is not None: e.set_confusion(cm)
-        t0 = time.perf_counter(); e.set_source(src, sl); e.set_target(tgt, tl); t_set = time.perf_counter() - t0
+        e.set_source(src, sl); e.set_target(tgt, tl); e.synchronize()      # first upload: allocations
+        t0 = time.perf_counter(); e.set_source(src, sl); e.set_target(tgt, tl); e.synchronize(); t_set = time.perf_counter() - t0
         qt, st = e.align()
         t0 = time.perf_counter()
         for _ in range(reps): qt, st = e.align()
