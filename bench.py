@@ -6,7 +6,7 @@ Metric (BASELINE.json): correspondences/sec (+ ms per outer ICP iteration) for E
 subsampled to exactly 100 000 x 100 000 points -- the metric point of configs[1].
 
 A "step" registers one batch of independent scan pairs on each GPU: `--pairs-in-flight` S pairs
-(default 32), every one a DIFFERENT pair (its own street, ego-motion and noise: seeds
+(default 64), every one a DIFFERENT pair (its own street, ego-motion and noise: seeds
 2 + S*rank + k) and a complete align() (covariances of both clouds + every outer ICP iteration:
 transform -> kNN -> EM weights -> inner LM solve) on its own handle, with all clouds already
 resident in HBM when the timed region starts.  Independent pairs are the reference's unit of work
@@ -70,8 +70,8 @@ def parse_args():
     ap.add_argument("--nn-method", type=int, default=None, help="0 brute force, 1 box tree (default: library default)")
     ap.add_argument("--lm-on-device", type=int, default=None, help="0 host LM loop, 1 device-resident (default: library default)")
     ap.add_argument("--lm-batch", type=int, default=None)
-    ap.add_argument("--pairs-in-flight", type=int, default=32,
-                    help="independent, distinct scan pairs registered in lock step on each GPU (one handle each)")
+    ap.add_argument("--pairs-in-flight", type=int, default=64,
+                    help="independent, distinct scan pairs registered together on each GPU (one handle each; round 1 used 32)")
     ap.add_argument("--same-pair", action="store_true", help="r01 behaviour: every handle of a GPU gets the rank's first pair")
     ap.add_argument("--profile", type=int, default=0, help="SICP_PROFILE_* mask applied inside the timed region")
     ap.add_argument("--sequence-pairs", type=int, default=128, help="registrations of the end-to-end sequence leg (0 = skip)")
@@ -470,7 +470,7 @@ def main():
             e.close()
         # --- end-to-end sequence (cloud upload + tree build inside the timed region) ------------------
         if args.sequence_pairs > 0 and em:
-            others.append(sequence_leg(sicp, device, engine.get_params(), cm, args.sequence_pairs, S, n, seed=5))
+            others.append(sequence_leg(sicp, device, engine.get_params(), cm, args.sequence_pairs, 32, n, seed=5))
         out["other_workloads"] = others
 
         # --- rooflines (SURVEY.md 8d per-unit bytes x units per launch / HIP-event duration) ----------
@@ -478,20 +478,21 @@ def main():
         # pass).  The timed region runs it as accumulate_batch_kernel, one launch per LM evaluation for
         # all pairs that still iterate; here the launch over all S pairs is timed alone with HIP events
         # on its stream (sicp_accumulate_batch: 50 launches back to back between two events)
-        for e, q in zip(engines, qts):
+        L = min(S, 32)  # the launch shape of round 1's roofline and of the committed PMC passes: 32 pairs
+        for e, q in zip(engines[:L], qts[:L]):
             e.correspondences(q)
         acc_ms_l = []
         for _ in range(8):
-            _, ms = sicp.accumulate_batch(engines, np.array(qts), repeat=50)
+            _, ms = sicp.accumulate_batch(engines[:L], np.array(qts[:L]), repeat=50)
             acc_ms_l.append(ms)
         acc_us = 1e3 * float(np.mean(acc_ms_l[2:]))
-        acc_bytes = S * (24 * n + 32 * K * n)
+        acc_bytes = L * (24 * n + 32 * K * n)
         acc_gbs = acc_bytes / (acc_us * 1e-6) / 1e9
         traffic, traffic_src = None, None
         if os.path.exists(TRAFFIC_FILE):
             try:
                 t = json.load(open(TRAFFIC_FILE))
-                key = f"accumulate_batch_K{K}_pairs{S}_n{n}"
+                key = f"accumulate_batch_K{K}_pairs{L}_n{n}"
                 if key in t:
                     traffic = t[key]["bytes_per_launch"]
                     traffic_src = (f"profiles/r02/pmc_hbm_traffic.json:{key}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same launch "
@@ -501,11 +502,11 @@ def main():
                 pass
         out["roofline"] = {
             "kernel": f"accumulate_staged_kernel<K={K}> (Mahalanobis residual + 6-DoF Jacobian + robust loss -> 28 sums per pair; persistent "
-                      f"workgroups, LDS-staged gathers; one launch per LM evaluation, timed here over all {S} pairs of the batch)",
+                      f"workgroups, LDS-staged gathers; one launch per LM evaluation, timed here over {L} pairs of the batch)",
             "bound": "hbm", "achieved": acc_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": acc_gbs / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": traffic_src,
             "avg_launch_us": acc_us, "launches_timed": 50 * len(acc_ms_l[2:]), "algorithmic_bytes_per_launch": acc_bytes,
-            "pairs_per_launch": S,
+            "pairs_per_launch": L,
             "note": "not an HBM-bound kernel in practice: the memory side moves ~0.98x the algorithmic bytes (no re-reads) at ~3 TB/s; the launch is "
                     "bound by FP64 issue (PMC: ~250 VALU instructions per correspondence = 83 us of pure issue at 2.4 GHz) plus the exposed part "
                     "of the index -> gather latency (DESIGN.md section 3)",

@@ -584,3 +584,27 @@ def test_align_batch_at_metric_size_equals_single():
     finally:
         for e in engines:
             e.close()
+
+
+def test_align_batch_of_sixty_pairs_one_tick_group():
+    """More than 48 pairs: the batch runs as ONE tick group (below it, two alternate).  Same bits as
+    lone aligns either way; 60 small GICP pairs of ragged sizes."""
+    rng = np.random.default_rng(11)
+    engines, singles = [], []
+    try:
+        for k in range(60):
+            n = int(rng.integers(300, 1500))
+            tgt = rng.uniform(0, 6, (n, 3)).astype(np.float32)
+            tgt[:, 2] = (0.1 * np.sin(tgt[:, 0]) + 0.05 * tgt[:, 1]).astype(np.float32)  # a gently curved sheet
+            R = Rotation.from_rotvec(rng.normal(0, 0.01, 3)).as_matrix()
+            src = ((tgt.astype(np.float64) - rng.normal(0, 0.02, 3)) @ R).astype(np.float32)
+            e, p = make_engine(sicp.MODE_GICP)
+            e.set_source(src, None); e.set_target(tgt, None)
+            engines.append(e)
+            singles.append(e.align())
+        for k, ((qb, sb), (q1, s1)) in enumerate(zip(sicp.align_batch(engines), singles)):
+            assert np.array_equal(qb, q1), k
+            assert sb["outer_iters"] == s1["outer_iters"] and sb["total_evals"] == s1["total_evals"]
+    finally:
+        for e in engines:
+            e.close()
