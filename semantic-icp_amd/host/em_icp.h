@@ -36,6 +36,19 @@ class EmIterativeClosestPoint {
   inline void setSourceCloud(const PointCloudPtr& cloud) { source_cloud_ = cloud; upload(SICP_SOURCE, cloud); }
   inline void setTargetCloud(const PointCloudPtr& cloud) { target_cloud_ = cloud; upload(SICP_TARGET, cloud); }
 
+  // Engine extensions for scan sequences (no reference counterpart in this class; GICP has
+  // setSourceCloud(cloud, kdtree, covs), gicp.h:48-56, for the same purpose): the target of this
+  // registration IS the source cloud of `other` -- one upload, one search tree, one set of normals and
+  // histograms on the GPU (sicp_share_cloud) -- and keepFeatures(true) computes them once per upload
+  // instead of once per align() (impl/em_icp.hpp:28-29 recomputes; the values are the same).
+  inline void setTargetCloudSharedWithSourceOf(EmIterativeClosestPoint& other) {
+    target_cloud_ = other.source_cloud_;
+    sicp_handle h = engine_.get();
+    configure(h);
+    detail::check(sicp_share_cloud(h, SICP_TARGET, other.engine_.get(), SICP_SOURCE), h, "sicp_share_cloud");
+  }
+  inline void keepFeatures(bool on) { reuse_features_ = on; }
+
   // reference: em_icp.h:68-71
   inline void setConfusionMatrix(const Eigen::Matrix<double, (int)N, (int)N>& in) {
     double cm[N * N];
@@ -114,6 +127,7 @@ class EmIterativeClosestPoint {
     p.k_cov = kCorrespondences_;
     p.epsilon = kEpsilon_;
     p.num_classes = (int32_t)N;
+    p.reuse_features = reuse_features_ ? 1 : 0;
     detail::check(sicp_set_params(h, &p), h, "sicp_set_params");
   }
   void upload(int which, const PointCloudPtr& cloud) {
@@ -127,6 +141,7 @@ class EmIterativeClosestPoint {
   double kEpsilon_;
   int outer_iter;
   bool cm_set_;
+  bool reuse_features_ = false;
   Sophus::SE3d final_transformation_;
   PointCloudPtr source_cloud_, target_cloud_;
   detail::Engine engine_;

@@ -6,8 +6,11 @@
 // Not reproduced: the pcl::GeneralizedIterativeClosestPoint comparison (third-party algorithm), the
 // disabled FPFH bootstrap, and quirk Q7 (the reference hands SE3-GICP the kd-tree of another scan,
 // exec/kitti_eval.cc:213; here every align() sees its own clouds).
-// -b <pairs>: register that many pairs at a time in lock step (alignBatch, sicp_align_batch) instead
-// of one after the other; the rows are the same, the run is several times faster.
+// -b <pairs>: register that many pairs at a time (alignBatch, sicp_align_batch) instead of one after
+// the other; the rows are the same, the run is several times faster.
+// -r: every scan is read, uploaded and indexed ONCE: the source of pair (n, n+3) stays on the GPU and is
+// the target of pair (n+3, n+6) (setTargetCloudSharedWithSourceOf), and its normals / histograms are
+// kept (keepFeatures) instead of being recomputed by both registrations.  Same rows again.
 #include <chrono>
 #include <cstdio>
 #include <fstream>
@@ -28,6 +31,8 @@ int main(int argc, char** argv) {
   const char *dir = arg(argc, argv, "-s"), *gt = arg(argc, argv, "-t"), *cmf = arg(argc, argv, "-m"), *prefix = arg(argc, argv, "-o");
   const char* barg = arg(argc, argv, "-b");
   const size_t batch = barg ? (size_t)std::max(1, std::atoi(barg)) : 1;
+  bool share = false;
+  for (int i = 1; i < argc; ++i) share = share || std::string(argv[i]) == "-r";
   if (!dir) { std::cout << "Need source directory (-s)\n"; return -1; }
   if (!gt) { std::cout << "Need ground truth file (-t)\n"; return -1; }
   if (!cmf) { std::cout << "Need ground confusion matrix file (-m)\n"; return -1; }
@@ -48,7 +53,10 @@ int main(int argc, char** argv) {
       em[b].reset(new Em());
       gi[b].reset(new Gicp());
       em[b]->setConfusionMatrix(cm);
+      em[b]->keepFeatures(share);
+      gi[b]->keepFeatures(share);
     }
+    size_t prev_slot = 0;  // batch slot of the previous pair (its source scan is this pair's target scan)
     std::vector<size_t> starts;
     for (size_t n = 0; n + 3 < pcd_fns.size(); n += 3) starts.push_back(n);  // exec/kitti_eval.cc:124-129
     for (size_t g0 = 0; g0 < starts.size(); g0 += batch) {
@@ -60,23 +68,33 @@ int main(int argc, char** argv) {
       std::vector<Sophus::SE3d> inits(cnt);  // identity (:172-176)
       for (size_t b = 0; b < cnt; ++b) {
         const size_t indxTarget = starts[g0 + b], indxSource = indxTarget + 3;
+        const bool shared = share && g0 + b > 0;  // the target scan is the previous pair's source scan
         pcl::PointCloud<pcl::PointXYZL>::Ptr cloudA(new pcl::PointCloud<pcl::PointXYZL>), cloudB(new pcl::PointCloud<pcl::PointXYZL>);
         if (pcl::io::loadPCDFile<pcl::PointXYZL>(pcd_fns[indxSource], *cloudA) == -1) { std::cerr << "Couldn't read source file\n"; return -1; }
-        if (pcl::io::loadPCDFile<pcl::PointXYZL>(pcd_fns[indxTarget], *cloudB) == -1) { std::cerr << "Couldn't read target file\n"; return -1; }
         filterRange(cloudA, 40.0);  // :138
-        filterRange(cloudB, 40.0);  // :159
         eo[b] = em[b].get();
+        if (shared) {
+          eo[b]->setTargetCloudSharedWithSourceOf(*em[prev_slot]);  // before this slot's own source is replaced
+        } else {
+          if (pcl::io::loadPCDFile<pcl::PointXYZL>(pcd_fns[indxTarget], *cloudB) == -1) { std::cerr << "Couldn't read target file\n"; return -1; }
+          filterRange(cloudB, 40.0);  // :159
+          eo[b]->setTargetCloud(cloudB);
+        }
         eo[b]->setSourceCloud(cloudA);
-        eo[b]->setTargetCloud(cloudB);
         finalEm[b].reset(new pcl::PointCloud<pcl::PointXYZL>);
         // the reference re-loads the files as PointXYZ (:201-204): same points, no labels, no range filter
         pcl::PointCloud<pcl::PointXYZ>::Ptr cloudAnoL(new pcl::PointCloud<pcl::PointXYZ>), cloudBnoL(new pcl::PointCloud<pcl::PointXYZ>);
         pcl::io::loadPCDFile<pcl::PointXYZ>(pcd_fns[indxSource], *cloudAnoL);
-        pcl::io::loadPCDFile<pcl::PointXYZ>(pcd_fns[indxTarget], *cloudBnoL);
         go[b] = gi[b].get();
         go[b]->setSourceCloud(cloudAnoL);
-        go[b]->setTargetCloud(cloudBnoL);
+        if (shared) {
+          go[b]->setTargetCloudSharedWithSourceOf(*gi[prev_slot]);
+        } else {
+          pcl::io::loadPCDFile<pcl::PointXYZ>(pcd_fns[indxTarget], *cloudBnoL);
+          go[b]->setTargetCloud(cloudBnoL);
+        }
         finalGi[b].reset(new pcl::PointCloud<pcl::PointXYZ>);
+        prev_slot = b;
       }
       auto begin = std::chrono::steady_clock::now();
       if (batch == 1) eo[0]->align(finalEm[0], inits[0]);

@@ -41,14 +41,25 @@ class GICP {
     sourceCloud_ = cloud; sourceKdTree_ = tree; sourceCovariances_ = covs;
   }
   inline void setTargetCloud(const PointCloudPtr& cloud) {
+    shared_target_from_ = nullptr;
     targetCloud_ = cloud;
     targetKdTree_ = KdTreePtr(new KdTree());
     targetKdTree_->setInputCloud(targetCloud_);
     targetCovariances_ = MatricesVectorPtr(new MatricesVector());
   }
   inline void setTargetCloud(const PointCloudPtr& cloud, const KdTreePtr& tree, const MatricesVectorPtr& covs) {
+    shared_target_from_ = nullptr;
     targetCloud_ = cloud; targetKdTree_ = tree; targetCovariances_ = covs;
   }
+  // Engine extensions for scan sequences: the target of this registration is the source cloud of
+  // `other` as it lives on the GPU after other's align() (one upload, tree and covariance set per scan;
+  // what the 3-argument overloads above exist for), and keepFeatures(true) keeps the covariances of a
+  // cloud across align() calls instead of recomputing them (impl/gicp.hpp:33-34; same values).
+  inline void setTargetCloudSharedWithSourceOf(GICP& other) {
+    targetCloud_ = other.sourceCloud_;
+    shared_target_from_ = &other;
+  }
+  inline void keepFeatures(bool on) { reuse_features_ = on; }
   inline KdTreePtr getSourceKdTree() { return sourceKdTree_; }
   inline MatricesVectorPtr getSourceCovariances() { fetch_covariances(SICP_SOURCE, sourceCovariances_, source_cov_stale_); return sourceCovariances_; }
   inline KdTreePtr getTargetKdTree() { return targetKdTree_; }
@@ -65,10 +76,9 @@ class GICP {
     detail::check(sicp_default_params(SICP_MODE_GICP, &p), h, "sicp_default_params");
     p.k_cov = kCorrespondences_;
     p.epsilon = epsilon_;
+    p.reuse_features = reuse_features_ ? 1 : 0;
     detail::check(sicp_set_params(h, &p), h, "sicp_set_params");
-    detail::FlatCloud s = detail::flatten(*sourceCloud_), t = detail::flatten(*targetCloud_);
-    detail::check(sicp_set_cloud(h, SICP_SOURCE, s.size(), s.x.data(), s.y.data(), s.z.data(), nullptr), h, "sicp_set_cloud");
-    detail::check(sicp_set_cloud(h, SICP_TARGET, t.size(), t.x.data(), t.y.data(), t.z.data(), nullptr), h, "sicp_set_cloud");
+    upload_clouds(h);
     double out[7];
     int32_t iters = 0;
     detail::check(sicp_align(h, initTransform.data(), out, &iters, nullptr), h, "sicp_align");
@@ -102,10 +112,9 @@ class GICP {
       detail::check(sicp_default_params(SICP_MODE_GICP, &p), h, "sicp_default_params");
       p.k_cov = o.kCorrespondences_;
       p.epsilon = o.epsilon_;
+      p.reuse_features = o.reuse_features_ ? 1 : 0;
       detail::check(sicp_set_params(h, &p), h, "sicp_set_params");
-      detail::FlatCloud s = detail::flatten(*o.sourceCloud_), t = detail::flatten(*o.targetCloud_);
-      detail::check(sicp_set_cloud(h, SICP_SOURCE, s.size(), s.x.data(), s.y.data(), s.z.data(), nullptr), h, "sicp_set_cloud");
-      detail::check(sicp_set_cloud(h, SICP_TARGET, t.size(), t.x.data(), t.y.data(), t.z.data(), nullptr), h, "sicp_set_cloud");
+      o.upload_clouds(h);
       for (int i = 0; i < 7; ++i) init[7 * q + i] = initTransforms[q].data()[i];
     }
     detail::check(sicp_align_batch(hs.data(), (int32_t)n, init.data(), out.data(), iters.data(), nullptr), hs[0], "sicp_align_batch");
@@ -122,6 +131,20 @@ class GICP {
   }
 
  protected:
+  // source: uploaded; target: uploaded, or the device-resident source cloud of another object
+  void upload_clouds(sicp_handle h) {
+    // a shared target refers to the OTHER object's current source: bind it before this object's source
+    // slot is replaced (the other object may be this batch slot's predecessor from the previous batch)
+    if (shared_target_from_)
+      detail::check(sicp_share_cloud(h, SICP_TARGET, shared_target_from_->engine_.get(), SICP_SOURCE), h, "sicp_share_cloud");
+    detail::FlatCloud s = detail::flatten(*sourceCloud_);
+    detail::check(sicp_set_cloud(h, SICP_SOURCE, s.size(), s.x.data(), s.y.data(), s.z.data(), nullptr), h, "sicp_set_cloud");
+    if (!shared_target_from_) {
+      detail::FlatCloud t = detail::flatten(*targetCloud_);
+      detail::check(sicp_set_cloud(h, SICP_TARGET, t.size(), t.x.data(), t.y.data(), t.z.data(), nullptr), h, "sicp_set_cloud");
+    }
+  }
+
   // what align() computed on the GPU (normals -> C = I - (1-eps) n n^T), copied out once per align
   void fetch_covariances(int which, MatricesVectorPtr& out, bool& stale) {
     if (!stale) return;
@@ -142,6 +165,8 @@ class GICP {
   double epsilon_;
   int outer_iter;
   bool source_cov_stale_ = false, target_cov_stale_ = false;
+  bool reuse_features_ = false;
+  GICP* shared_target_from_ = nullptr;
   Sophus::SE3d finalTransformation_;
   PointCloudPtr sourceCloud_;
   KdTreePtr sourceKdTree_;

@@ -136,14 +136,14 @@ def test_kitti_eval_compiles_and_fails_loudly_without_gpu(tmp_path):
 @pytest.mark.gpu
 def test_kitti_eval_headless_rows_match_oracle(tmp_path):
     exe = build_example(tmp_path, "kitti_eval_headless")
-    scans, poses, cm, d, gt, cmf = make_sequence(tmp_path)
+    scans, poses, cm, d, gt, cmf = make_sequence(tmp_path, n_scans=10)
     prefix = str(tmp_path / "out_")
     r = subprocess.run([exe, "-s", d, "-t", gt, "-m", cmf, "-o", prefix], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr
     ident = np.array([0, 0, 0, 1, 0, 0, 0.0])
     for fname, mode in (("EMICPkitti.csv", O.MODE_EM), ("se3GICPkitti.csv", O.MODE_GICP)):
         rows = [[float(v) for v in line.split(",")] for line in open(prefix + fname) if line.strip()]
-        assert [int(r_[0]) for r_ in rows] == [0, 3] and [int(r_[1]) for r_ in rows] == [3, 6]  # stride-3 pairs
+        assert [int(r_[0]) for r_ in rows] == [0, 3, 6] and [int(r_[1]) for r_ in rows] == [3, 6, 9]  # stride-3 pairs
         for row in rows:
             a, b = int(row[0]), int(row[1])
             assert len(row) == 6 + 16 + 16 + 1
@@ -176,6 +176,18 @@ def test_kitti_eval_headless_rows_match_oracle(tmp_path):
         assert len(one) == len(two)
         for ra, rb in zip(one, two):  # every column but the wall time (5) is identical text
             assert ra[:5] == rb[:5] and ra[6:] == rb[6:]
+    # -r: every scan uploaded once and shared between its two registrations, features kept -- alone,
+    # and in batches of 2 (the third pair's target is a cloud left on the GPU by the previous batch)
+    for extra, tag in ((["-r"], "share1_"), (["-b", "2", "-r"], "share2_")):
+        prefix3 = str(tmp_path / tag)
+        r3 = subprocess.run([exe, "-s", d, "-t", gt, "-m", cmf, "-o", prefix3] + extra, capture_output=True, text=True, timeout=900)
+        assert r3.returncode == 0, r3.stderr
+        for fname in ("EMICPkitti.csv", "se3GICPkitti.csv"):
+            one = [line.split(",") for line in open(prefix + fname) if line.strip()]
+            three = [line.split(",") for line in open(prefix3 + fname) if line.strip()]
+            assert len(one) == len(three) == 3
+            for ra, rb in zip(one, three):
+                assert ra[:5] == rb[:5] and ra[6:] == rb[6:]
 
 
 # ------------------------------------------------------------------------------------------------
