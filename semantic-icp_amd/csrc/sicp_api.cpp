@@ -1022,10 +1022,17 @@ int tick_launch(sicp_context* h, TickSet& S, hipStream_t M, sicp_handle* hs, int
   return SICP_OK;
 }
 
+// Wait for the work queued on M so far.  (Polling with hipStreamQuery before blocking, to shorten the
+// wake-up of the host thread, measured no different: 3.76 vs 3.78 ms for one pair alone.)
+int tick_wait(sicp_context* h, hipStream_t M) {
+  HIPCHECK(hipStreamSynchronize(M));
+  return SICP_OK;
+}
+
 int run_tick(sicp_context* h, hipStream_t M, sicp_handle* hs, int n, const std::vector<int>& act, const std::vector<int>& joining,
              const double (*start)[7], int len) {
   SICPCHECK(tick_launch(h, h->ts[0], M, hs, 0, n, act, joining, start, len));
-  HIPCHECK(hipStreamSynchronize(M));
+  SICPCHECK(tick_wait(h, M));
   return SICP_OK;
 }
 
@@ -1386,7 +1393,9 @@ int sicp_align_batch(sicp_handle* hs, int32_t n, const double* init_qt, double* 
   std::vector<OuterState> o(n);
   std::vector<int> phase(n, NEED_SEARCH);
   for (int p = 0; p < n; ++p) std::memcpy(o[p].cur, init_qt + 7 * p, sizeof o[p].cur);
-  const int len = std::min(P.lm_batch > 0 ? P.lm_batch : 12, sicp::kMaxBatchLen);
+  // Tick length: lm_batch evaluations; twice that for up to 4 pairs, where the host's turn-around between
+  // ticks (not the idle tail of a tick: a launch over finished pairs costs ~7 us) is what hurts.
+  const int len = std::min((P.lm_batch > 0 ? P.lm_batch : 12) * (n <= 4 ? 2 : 1), sicp::kMaxBatchLen);
   // Two halves of the batch alternate (from 8 pairs on): while the host reads back one half's tick,
   // tests its pairs for convergence and queues their searches, the other half's tick is running, so the
   // GPU does not idle through the host's turn-around (~60 us per tick).  Each half has its own stream
@@ -1440,7 +1449,7 @@ int sicp_align_batch(sicp_handle* hs, int32_t n, const double* init_qt, double* 
   auto turn = [&](Group& G, JobCollector& jc) -> int {
     sicp_context* h = L;
     if (G.pending) {
-      HIPCHECK(hipStreamSynchronize(G.M));
+      SICPCHECK(tick_wait(h, G.M));
       G.pending = false;
       G.finished.clear();
       for (int p : G.act) {

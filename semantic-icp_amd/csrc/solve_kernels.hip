@@ -143,6 +143,103 @@ __device__ __forceinline__ void loss_eval_acc(double b, double c, double s, doub
   }
 }
 
+// ---- the same per-correspondence arithmetic on TWO slots at once --------------------------------------
+// The launch is bound by FP64 instruction issue, and a slot's arithmetic is one long dependent chain
+// (cofactors -> determinant -> reciprocal -> a -> b -> c -> J, then rsqrt -> reciprocal -> logarithm):
+// at two waves per SIMD the dependent-issue gaps are not filled.  Written on 2-vectors, every operation
+// of the chain appears twice, back to back and independent, so the second fills the first one's gap.
+// Same formulas, same operation order per slot as the scalar functions above.
+typedef double d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ d2 splat(double v) { return d2{v, v}; }
+__device__ __forceinline__ d2 rcp_newton2(d2 d) {
+#pragma clang fp contract(fast)
+  d2 r = d2{__builtin_amdgcn_rcp(d.x), __builtin_amdgcn_rcp(d.y)};
+  r = r + r * (1.0 - d * r);
+  r = r + r * (1.0 - d * r);
+  return r;
+}
+__device__ __forceinline__ d2 log_ge1_2(d2 x) {
+#pragma clang fp contract(fast)
+  d2 m = d2{__builtin_amdgcn_frexp_mant(x.x), __builtin_amdgcn_frexp_mant(x.y)};
+  int k0 = __builtin_amdgcn_frexp_exp(x.x), k1 = __builtin_amdgcn_frexp_exp(x.y);
+  const bool low0 = m.x < 0.70710678118654752440, low1 = m.y < 0.70710678118654752440;
+  m.x = low0 ? m.x + m.x : m.x; m.y = low1 ? m.y + m.y : m.y;
+  k0 = low0 ? k0 - 1 : k0; k1 = low1 ? k1 - 1 : k1;
+  const d2 f = m - 1.0, d = 2.0 + f, dk = d2{(double)k0, (double)k1};
+  const d2 r = rcp_newton2(d);
+  const d2 sq = f * r, z = sq * sq, w = z * z;
+  const d2 t1 = w * (3.999999999940941908e-01 + w * (2.222219843214978396e-01 + w * 1.531383769920937332e-01));
+  const d2 t2 = z * (6.666666666666735130e-01 + w * (2.857142874366239149e-01 + w * (1.818357216161805012e-01 + w * 1.479819860511658591e-01)));
+  const d2 R = t2 + t1, hfsq = 0.5 * f * f;
+  return dk * 6.93147180369123816490e-01 - ((hfsq - (sq * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
+}
+template <bool SQLOSS>
+__device__ __forceinline__ void loss_eval_acc2(double b, double c, d2 s, d2 w, d2& rho0, d2& rho1) {
+#pragma clang fp contract(fast)
+  if (SQLOSS) {
+    const d2 v = s + 2.220446049250313e-16;
+    const d2 y = d2{rsqrt(v.x), rsqrt(v.y)};
+    const d2 g0 = v * y, g1 = 0.5 * y;
+    const d2 sum = 1.0 + g0 * c, invs = rcp_newton2(sum);
+    rho0 = w * (b * log_ge1_2(sum));
+    rho1 = (w * d2{fmax(2.2250738585072014e-308, invs.x), fmax(2.2250738585072014e-308, invs.y)}) * g1;
+  } else {
+    const d2 sum = 1.0 + s * c, invs = rcp_newton2(sum);
+    rho0 = b * log_ge1_2(sum);
+    rho1 = d2{fmax(2.2250738585072014e-308, invs.x), fmax(2.2250738585072014e-308, invs.y)};
+  }
+}
+struct SrcTerms2 {
+  d2 qx, qy, qz, mx, my, mz, d00, d11, d22, n01, n02, n12;
+};
+__device__ __forceinline__ SrcTerms2 pack_src(const SrcTerms& a, const SrcTerms& b) {
+  SrcTerms2 s;
+  s.qx = d2{a.qx, b.qx}; s.qy = d2{a.qy, b.qy}; s.qz = d2{a.qz, b.qz};
+  s.mx = d2{a.mx, b.mx}; s.my = d2{a.my, b.my}; s.mz = d2{a.mz, b.mz};
+  s.d00 = d2{a.d00, b.d00}; s.d11 = d2{a.d11, b.d11}; s.d22 = d2{a.d22, b.d22};
+  s.n01 = d2{a.n01, b.n01}; s.n02 = d2{a.n02, b.n02}; s.n12 = d2{a.n12, b.n12};
+  return s;
+}
+struct Corr2 {
+  d2 r, J[6];
+};
+__device__ __forceinline__ void corr_eval_src2(const Pose& P, double one_m_eps, const SrcTerms2& s, d2 psx, d2 psy, d2 psz, d2 nsx, d2 nsy,
+                                               d2 nsz, d2 ptx, d2 pty, d2 ptz, d2 ntx, d2 nty, d2 ntz, Corr2& o) {
+#pragma clang fp contract(fast)
+  const double* R = P.R;
+  const d2 fx = one_m_eps * ntx, fy = one_m_eps * nty, fz = one_m_eps * ntz;
+  const d2 a00 = s.d00 - fx * ntx;
+  const d2 a01 = s.n01 - fx * nty;
+  const d2 a02 = s.n02 - fx * ntz;
+  const d2 a11 = s.d11 - fy * nty;
+  const d2 a12 = s.n12 - fy * ntz;
+  const d2 a22 = s.d22 - fz * ntz;
+  const d2 rx = ptx - s.qx, ry = pty - s.qy, rz = ptz - s.qz;
+  const d2 k00 = a11 * a22 - a12 * a12;
+  const d2 k01 = a02 * a12 - a01 * a22;
+  const d2 k02 = a01 * a12 - a02 * a11;
+  const d2 k11 = a00 * a22 - a02 * a02;
+  const d2 k12 = a01 * a02 - a00 * a12;
+  const d2 k22 = a00 * a11 - a01 * a01;
+  const d2 det = a00 * k00 + a01 * k01 + a02 * k02;
+  const d2 inv = rcp_newton2(det);
+  const d2 ax = inv * (k00 * rx + k01 * ry + k02 * rz);
+  const d2 ay = inv * (k01 * rx + k11 * ry + k12 * rz);
+  const d2 az = inv * (k02 * rx + k12 * ry + k22 * rz);
+  o.r = rx * ax + ry * ay + rz * az;
+  const d2 bx = R[0] * ax + R[3] * ay + R[6] * az;
+  const d2 by = R[1] * ax + R[4] * ay + R[7] * az;
+  const d2 bz = R[2] * ax + R[5] * ay + R[8] * az;
+  const d2 nb = one_m_eps * (nsx * bx + nsy * by + nsz * bz);
+  const d2 cx = psx + bx - nb * nsx;
+  const d2 cy = psy + by - nb * nsy;
+  const d2 cz = psz + bz - nb * nsz;
+  o.J[0] = -bx; o.J[1] = -by; o.J[2] = -bz;
+  o.J[3] = by * cz - bz * cy;
+  o.J[4] = bz * cx - bx * cz;
+  o.J[5] = bx * cy - by * cx;
+}
+
 // ------------------------------------------------------------------------------------------
 // accumulate: 28 doubles = [H upper 21 | g 6 | cost] over all correspondence slots
 // ------------------------------------------------------------------------------------------
@@ -292,9 +389,55 @@ __device__ __forceinline__ void load_data(const LoadCtx& L, int g, Group<K>& G) 
   for (int c = 0; c < SG; ++c) load_rec(L.trec + max(G.j[c], 0), G.tx[c], G.ty[c], G.tz[c], G.tnx[c], G.tny[c], G.tnz[c]);
 }
 
+#ifndef SICP_VEC2
+#define SICP_VEC2 0  // 1: two slots at a time on 2-vectors (compute_group_pairs; measured: no faster), 0: slot after slot
+#endif
+
+// two slots per pass (slots c, c + 1 of the group; the accumulators take slot c first, then c + 1)
+template <int K, bool SQLOSS>
+__device__ __forceinline__ void compute_group_pairs(const MathCtx& M, const Group<K>& G, double (&acc)[28]) {
+  constexpr int SG = GroupShape<K>::SG, NS = GroupShape<K>::NS;
+  static_assert(SG % 2 == 0, "pairs of slots");
+  SrcTerms st[2];
+#pragma unroll
+  for (int c = 0; c < SG; c += 2) {
+#pragma clang fp contract(fast)
+    const int s0 = NS == 1 ? 0 : c / (SG / NS), s1 = NS == 1 ? 0 : (c + 1) / (SG / NS);
+    if (NS == 1) {
+      if (c == 0) { src_terms(M.P, M.one_m_eps, G.sx[0], G.sy[0], G.sz[0], G.snx[0], G.sny[0], G.snz[0], st[0]); st[1] = st[0]; }
+    } else {
+      src_terms(M.P, M.one_m_eps, G.sx[s0], G.sy[s0], G.sz[s0], G.snx[s0], G.sny[s0], G.snz[s0], st[0]);
+      src_terms(M.P, M.one_m_eps, G.sx[s1], G.sy[s1], G.sz[s1], G.snx[s1], G.sny[s1], G.snz[s1], st[1]);
+    }
+    const SrcTerms2 s2 = pack_src(st[0], st[1]);
+    Corr2 cr;
+    corr_eval_src2(M.P, M.one_m_eps, s2, d2{(double)G.sx[s0], (double)G.sx[s1]}, d2{(double)G.sy[s0], (double)G.sy[s1]},
+                   d2{(double)G.sz[s0], (double)G.sz[s1]}, d2{G.snx[s0], G.snx[s1]}, d2{G.sny[s0], G.sny[s1]}, d2{G.snz[s0], G.snz[s1]},
+                   d2{(double)G.tx[c], (double)G.tx[c + 1]}, d2{(double)G.ty[c], (double)G.ty[c + 1]}, d2{(double)G.tz[c], (double)G.tz[c + 1]},
+                   d2{G.tnx[c], G.tnx[c + 1]}, d2{G.tny[c], G.tny[c + 1]}, d2{G.tnz[c], G.tnz[c + 1]}, cr);
+    d2 rho0, rho1;
+    loss_eval_acc2<SQLOSS>(M.loss_b, M.loss_c, cr.r * cr.r, d2{G.w[c], G.w[c + 1]}, rho0, rho1);
+    if (G.j[c] < 0) { rho0.x = 0.0; rho1.x = 0.0; }  // gated-out slots are weighted by exactly zero
+    if (G.j[c + 1] < 0) { rho0.y = 0.0; rho1.y = 0.0; }
+    const d2 rho4 = 4.0 * rho1, rh = 0.5 * cr.r;
+    int o = 0;
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
+      const d2 jp = rho4 * cr.J[p];
+#pragma unroll
+      for (int q = p; q < 6; ++q) { acc[o] += jp.x * cr.J[q].x; acc[o] += jp.y * cr.J[q].y; ++o; }
+      acc[21 + p] += jp.x * rh.x;
+      acc[21 + p] += jp.y * rh.y;
+    }
+    acc[27] += 0.5 * rho0.x;
+    acc[27] += 0.5 * rho0.y;
+  }
+}
+
 template <int K, bool SQLOSS>
 __device__ __forceinline__ void compute_group(const MathCtx& M, const Group<K>& G, double (&acc)[28]) {
   constexpr int SG = GroupShape<K>::SG, NS = GroupShape<K>::NS;
+  if (SICP_VEC2) { compute_group_pairs<K, SQLOSS>(M, G, acc); return; }
   SrcTerms st;
 #pragma unroll
   for (int c = 0; c < SG; ++c) {
@@ -532,11 +675,15 @@ __device__ __forceinline__ void block_reduce_store_raw(const double (&acc)[28], 
 #pragma unroll
   for (int p0 = 0; p0 < 28; p0 += RED_ROWS) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if !defined(SICP_DEBUG_NOBARRIER)
     __builtin_amdgcn_s_barrier();
+#endif
 #pragma unroll
     for (int k = 0; k < RED_ROWS; ++k) red[k][threadIdx.x] = acc[p0 + k];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if !defined(SICP_DEBUG_NOBARRIER)
     __builtin_amdgcn_s_barrier();
+#endif
     for (int kk = wave; kk < RED_ROWS; kk += NW) {
       double sum = 0.0;
 #pragma unroll
