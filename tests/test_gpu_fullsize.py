@@ -287,7 +287,7 @@ def test_heterogeneous_batch_equals_lone_aligns(mode):
         # at most one partial tick (lm_batch = 8 evaluations) per inner solve
         for _, sb in res:
             assert sb["total_evals"] <= sb["lockstep_slots"] <= sb["total_evals"] + 8 * sb["outer_iters"]
-        assert sum(s["graph_builds"] for _, s in res) <= 1
+        assert sum(s["graph_builds"] for _, s in res) <= 2  # one per tick group (two alternate for 8..48 pairs)
         # a different sub-batch (other leader, other sizes) and the first batch again: same bits,
         # and the instantiated graph is updated in place rather than rebuilt
         res2 = sicp.align_batch(engines[3:11])
