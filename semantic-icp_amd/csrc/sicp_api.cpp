@@ -45,8 +45,10 @@ struct DevBuf {
   hipError_t reserve(size_t n) {
     if (n <= cap) return hipSuccess;
     release();
-    size_t want = n + n / 8 + 64;
-    hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
+    // 64 elements of slack beyond the capacity: kernels that read whole vectors may touch up to one
+    // vector past the last element (the values are never used)
+    size_t want = n + n / 8;
+    hipError_t e = hipMalloc((void**)&p, (want + 64) * sizeof(T));
     if (e != hipSuccess) { p = nullptr; return e; }
     cap = want;
     return hipSuccess;

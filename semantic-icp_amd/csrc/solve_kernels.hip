@@ -331,25 +331,6 @@ __device__ __forceinline__ void load_rec(const SICP_GLOBAL PointRec* r, float& x
   x = b.z; y = b.w; z = c;
 }
 
-// the indices of group g (issued one pipeline stage before the gathers that need their values)
-template <int K>
-__device__ __forceinline__ void load_idx(const LoadCtx& L, int g, int (&j)[GroupShape<K>::SG]) {
-  constexpr int SG = GroupShape<K>::SG;
-  const int e0 = g * SG;
-  if (e0 + SG - 1 < L.total) {
-    if (SG == 4) {
-      const v4i v = *(const SICP_GLOBAL v4i*)(L.idx + e0);
-      j[0] = v.x; j[1] = v.y; j[SG - 2] = v.z; j[SG - 1] = v.w;
-    } else {
-      const v2i v = *(const SICP_GLOBAL v2i*)(L.idx + e0);
-      j[0] = v.x; j[SG - 1] = v.y;
-    }
-  } else {
-#pragma unroll
-    for (int c = 0; c < SG; ++c) j[c] = e0 + c < L.total ? L.idx[e0 + c] : -1;  // ragged tail / past the end: weight 0
-  }
-}
-
 // Unconditional form for the pipelined kernel: always one vector load (from the last group when g lies
 // past the end; the index buffer is allocated with slack, so the SG - 1 entries a ragged last group
 // reads beyond `total` exist), and the "past the end -> -1" fix-up is applied where the values are
@@ -372,21 +353,6 @@ __device__ __forceinline__ void fix_idx(int total, int g, int (&j)[GroupShape<K>
   constexpr int SG = GroupShape<K>::SG;
 #pragma unroll
   for (int c = 0; c < SG; ++c) j[c] = g * SG + c < total ? j[c] : -1;
-}
-
-template <int K>
-__device__ __forceinline__ void load_data(const LoadCtx& L, int g, Group<K>& G) {
-  constexpr int SG = GroupShape<K>::SG, NS = GroupShape<K>::NS;
-  const int e0 = g * SG;
-#pragma unroll
-  for (int c = 0; c < SG; ++c) G.w[c] = L.w ? L.w[max(min(e0 + c, L.total - 1), 0)] : 1.0;
-#pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    const int i = max(min((e0 + s * (SG / NS)) / K, L.n_s - 1), 0);
-    load_rec(L.srec + i, G.sx[s], G.sy[s], G.sz[s], G.snx[s], G.sny[s], G.snz[s]);
-  }
-#pragma unroll
-  for (int c = 0; c < SG; ++c) load_rec(L.trec + max(G.j[c], 0), G.tx[c], G.ty[c], G.tz[c], G.tnx[c], G.tny[c], G.tnz[c]);
 }
 
 #ifndef SICP_VEC2
@@ -467,50 +433,31 @@ __device__ __forceinline__ void compute_group(const MathCtx& M, const Group<K>& 
   }
 }
 
-// The 28 sums of a workgroup -> partials[k][chunk]: transpose through LDS, RED_ROWS rows at a time
-// (28 rows at once would be 56 KB), wave w sums rows w, w + 4, ... with DPP.  Fixed order.
-#ifndef SICP_RED_ROWS
-#define SICP_RED_ROWS 14
-#endif
-constexpr int RED_ROWS = SICP_RED_ROWS;  // divides 28
-template <int BS>
-__device__ __forceinline__ void block_reduce_store(const double (&acc)[28], double (&red)[RED_ROWS][BS], SICP_GLOBAL double* partials,
-                                                   int n_chunks, int chunk) {
-  constexpr int NW = BS / 64;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int p0 = 0; p0 < 28; p0 += RED_ROWS) {
-    __syncthreads();  // the previous round's (or the previous chunk's) reads are done
-#pragma unroll
-    for (int k = 0; k < RED_ROWS; ++k) red[k][threadIdx.x] = acc[p0 + k];
-    __syncthreads();
-    for (int kk = wave; kk < RED_ROWS; kk += NW) {
-      double sum = 0.0;
-#pragma unroll
-      for (int t = 0; t < NW; ++t) sum += red[kk][lane + 64 * t];
-      sum = wave_sum(sum);
-      if (lane == 0) partials[(size_t)(p0 + kk) * n_chunks + chunk] = sum;
-    }
-  }
-}
-
-__device__ __forceinline__ void load_ctx_from_args(const AccArgs& a, LoadCtx& L, MathCtx& M) {
-  L.idx = (const SICP_GLOBAL int*)a.idx;
-  L.w = (const SICP_GLOBAL double*)a.w;
-  L.srec = (const SICP_GLOBAL PointRec*)a.srec;
-  L.trec = (const SICP_GLOBAL PointRec*)a.trec;
-  L.n_s = a.n_s;
-  L.total = a.n_s * a.K;
-  M.one_m_eps = a.one_m_eps;
-  M.loss_b = a.loss.cauchy_a * a.loss.cauchy_a;
-  M.loss_c = 1.0 / M.loss_b;
-}
-
 // ------------------------------------------------------------------------------------------
-// Lock-step batch (sicp_align_batch): ONE launch evaluates the current LM pose of every pair that
-// still iterates.  Persistent workgroups (2 per CU) walk over the flattened list of (pair, chunk)
-// items, item = blockIdx.x, + gridDim.x, ...; the per-pair constants (pointers, rotation of the
-// current LM pose, loss) are staged in LDS once per workgroup.
+// The batched evaluation (every path: a pair alone is a batch of one).  ONE launch evaluates the
+// current LM pose of every pair of the tick that still iterates.
+//
+// Work split.  gridDim.x persistent workgroups (SICP_ACC_OCC per CU) split the chunks of the RUNNING
+// pairs -- counted on the device from the LM states, so a pair that finished inside a tick costs
+// nothing and unbalances nothing -- into equal CONTIGUOUS ranges.  A range is a few segments (runs of
+// chunks of one pair; mostly one).  Inside a segment the pair's constants live in SGPRs and a lane's
+// group index advances by the workgroup size: nothing is located, re-read or re-broadcast per step.
+//
+// Pipeline.  At two waves per SIMD plain wave interleaving hides about half of an index -> gather
+// chain, and a second register set for the next group does not fit beside the 28 accumulators.  So the
+// next group's TARGET records (36 gathered bytes x SG per lane) are fetched by LDS-DMA
+// (global_load_lds: no destination registers) into a wave-private staging area while the current
+// group is computed from registers; only the next group's indices, weights and source record travel
+// through registers.  Per lane and step:
+//     wait for everything issued a step ago | staging area -> registers | issue: LDS-DMA of group
+//     t+1's targets, loads of its weights / source, indices of group t+2 | compute group t
+//
+// Reduction.  A wave sums its OWN 64 lanes' 28 accumulators at the end of every chunk and writes one
+// column of partials[28][4 n_chunks] (column 4 chunk + wave): transposed through a wave-private LDS
+// tile, RED_ROWS rows at a time -- lane (r, q) adds up quarter q of row r in ascending order, one DPP
+// quad reduction joins the quarters.  No workgroup barrier anywhere in the loop: a block-wide
+// reduction (barrier | write | barrier | read, twice per chunk) cost 21 % of the launch, far more than
+// its instructions, because every barrier re-synchronises four waves whose memory waits differ.
 // ------------------------------------------------------------------------------------------
 struct PairCtx {
   const int* idx;
@@ -534,7 +481,7 @@ __device__ __forceinline__ void stage_pair_constants(const BatchArgs* __restrict
     c.n_s = a.n_s; c.total = a.n_s * a.K;
     const AccGeometry geo = acc_geometry(c.total, GroupShape<K>::SG);
     c.steps = geo.steps; c.chunk_groups = geo.chunk_groups; c.n_chunks = geo.n_chunks;
-    c.item_begin = B.item_begin;
+    c.item_begin = 0;
     c.pad_ = 0;
     Pose P;
     if (a.lm) {
@@ -556,74 +503,6 @@ __device__ __forceinline__ void stage_pair_constants(const BatchArgs* __restrict
   }
 }
 
-template <int K, bool SQLOSS, int BS>
-__global__ __launch_bounds__(BS, 2) void accumulate_stream_kernel(const BatchHeader* __restrict__ hdr, const BatchArgs* __restrict__ batch) {
-  extern __shared__ double smem[];
-  double (&red)[RED_ROWS][BS] = *reinterpret_cast<double (*)[RED_ROWS][BS]>(smem);
-  PairCtx* ctx = reinterpret_cast<PairCtx*>(smem + RED_ROWS * BS);
-  const int n_pairs = hdr->n_pairs, n_items = hdr->n_items;
-  if ((int)blockIdx.x >= n_items) return;
-  stage_pair_constants<K, BS>(batch, n_pairs, ctx);
-  __syncthreads();
-
-  const int G = (int)gridDim.x;
-  MathCtx M;
-  LoadCtx L;
-  int cur_pair = -1;
-  for (int item = (int)blockIdx.x; item < n_items; item += G) {
-    // item -> pair: last pair whose first item is <= item (uniform binary search in LDS)
-    int lo = 0, hi = n_pairs - 1;
-    while (lo < hi) {
-      const int mid = (lo + hi + 1) >> 1;
-      if (ctx[mid].item_begin <= item) lo = mid; else hi = mid - 1;
-    }
-    const int pair = uniform_i32(lo);
-    const PairCtx& p = ctx[pair];
-    if (!p.running) continue;  // the pair's solve has finished: its chunks are stepped over
-    if (pair != cur_pair) {
-      L.idx = (const SICP_GLOBAL int*)uniform_ptr(p.idx);
-      L.w = (const SICP_GLOBAL double*)uniform_ptr(p.w);
-      L.srec = (const SICP_GLOBAL PointRec*)uniform_ptr(p.srec);
-      L.trec = (const SICP_GLOBAL PointRec*)uniform_ptr(p.trec);
-      L.n_s = uniform_i32(p.n_s);
-      L.total = uniform_i32(p.total);
-#pragma unroll
-      for (int k = 0; k < 9; ++k) M.P.R[k] = uniform_f64(p.R[k]);
-#pragma unroll
-      for (int k = 0; k < 3; ++k) M.P.t[k] = uniform_f64(p.t[k]);
-      M.one_m_eps = uniform_f64(p.one_m_eps); M.loss_b = uniform_f64(p.loss_b); M.loss_c = uniform_f64(p.loss_c);
-      cur_pair = pair;
-    }
-    const int chunk = uniform_i32(item - p.item_begin);
-    const int g0 = chunk * uniform_i32(p.chunk_groups) + (int)threadIdx.x;
-    const int two_m = uniform_i32(p.steps);
-    double acc[28];
-#pragma unroll
-    for (int k = 0; k < 28; ++k) acc[k] = 0.0;
-    for (int s = 0; s < two_m; s += 2) {
-      Group<K> A, B;
-      load_idx<K>(L, g0 + s * BS, A.j);
-      load_idx<K>(L, g0 + (s + 1) * BS, B.j);
-      load_data<K>(L, g0 + s * BS, A);
-      load_data<K>(L, g0 + (s + 1) * BS, B);
-      compute_group<K, SQLOSS>(M, A, acc);
-      compute_group<K, SQLOSS>(M, B, acc);
-    }
-    block_reduce_store<BS>(acc, red, (SICP_GLOBAL double*)uniform_ptr(p.partials), uniform_i32(p.n_chunks), chunk);
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// The same walk, software pipelined through LDS.  At two waves per SIMD plain wave interleaving
-// hides about half of an index -> gather chain, and a second register set for the next group does
-// not fit beside the 28 accumulators.  So the next group's TARGET records (the 36 gathered bytes x SG
-// per lane) are fetched by LDS-DMA (global_load_lds: no destination registers) into a wave-private
-// staging area while the current group is computed from registers; only the next group's indices,
-// weights and source record travel through registers.  Per lane and step:
-//     wait for everything issued a step ago | staging area -> registers | issue: LDS-DMA of group
-//     t+1's targets, loads of its weights / source, indices of group t+2 | compute group t
-// The chunk-end reduction uses raw s_barrier + lgkmcnt waits, so the DMA stays in flight across it.
-// ------------------------------------------------------------------------------------------
 #define SICP_LDS __attribute__((address_space(3)))
 constexpr int STAGE_SLOT_BYTES = 64 * 36;  // one target record of every lane of a wave: 1024 + 1024 + 256
 
@@ -654,11 +533,21 @@ struct GroupRegs {
 };
 
 template <int K>
-__device__ __forceinline__ void load_regs(const LoadCtx& L, int g, GroupRegs<K>& G) {
+__device__ __forceinline__ void load_regs(const LoadCtx& L, int last, int g, GroupRegs<K>& G) {
   constexpr int SG = GroupShape<K>::SG, NS = GroupShape<K>::NS;
-  const int e0 = g * SG;
+  const int e0 = max(min(g * SG, last), 0);  // whole vectors: the buffers carry slack past `total` (DevBuf)
+  if (L.w) {
+    if (SG == 4) {
+      const v2d a = *(const SICP_GLOBAL v2d*)(L.w + e0), b = *(const SICP_GLOBAL v2d*)(L.w + e0 + 2);
+      G.w[0] = a.x; G.w[1] = a.y; G.w[SG - 2] = b.x; G.w[SG - 1] = b.y;
+    } else {
+      const v2d a = *(const SICP_GLOBAL v2d*)(L.w + e0);
+      G.w[0] = a.x; G.w[SG - 1] = a.y;
+    }
+  } else {
 #pragma unroll
-  for (int c = 0; c < SG; ++c) G.w[c] = L.w ? L.w[max(min(e0 + c, L.total - 1), 0)] : 1.0;
+    for (int c = 0; c < SG; ++c) G.w[c] = 1.0;
+  }
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     const int i = max(min((e0 + s * (SG / NS)) / K, L.n_s - 1), 0);
@@ -666,192 +555,210 @@ __device__ __forceinline__ void load_regs(const LoadCtx& L, int g, GroupRegs<K>&
   }
 }
 
-// block reduction with raw barriers (a __syncthreads would drain the LDS-DMA queue)
-template <int BS>
-__device__ __forceinline__ void block_reduce_store_raw(const double (&acc)[28], double (&red)[RED_ROWS][BS], SICP_GLOBAL double* partials,
-                                                       int n_chunks, int chunk) {
-  constexpr int NW = BS / 64;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// The 28 sums of ONE WAVE -> column `col` of partials[28][n_cols].  tile = this wave's
+// [RED_ROWS][RED_STRIDE] doubles of LDS.  Lane l writes its accumulators into column l of the tile; lane
+// (r = l / 4, q = l % 4) then adds elements 16 q .. 16 q + 15 of row r in ascending order, and the four
+// quarters of a row are joined as (q0 + q1) + (q2 + q3).  Same-wave LDS accesses execute in program
+// order, so no barrier is involved: the fences only pin the compiler.  RED_STRIDE = 66: even (16-byte
+// reads stay aligned) and not a multiple of the 32 8-byte banks (the quarter reads of the 56 active
+// lanes spread over all banks: ~4 lanes per 16-byte slot, the minimum for 64 lanes x 16 bytes).
+#ifndef SICP_RED_ROWS
+#define SICP_RED_ROWS 14
+#endif
+constexpr int RED_ROWS = SICP_RED_ROWS;  // divides 28; RED_ROWS * 4 <= 64 lanes
+constexpr int RED_STRIDE = 66;
+static_assert(28 % RED_ROWS == 0 && RED_ROWS * 4 <= 64, "one lane per (row, quarter)");
+__device__ __forceinline__ void wave_reduce_store(const double (&acc)[28], SICP_LDS double* tile, SICP_GLOBAL double* partials, int n_cols,
+                                                  int col, int lane) {
+  const int r = lane >> 2, q = lane & 3;
+  const SICP_LDS v2d* mine = (const SICP_LDS v2d*)(tile + min(r, RED_ROWS - 1) * RED_STRIDE + 16 * q);
 #pragma unroll
   for (int p0 = 0; p0 < 28; p0 += RED_ROWS) {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#if !defined(SICP_DEBUG_NOBARRIER)
-    __builtin_amdgcn_s_barrier();
-#endif
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 #pragma unroll
-    for (int k = 0; k < RED_ROWS; ++k) red[k][threadIdx.x] = acc[p0 + k];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#if !defined(SICP_DEBUG_NOBARRIER)
-    __builtin_amdgcn_s_barrier();
-#endif
-    for (int kk = wave; kk < RED_ROWS; kk += NW) {
-      double sum = 0.0;
+    for (int k = 0; k < RED_ROWS; ++k) tile[k * RED_STRIDE + lane] = acc[p0 + k];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    v2d v[8];
 #pragma unroll
-      for (int t = 0; t < NW; ++t) sum += red[kk][lane + 64 * t];
-      sum = wave_sum(sum);
-      if (lane == 0) partials[(size_t)(p0 + kk) * n_chunks + chunk] = sum;
-    }
+    for (int m = 0; m < 8; ++m) v[m] = mine[m];
+    double s = 0.0;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) { s += v[m].x; s += v[m].y; }
+    s += dpp_f64<0xB1>(s);  // quad_perm:[1,0,3,2]
+    s += dpp_f64<0x4E>(s);  // quad_perm:[2,3,0,1]
+    if (q == 0 && r < RED_ROWS) partials[(size_t)(p0 + r) * n_cols + col] = s;
+    __builtin_amdgcn_wave_barrier();
   }
 }
-
-// position of a workgroup's walk: item (workgroup-uniform), sub-group s inside the chunk
-struct Cursor {
-  int item, s, pair, chunk, two_m;
-  bool valid;
-};
 
 template <int K, bool SQLOSS, int BS>
 __global__ __launch_bounds__(BS, SICP_ACC_OCC) void accumulate_staged_kernel(const BatchHeader* __restrict__ hdr, const BatchArgs* __restrict__ batch) {
   constexpr int SG = GroupShape<K>::SG, NS = GroupShape<K>::NS, NW = BS / 64;
-  extern __shared__ double smem[];  // ONE shared object: [reduction rows | staging | per-pair constants]
-  double (&red)[RED_ROWS][BS] = *reinterpret_cast<double (*)[RED_ROWS][BS]>(smem);
-  char* stage_all = reinterpret_cast<char*>(smem + RED_ROWS * BS);
+  extern __shared__ __attribute__((aligned(16))) double smem[];  // ONE shared object: [reduction tiles | staging | per-pair constants]
+  __shared__ int total_running;
+  char* stage_all = reinterpret_cast<char*>(smem + NW * RED_ROWS * RED_STRIDE);
   PairCtx* ctx = reinterpret_cast<PairCtx*>(stage_all + NW * SG * STAGE_SLOT_BYTES);
-  const int n_pairs = hdr->n_pairs, n_items = hdr->n_items;
-  if ((int)blockIdx.x >= n_items) return;
+  const int n_pairs = hdr->n_pairs;
+  if (n_pairs <= 0) return;
   stage_pair_constants<K, BS>(batch, n_pairs, ctx);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = uniform_i32((int)(threadIdx.x >> 6));
-  SICP_LDS char* stage = (SICP_LDS char*)stage_all + wave * (SG * STAGE_SLOT_BYTES);
-
-  const int G = (int)gridDim.x;
-  auto locate = [&](Cursor& c) {
-    c.valid = c.item < n_items;
-    if (!c.valid) return;
-    int lo = 0, hi = n_pairs - 1;
-    while (lo < hi) {
-      const int mid = (lo + hi + 1) >> 1;
-      if (ctx[mid].item_begin <= c.item) lo = mid; else hi = mid - 1;
-    }
-    c.pair = uniform_i32(lo);
-    c.chunk = uniform_i32(c.item - ctx[lo].item_begin);
-    c.two_m = uniform_i32(ctx[lo].steps);
-  };
-  auto advance = [&](Cursor& c) {  // next group of the walk; chunks of finished pairs are stepped over
-    if (++c.s < c.two_m) return;
-    c.s = 0;
-    for (;;) {
-      c.item += G;
-      locate(c);
-      if (!c.valid || ctx[c.pair].running) return;
-    }
-  };
-  auto load_ctx = [&](const Cursor& c, LoadCtx& L) {
-    const PairCtx& p = ctx[c.pair];
-    L.idx = (const SICP_GLOBAL int*)uniform_ptr(p.idx);
-    L.w = (const SICP_GLOBAL double*)uniform_ptr(p.w);
-    L.srec = (const SICP_GLOBAL PointRec*)uniform_ptr(p.srec);
-    L.trec = (const SICP_GLOBAL PointRec*)uniform_ptr(p.trec);
-    L.n_s = uniform_i32(p.n_s);
-    L.total = uniform_i32(p.total);
-  };
-  auto group_of = [&](const Cursor& c) { return c.chunk * uniform_i32(ctx[c.pair].chunk_groups) + c.s * BS + (int)threadIdx.x; };
-  // hdr->pad_[0] (developer aid, SICP_ACC_DEBUG_NOGATHER): every gather reads target 0, i.e. the launch
-  // without its memory traffic -- what is left is the arithmetic's own time.  Results are wrong.
-  const int gather_mask = uniform_i32(hdr->pad_[0]) ? 0 : -1;
-  auto issue_targets = [&](const LoadCtx& L, const int (&j)[SG]) {
+  // item_begin[p] := number of chunks of RUNNING pairs before pair p (wave 0: a few pairs per lane, then
+  // a scan over the lanes)
+  if (threadIdx.x < 64) {
+    const int per = (n_pairs + 63) / 64, p0 = lane * per, p1 = min(p0 + per, n_pairs);
+    int mine = 0;
+    for (int p = p0; p < p1; ++p) mine += ctx[p].running ? ctx[p].n_chunks : 0;
+    int incl = mine;
 #pragma unroll
-    for (int c = 0; c < SG; ++c) lds_dma_rec(L.trec + (max(j[c], 0) & gather_mask), stage + c * STAGE_SLOT_BYTES);
-  };
+    for (int off = 1; off < 64; off <<= 1) {
+      const int v = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += v;
+    }
+    int base = incl - mine;
+    for (int p = p0; p < p1; ++p) {
+      ctx[p].item_begin = base;
+      base += ctx[p].running ? ctx[p].n_chunks : 0;
+    }
+    if (lane == 63) total_running = incl;
+  }
+  __syncthreads();
+  // equal ranges; with fewer chunks than workgroups, one chunk each for the FIRST workgroups (they are
+  // dispatched to different CUs; spreading b * T / G would put two working groups on some CUs and none
+  // on others).  T <= 128 pairs x 1024 chunks and gridDim.x < 2^12: the products fit 32 bits.
+  const unsigned T = (unsigned)total_running, G = gridDim.x, b = blockIdx.x;
+  int item = T < G ? (int)b : (int)(b * T / G);
+  const int item_end = T < G ? (b < T ? (int)b + 1 : (int)b) : (int)((b + 1) * T / G);
+  if (item >= item_end) return;
+  SICP_LDS char* stage = (SICP_LDS char*)stage_all + wave * (SG * STAGE_SLOT_BYTES);
+  SICP_LDS double* tile = (SICP_LDS double*)smem + wave * (RED_ROWS * RED_STRIDE);
 
-  Cursor cC;  // the group being computed
-  cC.item = (int)blockIdx.x; cC.s = 0;
-  locate(cC);
-  while (cC.valid && !ctx[cC.pair].running) { cC.item += G; locate(cC); }
-  if (!cC.valid) return;
-  Cursor cN = cC;  // the group whose targets are fetched next
-  advance(cN);
-  Cursor cN2 = cN;  // the group whose indices are fetched next
-  if (cN.valid) advance(cN2);
-
+  double acc[28];
+#pragma unroll
+  for (int k = 0; k < 28; ++k) acc[k] = 0.0;
   // Two sets of the register-borne part alternate as "current" and "next" (the step below is
   // instantiated twice with the roles swapped): a copy `current = next` would be scheduled into the
   // arithmetic and wait there for the very loads it is meant to overlap.
   GroupRegs<K> R0, R1;
-  {
-    LoadCtx L;
-    load_ctx(cC, L);
-    load_idx_raw<K>(L, group_of(cC), R0.j);
-    {
-      const Cursor eN = cN.valid ? cN : cC;
-      LoadCtx Ln;
-      load_ctx(eN, Ln);
-      load_idx_raw<K>(Ln, group_of(eN), R1.j);
-    }
-    fix_idx<K>(L.total, group_of(cC), R0.j);
-    issue_targets(L, R0.j);
-    load_regs<K>(L, group_of(cC), R0);
-  }
-  MathCtx M;
-  int math_pair = -1;
-  double acc[28];
-#pragma unroll
-  for (int k = 0; k < 28; ++k) acc[k] = 0.0;
 
-  auto step = [&](GroupRegs<K>& cur, GroupRegs<K>& nxt) -> bool {
-    // (A) everything issued a step ago has landed.  The empty asm statements "use" every register a
-    // load of the previous step wrote: hipcc places its own (conservative, vmcnt(0)) wait for them
-    // here, where nothing is in flight, instead of at their first arithmetic use below -- where it
-    // would drain the loads issued in (B).
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int c = 0; c < SG; ++c) { asm volatile("" : "+v"(cur.w[c]), "+v"(nxt.j[c])); }
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      asm volatile("" : "+v"(cur.sx[s]), "+v"(cur.sy[s]), "+v"(cur.sz[s]), "+v"(cur.snx[s]), "+v"(cur.sny[s]), "+v"(cur.snz[s]));
+  while (item < item_end) {
+    // the pair this item belongs to: the last one that begins at or before it (always a running one)
+    int lo = 0, hi = n_pairs - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (ctx[mid].item_begin <= item) lo = mid; else hi = mid - 1;
     }
-    Group<K> Gc;
+    const PairCtx& pc = ctx[uniform_i32(lo)];
+    const int chunk_lo = uniform_i32(item - pc.item_begin);
+    const int n_chunks = uniform_i32(pc.n_chunks), steps = uniform_i32(pc.steps);
+    const int n_here = min(n_chunks - chunk_lo, item_end - item);
+    const int nsteps = n_here * steps;
+    LoadCtx L;
+    L.idx = (const SICP_GLOBAL int*)uniform_ptr(pc.idx);
+    L.w = (const SICP_GLOBAL double*)uniform_ptr(pc.w);
+    L.srec = (const SICP_GLOBAL PointRec*)uniform_ptr(pc.srec);
+    L.trec = (const SICP_GLOBAL PointRec*)uniform_ptr(pc.trec);
+    L.n_s = uniform_i32(pc.n_s);
+    L.total = uniform_i32(pc.total);
+    const int last = ((L.total - 1) / SG) * SG;
+    SICP_GLOBAL double* partials = (SICP_GLOBAL double*)uniform_ptr(pc.partials);
+    MathCtx M;
 #pragma unroll
-    for (int c = 0; c < SG; ++c) {
-      Gc.j[c] = cur.j[c]; Gc.w[c] = cur.w[c];
-      lds_read_rec(stage + c * STAGE_SLOT_BYTES, lane, Gc.tx[c], Gc.ty[c], Gc.tz[c], Gc.tnx[c], Gc.tny[c], Gc.tnz[c]);
+    for (int k = 0; k < 9; ++k) M.P.R[k] = uniform_f64(pc.R[k]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) M.P.t[k] = uniform_f64(pc.t[k]);
+    M.one_m_eps = uniform_f64(pc.one_m_eps); M.loss_b = uniform_f64(pc.loss_b); M.loss_c = uniform_f64(pc.loss_c);
+
+    int g = chunk_lo * uniform_i32(pc.chunk_groups) + (int)threadIdx.x;  // this lane's group; + BS per step
+    int t = 0, in_chunk = 0, chunk = chunk_lo;
+    auto issue_targets = [&](const int (&j)[SG]) {
+#pragma unroll
+#if defined(SICP_DEBUG_NOGATHER)  // developer aid: every gather reads target 0 (results are wrong)
+      for (int c = 0; c < SG; ++c) lds_dma_rec(L.trec + (max(j[c], 0) & 0), stage + c * STAGE_SLOT_BYTES);
+#else
+      for (int c = 0; c < SG; ++c) lds_dma_rec(L.trec + max(j[c], 0), stage + c * STAGE_SLOT_BYTES);
+#endif
+    };
+    // fill: indices of the first two groups, then targets / weights / source of the first
+    load_idx_raw<K>(L, g, R0.j);
+    load_idx_raw<K>(L, g + BS, R1.j);
+    fix_idx<K>(L.total, g, R0.j);
+    issue_targets(R0.j);
+    load_regs<K>(L, last, g, R0);
+
+    auto step = [&](GroupRegs<K>& cur, GroupRegs<K>& nxt) -> bool {
+      // (A) everything issued a step ago has landed.  The empty asm statements "use" every register a
+      // load of the previous step wrote: hipcc places its own (conservative, vmcnt(0)) wait for them
+      // here, where nothing is in flight, instead of at their first arithmetic use below -- where it
+      // would drain the loads issued in (B).
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int c = 0; c < SG; ++c) { asm volatile("" : "+v"(cur.w[c]), "+v"(nxt.j[c])); }
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        asm volatile("" : "+v"(cur.sx[s]), "+v"(cur.sy[s]), "+v"(cur.sz[s]), "+v"(cur.snx[s]), "+v"(cur.sny[s]), "+v"(cur.snz[s]));
+      }
+      Group<K> Gc;
+#pragma unroll
+      for (int c = 0; c < SG; ++c) {
+        Gc.j[c] = cur.j[c]; Gc.w[c] = cur.w[c];
+        lds_read_rec(stage + c * STAGE_SLOT_BYTES, lane, Gc.tx[c], Gc.ty[c], Gc.tz[c], Gc.tnx[c], Gc.tny[c], Gc.tnz[c]);
+      }
+#pragma unroll
+      for (int s = 0; s < NS; ++s) { Gc.sx[s] = cur.sx[s]; Gc.sy[s] = cur.sy[s]; Gc.sz[s] = cur.sz[s]; Gc.snx[s] = cur.snx[s]; Gc.sny[s] = cur.sny[s]; Gc.snz[s] = cur.snz[s]; }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the staging area may be overwritten
+      // (B) the next group's traffic, and the indices of the group after it.  Unconditional: a load
+      // under a branch merges with the "not taken" value in a register copy, which is a use of the load
+      // -- the compiler would wait for it right here.  Past the end of the segment the fetch is target
+      // 0 of dead slots, and is never computed.
+      const bool more = t + 1 < nsteps;
+      fix_idx<K>(more ? L.total : 0, g + BS, nxt.j);
+      issue_targets(nxt.j);
+      load_regs<K>(L, last, g + BS, nxt);
+      load_idx_raw<K>(L, g + 2 * BS, cur.j);
+      // nothing of (B) may sink into the arithmetic: left alone, the scheduler issues the source-record
+      // and index loads half way through / near the end of the step (shorter live ranges), which leaves
+      // them a fraction of a step to land before (A) of the next step waits for them
+      __builtin_amdgcn_sched_barrier(0);
+      // (C) the arithmetic of the current group
+#if defined(SICP_DEBUG_NOCOMPUTE)  // developer aid: the memory pipeline alone (every loaded value is consumed once)
+#pragma unroll
+      for (int c = 0; c < SG; ++c) acc[c] += (double)(Gc.tx[c] + Gc.ty[c] + Gc.tz[c]) + Gc.tnx[c] + Gc.tny[c] + Gc.tnz[c] + Gc.w[c] + (double)Gc.j[c];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) acc[8 + s] += (double)(Gc.sx[s] + Gc.sy[s] + Gc.sz[s]) + Gc.snx[s] + Gc.sny[s] + Gc.snz[s];
+#else
+      compute_group<K, SQLOSS>(M, Gc, acc);
+#endif
+      if (++in_chunk == steps) {  // the chunk is complete
+#if defined(SICP_DEBUG_NOREDUCE)  // developer aid: no LDS transpose / DPP, all 28 sums stay live
+        {
+          double chk = 0.0;
+#pragma unroll
+          for (int k = 0; k < 28; ++k) chk += acc[k];
+          if (chk == 1.2345e300) partials[chunk] = chk;
+        }
+#else
+        wave_reduce_store(acc, tile, partials, n_chunks * NW, chunk * NW + wave, lane);
+#endif
+#pragma unroll
+        for (int k = 0; k < 28; ++k) acc[k] = 0.0;
+        in_chunk = 0;
+        ++chunk;
+      }
+      g += BS;
+      ++t;
+      return more;
+    };
+    for (;;) {
+      if (!step(R0, R1)) break;
+      if (!step(R1, R0)) break;
     }
-#pragma unroll
-    for (int s = 0; s < NS; ++s) { Gc.sx[s] = cur.sx[s]; Gc.sy[s] = cur.sy[s]; Gc.sz[s] = cur.sz[s]; Gc.snx[s] = cur.snx[s]; Gc.sny[s] = cur.sny[s]; Gc.snz[s] = cur.snz[s]; }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the staging area may be overwritten
-    // (B) the next group's traffic; the indices of the group after it replace the current ones.
-    // Unconditional: a load under a branch merges with the "not taken" value in a register copy,
-    // which is a use of the load -- the compiler would wait for it right here.  Past the end of the
-    // walk the current group is simply fetched again (with indices -1) and never computed.
-    {
-      const Cursor eN = cN.valid ? cN : cC, eN2 = cN2.valid ? cN2 : cC;
-      LoadCtx L, L2;
-      load_ctx(eN, L);
-      load_ctx(eN2, L2);
-      fix_idx<K>(cN.valid ? L.total : 0, group_of(eN), nxt.j);
-      issue_targets(L, nxt.j);
-      load_regs<K>(L, group_of(eN), nxt);
-      load_idx_raw<K>(L2, group_of(eN2), cur.j);
-    }
-    // (C) the arithmetic of the current group
-    if (cC.pair != math_pair) {
-      const PairCtx& p = ctx[cC.pair];
-#pragma unroll
-      for (int k = 0; k < 9; ++k) M.P.R[k] = uniform_f64(p.R[k]);
-#pragma unroll
-      for (int k = 0; k < 3; ++k) M.P.t[k] = uniform_f64(p.t[k]);
-      M.one_m_eps = uniform_f64(p.one_m_eps); M.loss_b = uniform_f64(p.loss_b); M.loss_c = uniform_f64(p.loss_c);
-      math_pair = cC.pair;
-    }
-    compute_group<K, SQLOSS>(M, Gc, acc);
-    if (cC.s == cC.two_m - 1) {  // the chunk is complete
-      const PairCtx& p = ctx[cC.pair];
-      block_reduce_store_raw<BS>(acc, red, (SICP_GLOBAL double*)uniform_ptr(p.partials), uniform_i32(p.n_chunks), cC.chunk);
-#pragma unroll
-      for (int k = 0; k < 28; ++k) acc[k] = 0.0;
-    }
-    if (!cN.valid) return false;
-    cC = cN; cN = cN2;
-    if (cN2.valid) advance(cN2);
-    return true;
-  };
-  for (;;) {
-    if (!step(R0, R1)) break;
-    if (!step(R1, R0)) break;
+    item += n_here;
   }
 }
 
-// fixed-order sum of the chunk partials (layout [28][n_chunks]) by one wave: every lane owns chunks
+// fixed-order sum of the partial columns (layout [28][n_blocks]) by one wave: every lane owns columns
 // lane, lane+64, ... ; the 28 loads of one trip are independent and coalesced
 __device__ __forceinline__ void reduce_partials(const double* __restrict__ partials, int n_blocks, int lane, double (&o)[28]) {
   double s[28];
@@ -965,25 +872,11 @@ hipError_t launch_se3_ops(int op, int n, const double* in, double* out, hipStrea
 // ------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------
-int accumulate_blocks(int total, int K) { return acc_geometry(total, acc_slots_per_group(K)).n_chunks; }
+// columns of partials[28][.]: one per (chunk, wave of the workgroup that sums it)
+int accumulate_blocks(int total, int K) { return 4 * acc_geometry(total, acc_slots_per_group(K)).n_chunks; }
 
 // ---- the batched evaluation --------------------------------------------------------------------
-// SICP_ACC_VARIANT (tuning aid): 1 = LDS-staged software pipeline (default), 0 = plain persistent walk.
-// Same chunks, same additions: the two produce the same bits.
-static int accumulate_variant() {
-  static const int v = [] { const char* e = getenv("SICP_ACC_VARIANT"); return e ? atoi(e) : 1; }();
-  return v;
-}
-
 static void* accumulate_stream_fn(int K, int use_sqloss) {
-  if (accumulate_variant() == 0) {
-    switch (K) {
-      case 1: return use_sqloss ? (void*)accumulate_stream_kernel<1, true, 256> : (void*)accumulate_stream_kernel<1, false, 256>;
-      case 4: return use_sqloss ? (void*)accumulate_stream_kernel<4, true, 256> : (void*)accumulate_stream_kernel<4, false, 256>;
-      case 20: return use_sqloss ? (void*)accumulate_stream_kernel<20, true, 256> : (void*)accumulate_stream_kernel<20, false, 256>;
-      default: return nullptr;
-    }
-  }
   switch (K) {
     case 1: return use_sqloss ? (void*)accumulate_staged_kernel<1, true, 256> : (void*)accumulate_staged_kernel<1, false, 256>;
     case 4: return use_sqloss ? (void*)accumulate_staged_kernel<4, true, 256> : (void*)accumulate_staged_kernel<4, false, 256>;
@@ -1005,8 +898,8 @@ int accumulate_stream_grid() {
 }
 
 static size_t stream_smem_bytes(int capacity, int K) {
-  const size_t staging = accumulate_variant() == 0 ? 0 : (size_t)4 * acc_slots_per_group(K) * STAGE_SLOT_BYTES;
-  return sizeof(double) * RED_ROWS * 256 + staging + sizeof(PairCtx) * (size_t)capacity;
+  const size_t staging = (size_t)4 * acc_slots_per_group(K) * STAGE_SLOT_BYTES;
+  return sizeof(double) * 4 * RED_ROWS * RED_STRIDE + staging + sizeof(PairCtx) * (size_t)capacity;
 }
 
 hipError_t launch_accumulate_batch(int K, int use_sqloss, const BatchHeader* hdr, const BatchArgs* batch, int capacity, hipStream_t st) {
