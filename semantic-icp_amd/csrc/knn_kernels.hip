@@ -588,10 +588,11 @@ __device__ __forceinline__ int xcd_contiguous_block(int bid, int nblk) {
 }
 
 __device__ __forceinline__ unsigned child_mask_packet(const float4* __restrict__ blo, const float4* __restrict__ bhi, int child_off,
-                                                      int child_cnt, int parent, int sub, float px, float py, float pz, float wd) {
+                                                      int child_cnt, int parent, int sub, float px, float py, float pz, float wd,
+                                                      float& lb) {
   const int c = parent * kFan + sub;
   const int node = child_off + min(c, child_cnt - 1);
-  const float lb = box_lb(blo[node], bhi[node], px, py, pz);
+  lb = box_lb(blo[node], bhi[node], px, py, pz);
   const bool ok = c < child_cnt && !(lb > wd);  // lb == wd may hide an equal distance with a lower index
   u64 b = __ballot(ok);                         // bit 4*q + c
   b |= b >> 32; b |= b >> 16; b |= b >> 8; b |= b >> 4;
@@ -702,7 +703,12 @@ __device__ __forceinline__ void knn_packet_body(const KnnArgs& a, int wg, int n_
   if (top >= 2) {
     u64 masks = 0;  // 4 sibling bits per level
     int L = top - 1, base = 0;
-    masks = (u64)child_mask_packet(blo, bhi, a.tree.lv.off[L], a.tree.lv.cnt[L], 0, sub, px, py, pz, wd) << (4 * L);
+    // lane (q, sub)'s lower bound of query q to child `sub` of the node expanded last.  When that node is
+    // a parent of leaves the bounds are kept for the leaves' own (re)test against the tightened lists:
+    // the leaf's box is not loaded a second time -- one dependent load less per leaf visit, and the
+    // launch lasts as long as its longest chain of dependent loads.
+    float child_lb;
+    masks = (u64)child_mask_packet(blo, bhi, a.tree.lv.off[L], a.tree.lv.cnt[L], 0, sub, px, py, pz, wd, child_lb) << (4 * L);
     for (;;) {
       int leaf = -1;
       for (;;) {
@@ -718,12 +724,11 @@ __device__ __forceinline__ void knn_packet_body(const KnnArgs& a, int wg, int n_
         const int node = base + c;
         if (L == 1 && node == seed) continue;
         if (L == 0) {
-          const int bn = a.tree.lv.off[0] + node;
-          const float lb = box_lb(blo[bn], bhi[bn], px, py, pz);  // the bounds may have tightened since the parent's test
-          if (__ballot(!(lb > wd)) != 0) { leaf = node; break; }
+          // the bounds may have tightened since the parent's test; the lanes with sub == c hold this leaf's
+          if (__ballot(sub == c && !(child_lb > wd)) != 0) { leaf = node; break; }
         } else {
           ++n_box;
-          const unsigned cm = child_mask_packet(blo, bhi, a.tree.lv.off[L - 1], a.tree.lv.cnt[L - 1], node, sub, px, py, pz, wd);
+          const unsigned cm = child_mask_packet(blo, bhi, a.tree.lv.off[L - 1], a.tree.lv.cnt[L - 1], node, sub, px, py, pz, wd, child_lb);
           --L;
           masks = (masks & ~(15ull << (4 * L))) | ((u64)cm << (4 * L));
           base = node * kFan;

@@ -477,6 +477,14 @@ int run_nn(sicp_context* h, int K, const Cloud& Qc, int q_begin, int q_count, co
       }
       std::fprintf(stderr, "[sicp knn stats] K=%d self=%d n=%d: boxes/query avg %.1f max %d (wave-max avg %.1f), leaves/query avg %.1f max %d (wave-max avg %.1f)\n",
                    K, (int)self, q_count, sn / q_count, mn, wsum_n / nw, sl / q_count, ml, wsum_l / nw);
+      // the walk is shared by the 16 queries of a packet: distribution of the packets' work (the launch
+      // ends with its slowest packet)
+      std::vector<int> pb, pl;
+      for (int i = 0; i < q_count; i += 16) { pb.push_back(hd[2 * i]); pl.push_back(hd[2 * i + 1]); }
+      std::sort(pb.begin(), pb.end()); std::sort(pl.begin(), pl.end());
+      auto pct = [](const std::vector<int>& v, double f) { return v[std::min(v.size() - 1, (size_t)(f * v.size()))]; };
+      std::fprintf(stderr, "[sicp knn stats]   per packet: boxes p50 %d p90 %d p99 %d p99.9 %d max %d | leaves p50 %d p90 %d p99 %d p99.9 %d max %d\n",
+                   pct(pb, .5), pct(pb, .9), pct(pb, .99), pct(pb, .999), pb.back(), pct(pl, .5), pct(pl, .9), pct(pl, .99), pct(pl, .999), pl.back());
     }
     return SICP_OK;
   }

@@ -459,49 +459,11 @@ __device__ __forceinline__ void compute_group(const MathCtx& M, const Group<K>& 
 // reduction (barrier | write | barrier | read, twice per chunk) cost 21 % of the launch, far more than
 // its instructions, because every barrier re-synchronises four waves whose memory waits differ.
 // ------------------------------------------------------------------------------------------
-struct PairCtx {
-  const int* idx;
-  const double* w;
-  const PointRec* srec;
-  const PointRec* trec;
-  double* partials;
-  int n_s, total, steps, chunk_groups, n_chunks, item_begin, running, pad_;
-  double R[9], t[3];
-  double one_m_eps, loss_b, loss_c;
+// what the walk needs of every pair of the launch (LDS, 12 bytes per pair); everything else is read
+// from the argument array when a workgroup enters a segment of the pair
+struct PairSlot {
+  int running, n_chunks, item_begin;
 };
-
-// the per-pair constants of a batched launch -> LDS (lane p: pair p)
-template <int K, int BS>
-__device__ __forceinline__ void stage_pair_constants(const BatchArgs* __restrict__ batch, int n_pairs, PairCtx* ctx) {
-  for (int p = threadIdx.x; p < n_pairs; p += BS) {
-    const BatchArgs& B = batch[p];
-    const AccArgs& a = B.a;
-    PairCtx c;
-    c.idx = a.idx; c.w = a.w; c.srec = a.srec; c.trec = a.trec; c.partials = a.partials;
-    c.n_s = a.n_s; c.total = a.n_s * a.K;
-    const AccGeometry geo = acc_geometry(c.total, GroupShape<K>::SG);
-    c.steps = geo.steps; c.chunk_groups = geo.chunk_groups; c.n_chunks = geo.n_chunks;
-    c.item_begin = 0;
-    c.pad_ = 0;
-    Pose P;
-    if (a.lm) {
-      c.running = a.lm->status == LM_RUNNING;
-      se3::rotation(a.lm->pose, P.R);
-      P.t[0] = a.lm->pose[4]; P.t[1] = a.lm->pose[5]; P.t[2] = a.lm->pose[6];
-    } else {
-      c.running = 1;
-      P = a.pose;
-    }
-#pragma unroll
-    for (int k = 0; k < 9; ++k) c.R[k] = P.R[k];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) c.t[k] = P.t[k];
-    c.one_m_eps = a.one_m_eps;
-    c.loss_b = a.loss.cauchy_a * a.loss.cauchy_a;
-    c.loss_c = 1.0 / c.loss_b;
-    ctx[p] = c;
-  }
-}
 
 #define SICP_LDS __attribute__((address_space(3)))
 constexpr int STAGE_SLOT_BYTES = 64 * 36;  // one target record of every lane of a wave: 1024 + 1024 + 256
@@ -595,13 +557,20 @@ __device__ __forceinline__ void wave_reduce_store(const double (&acc)[28], SICP_
 template <int K, bool SQLOSS, int BS>
 __global__ __launch_bounds__(BS, SICP_ACC_OCC) void accumulate_staged_kernel(const BatchHeader* __restrict__ hdr, const BatchArgs* __restrict__ batch) {
   constexpr int SG = GroupShape<K>::SG, NS = GroupShape<K>::NS, NW = BS / 64;
-  extern __shared__ __attribute__((aligned(16))) double smem[];  // ONE shared object: [reduction tiles | staging | per-pair constants]
+  extern __shared__ __attribute__((aligned(16))) double smem[];  // ONE shared object: [reduction tiles | staging | per-pair walk state]
   __shared__ int total_running;
   char* stage_all = reinterpret_cast<char*>(smem + NW * RED_ROWS * RED_STRIDE);
-  PairCtx* ctx = reinterpret_cast<PairCtx*>(stage_all + NW * SG * STAGE_SLOT_BYTES);
+  PairSlot* ctx = reinterpret_cast<PairSlot*>(stage_all + NW * SG * STAGE_SLOT_BYTES);
   const int n_pairs = hdr->n_pairs;
   if (n_pairs <= 0) return;
-  stage_pair_constants<K, BS>(batch, n_pairs, ctx);
+  for (int p = threadIdx.x; p < n_pairs; p += BS) {
+    const AccArgs& a = batch[p].a;
+    PairSlot c;
+    c.running = a.lm ? a.lm->status == LM_RUNNING : 1;
+    c.n_chunks = acc_geometry(a.n_s * a.K, SG).n_chunks;
+    c.item_begin = 0;
+    ctx[p] = c;
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = uniform_i32((int)(threadIdx.x >> 6));
   // item_begin[p] := number of chunks of RUNNING pairs before pair p (wave 0: a few pairs per lane, then
@@ -649,28 +618,41 @@ __global__ __launch_bounds__(BS, SICP_ACC_OCC) void accumulate_staged_kernel(con
       const int mid = (lo + hi + 1) >> 1;
       if (ctx[mid].item_begin <= item) lo = mid; else hi = mid - 1;
     }
-    const PairCtx& pc = ctx[uniform_i32(lo)];
-    const int chunk_lo = uniform_i32(item - pc.item_begin);
-    const int n_chunks = uniform_i32(pc.n_chunks), steps = uniform_i32(pc.steps);
+    const int pair = uniform_i32(lo);
+    const int chunk_lo = uniform_i32(item - ctx[pair].item_begin);
+    // the pair's constants: uniform addresses, i.e. scalar loads straight into SGPRs
+    const AccArgs& a = batch[pair].a;
+    LoadCtx L;
+    L.idx = (const SICP_GLOBAL int*)uniform_ptr(a.idx);
+    L.w = (const SICP_GLOBAL double*)uniform_ptr(a.w);
+    L.srec = (const SICP_GLOBAL PointRec*)uniform_ptr(a.srec);
+    L.trec = (const SICP_GLOBAL PointRec*)uniform_ptr(a.trec);
+    L.n_s = uniform_i32(a.n_s);
+    L.total = uniform_i32(a.n_s * a.K);
+    const AccGeometry geo = acc_geometry(L.total, SG);
+    const int n_chunks = uniform_i32(geo.n_chunks), steps = uniform_i32(geo.steps);
     const int n_here = min(n_chunks - chunk_lo, item_end - item);
     const int nsteps = n_here * steps;
-    LoadCtx L;
-    L.idx = (const SICP_GLOBAL int*)uniform_ptr(pc.idx);
-    L.w = (const SICP_GLOBAL double*)uniform_ptr(pc.w);
-    L.srec = (const SICP_GLOBAL PointRec*)uniform_ptr(pc.srec);
-    L.trec = (const SICP_GLOBAL PointRec*)uniform_ptr(pc.trec);
-    L.n_s = uniform_i32(pc.n_s);
-    L.total = uniform_i32(pc.total);
     const int last = ((L.total - 1) / SG) * SG;
-    SICP_GLOBAL double* partials = (SICP_GLOBAL double*)uniform_ptr(pc.partials);
+    SICP_GLOBAL double* partials = (SICP_GLOBAL double*)uniform_ptr(a.partials);
     MathCtx M;
+    {
+      Pose P;
+      if (a.lm) {
+        se3::rotation(a.lm->pose, P.R);
+        P.t[0] = a.lm->pose[4]; P.t[1] = a.lm->pose[5]; P.t[2] = a.lm->pose[6];
+      } else {
+        P = a.pose;
+      }
 #pragma unroll
-    for (int k = 0; k < 9; ++k) M.P.R[k] = uniform_f64(pc.R[k]);
+      for (int k = 0; k < 9; ++k) M.P.R[k] = uniform_f64(P.R[k]);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) M.P.t[k] = uniform_f64(pc.t[k]);
-    M.one_m_eps = uniform_f64(pc.one_m_eps); M.loss_b = uniform_f64(pc.loss_b); M.loss_c = uniform_f64(pc.loss_c);
+      for (int k = 0; k < 3; ++k) M.P.t[k] = uniform_f64(P.t[k]);
+      const double loss_b = a.loss.cauchy_a * a.loss.cauchy_a;
+      M.one_m_eps = uniform_f64(a.one_m_eps); M.loss_b = uniform_f64(loss_b); M.loss_c = uniform_f64(1.0 / loss_b);
+    }
 
-    int g = chunk_lo * uniform_i32(pc.chunk_groups) + (int)threadIdx.x;  // this lane's group; + BS per step
+    int g = chunk_lo * uniform_i32(geo.chunk_groups) + (int)threadIdx.x;  // this lane's group; + BS per step
     int t = 0, in_chunk = 0, chunk = chunk_lo;
     auto issue_targets = [&](const int (&j)[SG]) {
 #pragma unroll
@@ -746,7 +728,9 @@ __global__ __launch_bounds__(BS, SICP_ACC_OCC) void accumulate_staged_kernel(con
         in_chunk = 0;
         ++chunk;
       }
+#if !defined(SICP_DEBUG_NOSTREAM)  // developer aid: with it, every step re-reads the segment's first groups (cache hits)
       g += BS;
+#endif
       ++t;
       return more;
     };
@@ -758,62 +742,38 @@ __global__ __launch_bounds__(BS, SICP_ACC_OCC) void accumulate_staged_kernel(con
   }
 }
 
-// fixed-order sum of the partial columns (layout [28][n_blocks]) by one wave: every lane owns columns
-// lane, lane+64, ... ; the 28 loads of one trip are independent and coalesced
-__device__ __forceinline__ void reduce_partials(const double* __restrict__ partials, int n_blocks, int lane, double (&o)[28]) {
-  double s[28];
-#pragma unroll
-  for (int k = 0; k < 28; ++k) s[k] = 0.0;
-  for (int b = lane; b < n_blocks; b += 64) {
-    // issue all 28 loads of the trip before the first add: left to itself hipcc recycles one
-    // address register and keeps only ~3 loads in flight, which serialises ~200 L2 round trips
-    double v[28];
-    const double* __restrict__ p = partials + b;
-#pragma unroll
-    for (int k = 0; k < 28; ++k) v[k] = __builtin_nontemporal_load(p + (size_t)k * n_blocks);
-    // one empty asm that "uses" all 28 values: every load has to be issued (and waited for once)
-    // before the adds start
-    asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
-                      "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]));
-    asm volatile("" : "+v"(v[14]), "+v"(v[15]), "+v"(v[16]), "+v"(v[17]), "+v"(v[18]), "+v"(v[19]), "+v"(v[20]), "+v"(v[21]),
-                      "+v"(v[22]), "+v"(v[23]), "+v"(v[24]), "+v"(v[25]), "+v"(v[26]), "+v"(v[27]));
-#pragma unroll
-    for (int k = 0; k < 28; ++k) s[k] += v[k];
-  }
-#pragma unroll
-  for (int k = 0; k < 28; ++k) o[k] = wave_sum(s[k]);
-}
-
-// device-resident solve: reduce the chunk partials and advance the LM machine by one evaluation
-// (lm.hpp: the same lm_feed the host loop runs).  One wave per pair: 512 VGPRs are available to it, so
-// the whole 6x6 trust-region step stays in registers; lane 0 does the serial part.
-// batch forms: one block (one wave) per pair; the grid is the capacity of the batch buffers, the
-// blocks beyond the number of active pairs leave at once
-// Four waves share the reduction (wave w sums rows w, w + 4, ...: per row exactly the additions of
-// reduce_partials, so the 28 sums keep their bits), then lane 0 of wave 0 takes the trust-region step.
-__global__ __launch_bounds__(256) void lm_step_batch_kernel(const BatchHeader* __restrict__ hdr, const BatchArgs* __restrict__ batch) {
-  if ((int)blockIdx.x >= hdr->n_pairs) return;
-  const BatchArgs& B = batch[blockIdx.x];
-  LmState* lm = B.a.lm_step;
-  if (lm->status != LM_RUNNING) return;
-  __shared__ double s_out[28];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int n = B.nb;
-  const double* __restrict__ base = B.a.partials + (size_t)wave * n;  // row wave + 4 r lives at base + 4 r n
+// Fixed-order sum of the partial columns (layout [28][n], n a multiple of 4) by one workgroup of
+// REDUCE_THREADS / 64 waves: wave (cq = wave / 4, rg = wave % 4) sums the rows rg, rg + 4, ... (7 of
+// them) over the column part cq (all columns with 256 threads) -- lane l takes the columns l, l + 64,
+// ... in ascending order, twenty columns' loads in flight before the first add -- and reduces across
+// its lanes with wave_sum; with more than one part the parts of a row are joined in a fixed order.
+// Everyone who needs the 28 sums of a pair (the LM step, sicp_accumulate, the host-loop solve) goes
+// through this one routine, so they see the same bits.  Must be called by all REDUCE_THREADS threads
+// of the block; the result is valid for thread 0 after the call (s_part is block-shared scratch).
+#ifndef SICP_REDUCE_THREADS
+#define SICP_REDUCE_THREADS 256  // more threads leave lm_feed (312 VGPRs) too few registers: 512 -> spills
+#endif
+constexpr int REDUCE_THREADS = SICP_REDUCE_THREADS, REDUCE_PARTS = REDUCE_THREADS / 256;
+static_assert(REDUCE_PARTS == 1 || REDUCE_PARTS == 2 || REDUCE_PARTS == 4, "the column count is a multiple of 4");
+__device__ __forceinline__ void reduce_partials_block(const double* __restrict__ partials, int n, double (&s_part)[4][28], double (&o)[28]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, rg = wave & 3, cq = wave >> 2;
+  const int nq = n / REDUCE_PARTS, c0 = cq * nq, c1 = c0 + nq;
+  const double* __restrict__ base = partials + (size_t)rg * n;  // row rg + 4 r lives at base + 4 r n
   double s[7];
 #pragma unroll
   for (int r = 0; r < 7; ++r) s[r] = 0.0;
-  for (int b0 = lane; b0 < n; b0 += 256) {
-    double v[4][7];
+  constexpr int DEEP = 20;  // column blocks in flight per trip: 140 loads per lane = 280 VGPRs (lm_feed needs 312 anyway); one trip up to 1280 columns = 160K source points at K = 4
+  for (int b0 = c0 + lane; b0 < c1; b0 += 64 * DEEP) {
+    double v[DEEP][7];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int b = min(b0 + 64 * t, n - 1);  // clamped: loaded unconditionally, added only when in range
+    for (int t = 0; t < DEEP; ++t) {
+      const int b = min(b0 + 64 * t, c1 - 1);  // clamped: loaded unconditionally, added only when in range
 #pragma unroll
       for (int r = 0; r < 7; ++r) v[t][r] = __builtin_nontemporal_load(base + (size_t)(4 * r) * n + b);
     }
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
-      if (b0 + 64 * t < n) {
+    for (int t = 0; t < DEEP; ++t)
+      if (b0 + 64 * t < c1) {
 #pragma unroll
         for (int r = 0; r < 7; ++r) s[r] += v[t][r];
       }
@@ -821,32 +781,47 @@ __global__ __launch_bounds__(256) void lm_step_batch_kernel(const BatchHeader* _
 #pragma unroll
   for (int r = 0; r < 7; ++r) {
     const double sum = wave_sum(s[r]);
-    if (lane == 0) s_out[wave + 4 * r] = sum;
+    if (lane == 0) s_part[cq][rg + 4 * r] = sum;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    double o[28];
 #pragma unroll
-    for (int k = 0; k < 28; ++k) o[k] = s_out[k];
+    for (int k = 0; k < 28; ++k)
+      o[k] = REDUCE_PARTS == 4 ? (s_part[0][k] + s_part[1][k]) + (s_part[2][k] + s_part[3][k])
+           : REDUCE_PARTS == 2 ? s_part[0][k] + s_part[1][k] : s_part[0][k];
+  }
+}
+
+// device-resident solve: reduce the partial columns and advance the LM machine by one evaluation
+// (lm.hpp: the same lm_feed the host loop runs).  One workgroup per pair; the grid is the capacity of
+// the batch buffers, the blocks beyond the number of active pairs leave at once.  Thread 0 takes the
+// trust-region step (serial: ~10 us, the longest link of a pair-alone evaluation).
+__global__ __launch_bounds__(REDUCE_THREADS) void lm_step_batch_kernel(const BatchHeader* __restrict__ hdr, const BatchArgs* __restrict__ batch) {
+  if ((int)blockIdx.x >= hdr->n_pairs) return;
+  const BatchArgs& B = batch[blockIdx.x];
+  LmState* lm = B.a.lm_step;
+  if (lm->status != LM_RUNNING) return;
+  __shared__ double s_part[4][28];
+  double o[28];
+  reduce_partials_block(B.a.partials, B.nb, s_part, o);
+  if (threadIdx.x == 0) {
     LmCore st = *lm;  // the options stay in memory: uniform, read with scalar loads
     lm_feed(st, lm->opt, o);
     *static_cast<LmCore*>(lm) = st;
   }
 }
 
-__global__ __launch_bounds__(64) void finalize_batch_kernel(const BatchArgs* __restrict__ batch, double* out28) {
+__global__ __launch_bounds__(REDUCE_THREADS) void finalize_batch_kernel(const BatchArgs* __restrict__ batch, double* out28) {
   const BatchArgs& B = batch[blockIdx.x];
+  __shared__ double s_part[4][28];
   double o[28];
-  reduce_partials(B.a.partials, B.nb, threadIdx.x, o);
-  if (threadIdx.x < 28) {
-    double v = 0.0;
+  reduce_partials_block(B.a.partials, B.nb, s_part, o);
+  if (threadIdx.x == 0) {
 #pragma unroll
-    for (int k = 0; k < 28; ++k) v = (int)threadIdx.x == k ? o[k] : v;
-    out28[28 * blockIdx.x + threadIdx.x] = v;
+    for (int k = 0; k < 28; ++k) out28[28 * blockIdx.x + k] = o[k];
   }
 }
 
-// test hook (sicp_se3_device): the SE(3) code of the device-resident solve, one lane per item
 __global__ __launch_bounds__(64) void se3_ops_kernel(int op, int n, const double* __restrict__ in, double* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -899,7 +874,7 @@ int accumulate_stream_grid() {
 
 static size_t stream_smem_bytes(int capacity, int K) {
   const size_t staging = (size_t)4 * acc_slots_per_group(K) * STAGE_SLOT_BYTES;
-  return sizeof(double) * 4 * RED_ROWS * RED_STRIDE + staging + sizeof(PairCtx) * (size_t)capacity;
+  return sizeof(double) * 4 * RED_ROWS * RED_STRIDE + staging + sizeof(PairSlot) * (size_t)capacity;
 }
 
 hipError_t launch_accumulate_batch(int K, int use_sqloss, const BatchHeader* hdr, const BatchArgs* batch, int capacity, hipStream_t st) {
@@ -911,13 +886,13 @@ hipError_t launch_accumulate_batch(int K, int use_sqloss, const BatchHeader* hdr
 
 hipError_t launch_lm_step_batch(const BatchHeader* hdr, const BatchArgs* batch, int capacity, hipStream_t st) {
   if (capacity <= 0) return hipSuccess;
-  hipLaunchKernelGGL(lm_step_batch_kernel, dim3(capacity), dim3(256), 0, st, hdr, batch);
+  hipLaunchKernelGGL(lm_step_batch_kernel, dim3(capacity), dim3(REDUCE_THREADS), 0, st, hdr, batch);
   return hipGetLastError();
 }
 
 hipError_t launch_finalize_batch(const BatchArgs* batch, int n, double* out28, hipStream_t st) {
   if (n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(finalize_batch_kernel, dim3(n), dim3(64), 0, st, batch, out28);
+  hipLaunchKernelGGL(finalize_batch_kernel, dim3(n), dim3(REDUCE_THREADS), 0, st, batch, out28);
   return hipGetLastError();
 }
 
@@ -949,7 +924,7 @@ hipError_t batch_graph_prepare(BatchGraph& g, int K, int use_sqloss, const Batch
   memset(&ps, 0, sizeof ps);
   ps.func = (void*)lm_step_batch_kernel;
   ps.gridDim = dim3(capacity);
-  ps.blockDim = dim3(256);
+  ps.blockDim = dim3(REDUCE_THREADS);
   ps.kernelParams = args;
   hipError_t e = hipGraphCreate(&g.graph, 0);
   if (e != hipSuccess) return e;
