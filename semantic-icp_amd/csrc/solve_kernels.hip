@@ -452,12 +452,13 @@ __device__ __forceinline__ void compute_group(const MathCtx& M, const Group<K>& 
 //     wait for everything issued a step ago | staging area -> registers | issue: LDS-DMA of group
 //     t+1's targets, loads of its weights / source, indices of group t+2 | compute group t
 //
-// Reduction.  A wave sums its OWN 64 lanes' 28 accumulators at the end of every chunk and writes one
-// column of partials[28][4 n_chunks] (column 4 chunk + wave): transposed through a wave-private LDS
-// tile, RED_ROWS rows at a time -- lane (r, q) adds up quarter q of row r in ascending order, one DPP
-// quad reduction joins the quarters.  No workgroup barrier anywhere in the loop: a block-wide
-// reduction (barrier | write | barrier | read, twice per chunk) cost 21 % of the launch, far more than
-// its instructions, because every barrier re-synchronises four waves whose memory waits differ.
+// Reduction.  A wave sums its OWN 64 lanes' 28 accumulators at the end of every chunk: transposed through
+// a wave-private LDS tile, RED_ROWS rows at a time -- lane (r, q) adds up quarter q of row r in ascending
+// order, one DPP quad reduction joins the quarters -- and parks the 28 sums in LDS.  Every COMB_CHUNKS
+// chunks (and at the end of a segment) ONE workgroup barrier lets the 256 threads join the four waves'
+// sums of each parked chunk as (w0 + w1) + (w2 + w3) and write column `chunk` of partials[28][n_chunks].
+// A block-wide reduction per chunk (barrier | write | barrier | read, twice) cost 21 % of the launch, far
+// more than its instructions: every barrier re-synchronises four waves whose memory waits differ.
 // ------------------------------------------------------------------------------------------
 // what the walk needs of every pair of the launch (LDS, 12 bytes per pair); everything else is read
 // from the argument array when a workgroup enters a segment of the pair
@@ -530,8 +531,8 @@ __device__ __forceinline__ void load_regs(const LoadCtx& L, int last, int g, Gro
 constexpr int RED_ROWS = SICP_RED_ROWS;  // divides 28; RED_ROWS * 4 <= 64 lanes
 constexpr int RED_STRIDE = 66;
 static_assert(28 % RED_ROWS == 0 && RED_ROWS * 4 <= 64, "one lane per (row, quarter)");
-__device__ __forceinline__ void wave_reduce_store(const double (&acc)[28], SICP_LDS double* tile, SICP_GLOBAL double* partials, int n_cols,
-                                                  int col, int lane) {
+constexpr int COMB_CHUNKS = 8;  // chunks whose four wave sums wait in LDS for one combining pass
+__device__ __forceinline__ void wave_reduce(const double (&acc)[28], SICP_LDS double* tile, SICP_LDS double* out28, int lane) {
   const int r = lane >> 2, q = lane & 3;
   const SICP_LDS v2d* mine = (const SICP_LDS v2d*)(tile + min(r, RED_ROWS - 1) * RED_STRIDE + 16 * q);
 #pragma unroll
@@ -549,7 +550,7 @@ __device__ __forceinline__ void wave_reduce_store(const double (&acc)[28], SICP_
     for (int m = 0; m < 8; ++m) { s += v[m].x; s += v[m].y; }
     s += dpp_f64<0xB1>(s);  // quad_perm:[1,0,3,2]
     s += dpp_f64<0x4E>(s);  // quad_perm:[2,3,0,1]
-    if (q == 0 && r < RED_ROWS) partials[(size_t)(p0 + r) * n_cols + col] = s;
+    if (q == 0 && r < RED_ROWS) out28[p0 + r] = s;
     __builtin_amdgcn_wave_barrier();
   }
 }
@@ -559,6 +560,7 @@ __global__ __launch_bounds__(BS, SICP_ACC_OCC) void accumulate_staged_kernel(con
   constexpr int SG = GroupShape<K>::SG, NS = GroupShape<K>::NS, NW = BS / 64;
   extern __shared__ __attribute__((aligned(16))) double smem[];  // ONE shared object: [reduction tiles | staging | per-pair walk state]
   __shared__ int total_running;
+  __shared__ double comb[COMB_CHUNKS][NW][28];
   char* stage_all = reinterpret_cast<char*>(smem + NW * RED_ROWS * RED_STRIDE);
   PairSlot* ctx = reinterpret_cast<PairSlot*>(stage_all + NW * SG * STAGE_SLOT_BYTES);
   const int n_pairs = hdr->n_pairs;
@@ -653,7 +655,20 @@ __global__ __launch_bounds__(BS, SICP_ACC_OCC) void accumulate_staged_kernel(con
     }
 
     int g = chunk_lo * uniform_i32(geo.chunk_groups) + (int)threadIdx.x;  // this lane's group; + BS per step
-    int t = 0, in_chunk = 0, chunk = chunk_lo;
+    int t = 0, in_chunk = 0, chunk = chunk_lo, parked = 0;  // parked: chunks whose wave sums sit in comb[]
+    // join the four waves' sums of the parked chunks [chunk - parked, chunk) -> their columns.  Raw barriers:
+    // a __syncthreads would also wait for the LDS-DMA / loads in flight.
+    auto flush_parked = [&]() {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      for (int e = threadIdx.x; e < parked * 28; e += BS) {
+        const int c = e / 28, k = e - 28 * c;
+        partials[(size_t)k * n_chunks + (chunk - parked + c)] = (comb[c][0][k] + comb[c][1][k]) + (comb[c][2][k] + comb[c][3][k]);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      parked = 0;
+    };
     auto issue_targets = [&](const int (&j)[SG]) {
 #pragma unroll
 #if defined(SICP_DEBUG_NOGATHER)  // developer aid: every gather reads target 0 (results are wrong)
@@ -721,12 +736,15 @@ __global__ __launch_bounds__(BS, SICP_ACC_OCC) void accumulate_staged_kernel(con
           if (chk == 1.2345e300) partials[chunk] = chk;
         }
 #else
-        wave_reduce_store(acc, tile, partials, n_chunks * NW, chunk * NW + wave, lane);
+        wave_reduce(acc, tile, (SICP_LDS double*)&comb[parked][wave][0], lane);
 #endif
 #pragma unroll
         for (int k = 0; k < 28; ++k) acc[k] = 0.0;
         in_chunk = 0;
         ++chunk;
+#if !defined(SICP_DEBUG_NOREDUCE)
+        if (++parked == COMB_CHUNKS || t + 1 == nsteps) flush_parked();
+#endif
       }
 #if !defined(SICP_DEBUG_NOSTREAM)  // developer aid: with it, every step re-reads the segment's first groups (cache hits)
       g += BS;
@@ -742,10 +760,10 @@ __global__ __launch_bounds__(BS, SICP_ACC_OCC) void accumulate_staged_kernel(con
   }
 }
 
-// Fixed-order sum of the partial columns (layout [28][n], n a multiple of 4) by one workgroup of
+// Fixed-order sum of the partial columns (layout [28][n]) by one workgroup of
 // REDUCE_THREADS / 64 waves: wave (cq = wave / 4, rg = wave % 4) sums the rows rg, rg + 4, ... (7 of
 // them) over the column part cq (all columns with 256 threads) -- lane l takes the columns l, l + 64,
-// ... in ascending order, twenty columns' loads in flight before the first add -- and reduces across
+// ... in ascending order, four columns' loads in flight before the first add -- and reduces across
 // its lanes with wave_sum; with more than one part the parts of a row are joined in a fixed order.
 // Everyone who needs the 28 sums of a pair (the LM step, sicp_accumulate, the host-loop solve) goes
 // through this one routine, so they see the same bits.  Must be called by all REDUCE_THREADS threads
@@ -754,7 +772,7 @@ __global__ __launch_bounds__(BS, SICP_ACC_OCC) void accumulate_staged_kernel(con
 #define SICP_REDUCE_THREADS 256  // more threads leave lm_feed (312 VGPRs) too few registers: 512 -> spills
 #endif
 constexpr int REDUCE_THREADS = SICP_REDUCE_THREADS, REDUCE_PARTS = REDUCE_THREADS / 256;
-static_assert(REDUCE_PARTS == 1 || REDUCE_PARTS == 2 || REDUCE_PARTS == 4, "the column count is a multiple of 4");
+static_assert(REDUCE_PARTS == 1, "the column count need not divide");
 __device__ __forceinline__ void reduce_partials_block(const double* __restrict__ partials, int n, double (&s_part)[4][28], double (&o)[28]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, rg = wave & 3, cq = wave >> 2;
   const int nq = n / REDUCE_PARTS, c0 = cq * nq, c1 = c0 + nq;
@@ -762,7 +780,7 @@ __device__ __forceinline__ void reduce_partials_block(const double* __restrict__
   double s[7];
 #pragma unroll
   for (int r = 0; r < 7; ++r) s[r] = 0.0;
-  constexpr int DEEP = 20;  // column blocks in flight per trip: 140 loads per lane = 280 VGPRs (lm_feed needs 312 anyway); one trip up to 1280 columns = 160K source points at K = 4
+  constexpr int DEEP = 4;  // column blocks in flight per trip (clamped loads past the end are issued too: keep it near n / 64)
   for (int b0 = c0 + lane; b0 < c1; b0 += 64 * DEEP) {
     double v[DEEP][7];
 #pragma unroll
@@ -847,8 +865,8 @@ hipError_t launch_se3_ops(int op, int n, const double* in, double* out, hipStrea
 // ------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------
-// columns of partials[28][.]: one per (chunk, wave of the workgroup that sums it)
-int accumulate_blocks(int total, int K) { return 4 * acc_geometry(total, acc_slots_per_group(K)).n_chunks; }
+// columns of partials[28][.]: one per chunk
+int accumulate_blocks(int total, int K) { return acc_geometry(total, acc_slots_per_group(K)).n_chunks; }
 
 // ---- the batched evaluation --------------------------------------------------------------------
 static void* accumulate_stream_fn(int K, int use_sqloss) {
