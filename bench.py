@@ -6,14 +6,17 @@ Metric (BASELINE.json): correspondences/sec (+ ms per outer ICP iteration) for E
 subsampled to exactly 100 000 x 100 000 points -- the metric point of configs[1].
 
 A "step" registers one batch of independent scan pairs on each GPU: `--pairs-in-flight` S pairs
-(default 64), every one a DIFFERENT pair (its own street, ego-motion and noise: seeds
+(default 256 = ~30 GB of the 288 GB: the stragglers of a batch -- a pair that needs 500 evaluations
+when the median needs 150 -- weigh less the larger it is: 1.39 G corr/s at 64 pairs, 1.56 at 128,
+1.68 at 256 and 512), every one a DIFFERENT pair (its own street, ego-motion and noise: seeds
 2 + S*rank + k) and a complete align() (covariances of both clouds + every outer ICP iteration:
 transform -> kNN -> EM weights -> inner LM solve) on its own handle, with all clouds already
 resident in HBM when the timed region starts.  Independent pairs are the reference's unit of work
 (exec/kitti_eval.cc:124-249 loops over them) and the north star shards them across GPUs.  The S
-pairs of a GPU go through one sicp_align_batch call: every launch of the solve evaluates all pairs
-that are inside an inner solve, while the searches of the pairs between two solves run beside it
-(continuous batching: no pair waits for another pair's solve or outer loop); per pair the result
+pairs of a GPU go through one sicp_align_batch call: every launch of the solve evaluates the pairs
+that are inside an inner solve (up to 128 per launch), the searches of the pairs between two solves
+are queued on a second stream and those pairs rejoin at the next tick (continuous batching: no pair
+waits for another pair's solve or outer loop); per pair the result
 is bit-identical to a lone align().  `lockstep.busy_fraction` = the pairs' own LM evaluations / the
 evaluation launches they took part in.
 
@@ -70,7 +73,7 @@ def parse_args():
     ap.add_argument("--nn-method", type=int, default=None, help="0 brute force, 1 box tree (default: library default)")
     ap.add_argument("--lm-on-device", type=int, default=None, help="0 host LM loop, 1 device-resident (default: library default)")
     ap.add_argument("--lm-batch", type=int, default=None)
-    ap.add_argument("--pairs-in-flight", type=int, default=64,
+    ap.add_argument("--pairs-in-flight", type=int, default=256,
                     help="independent, distinct scan pairs registered together on each GPU (one handle each; round 1 used 32)")
     ap.add_argument("--same-pair", action="store_true", help="r01 behaviour: every handle of a GPU gets the rank's first pair")
     ap.add_argument("--profile", type=int, default=0, help="SICP_PROFILE_* mask applied inside the timed region")
@@ -502,14 +505,15 @@ def main():
                 pass
         out["roofline"] = {
             "kernel": f"accumulate_staged_kernel<K={K}> (Mahalanobis residual + 6-DoF Jacobian + robust loss -> 28 sums per pair; persistent "
-                      f"workgroups, LDS-staged gathers; one launch per LM evaluation, timed here over {L} pairs of the batch)",
+                      f"workgroups over contiguous chunk ranges, LDS-staged gathers, wave-private reductions; one launch per LM evaluation, timed here over {L} pairs of the batch)",
             "bound": "hbm", "achieved": acc_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": acc_gbs / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": traffic_src,
             "avg_launch_us": acc_us, "launches_timed": 50 * len(acc_ms_l[2:]), "algorithmic_bytes_per_launch": acc_bytes,
             "pairs_per_launch": L,
-            "note": "not an HBM-bound kernel in practice: the memory side moves ~0.98x the algorithmic bytes (no re-reads) at ~3 TB/s; the launch is "
-                    "bound by FP64 issue (PMC: ~250 VALU instructions per correspondence = 83 us of pure issue at 2.4 GHz) plus the exposed part "
-                    "of the index -> gather latency (DESIGN.md section 3)",
+            "note": "the memory side moves ~0.96x the algorithmic bytes (no re-reads).  Measured anatomy of the launch "
+                    "(profiles/r02/r02_accumulate_anatomy.txt, DESIGN.md section 3.1): its memory pipeline alone (no arithmetic) takes ~90 us, "
+                    "its arithmetic + reduction alone (all loads cache hits; 205 VALU instructions per correspondence, FP64) ~96 us, "
+                    "both together ~120 us: two waves per SIMD overlap the two imperfectly",
         }
         pp = engine.get_params()
         pp.profile = 1  # SICP_PROFILE_NN: the correspondence-search kernel alone, 20 launches at the final pose

@@ -190,15 +190,14 @@ static_assert(sizeof(KnnJobs) <= 4000 && sizeof(WeightJobs) <= 4000 && sizeof(Co
 // one pair of a lock-step batch (sicp_align_batch); an array of these lives in HBM
 struct BatchArgs {
   AccArgs a;
-  int nb;          // chunks of this pair (its partials are [28][nb])
-  int item_begin;  // index of the pair's first chunk in the batch's flattened (pair, chunk) list
+  int nb;    // columns of this pair's partials ([28][nb]): its chunks
+  int pad_;
 };
-// what the batched kernels need to know about the current outer iteration; lives in HBM next to the
-// BatchArgs array, so the instantiated graph never changes
+// what the batched kernels need to know about the current launch; lives in HBM next to the BatchArgs
+// array, so the instantiated graph never changes
 struct BatchHeader {
-  int n_pairs;   // pairs that still iterate = entries of the BatchArgs array
-  int n_items;   // sum of their chunk counts
-  int pad_[2];
+  int n_pairs;   // entries of the BatchArgs array (pairs whose solve has ended are skipped on the device)
+  int pad_[3];
 };
 
 // [accumulate_stream, lm_step_batch] x len of a lock-step batch as an instantiated graph with explicit

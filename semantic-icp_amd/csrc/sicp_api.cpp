@@ -721,8 +721,8 @@ int eval28(sicp_context* h, const double* qt, double* out28) {
   std::memset(&B, 0, sizeof B);
   fill_acc(h, B.a);
   fill_pose(qt, B.a.pose);
-  B.nb = nb; B.item_begin = 0;
-  h->ts[0].h_bhdr->n_pairs = 1; h->ts[0].h_bhdr->n_items = nb; h->ts[0].h_bhdr->pad_[0] = h->ts[0].h_bhdr->pad_[1] = 0;
+  B.nb = nb;
+  *h->ts[0].h_bhdr = sicp::BatchHeader{1, {0, 0, 0}};
   HIPCHECK(hipMemcpyAsync(h->ts[0].d_bhdr.p, h->ts[0].h_bhdr, sizeof(sicp::BatchHeader), hipMemcpyHostToDevice, h->stream));
   HIPCHECK(hipMemcpyAsync(h->ts[0].d_batch.p, h->ts[0].h_batch, sizeof(sicp::BatchArgs), hipMemcpyHostToDevice, h->stream));
   {
@@ -997,7 +997,7 @@ int tick_launch(sicp_context* h, TickSet& S, hipStream_t M, sicp_handle* hs, int
   }
   // the argument array in HBM only changes when the set of pairs inside a solve does
   const bool same_set = S.tick_valid && joining.empty() && S.tick_act == act;
-  int n_items = 0, k = 0;
+  int k = 0;
   for (int p : act) {
     if (same_set) break;
     sicp_context* g = hs[p];
@@ -1008,18 +1008,16 @@ int tick_launch(sicp_context* h, TickSet& S, hipStream_t M, sicp_handle* hs, int
     fill_acc(g, B.a);
     B.a.lm = B.a.lm_step = h->d_bstates.p + p;
     B.nb = nb;
-    B.item_begin = n_items;
-    n_items += nb;
   }
   if (!same_set) {
-    S.h_bhdr->n_pairs = (int)act.size(); S.h_bhdr->n_items = n_items; S.h_bhdr->pad_[0] = S.h_bhdr->pad_[1] = 0;
+    *S.h_bhdr = sicp::BatchHeader{(int)act.size(), {0, 0, 0}};
     HIPCHECK(hipMemcpyAsync(S.d_bhdr.p, S.h_bhdr, sizeof(sicp::BatchHeader), hipMemcpyHostToDevice, M));
     HIPCHECK(hipMemcpyAsync(S.d_batch.p, S.h_batch, sizeof(sicp::BatchArgs) * act.size(), hipMemcpyHostToDevice, M));
     S.tick_act = act;
     S.tick_valid = true;
   }
   // [accumulate, lm_step_batch] x len as an explicit graph with fixed grids: the kernels read the
-  // number of active pairs and chunks from the header, so the graph is instantiated once per tick set
+  // number of pairs from the header and their status from the LM states, so the graph is instantiated once per tick set
   // (buffer addresses) and never touched when pairs come and go or batches differ in size.
   {
     int built = 0;
@@ -1561,7 +1559,6 @@ int sicp_accumulate_batch(sicp_handle* hs, int32_t n, const double* qt, double* 
   SICPCHECK(set_device(h));
   SICPCHECK(batch_reserve(h, n));
   h->ts[0].tick_valid = false;
-  int n_items = 0;
   for (int p = 0; p < n; ++p) {
     sicp_context* g = hs[p];
     const int nb = sicp::accumulate_blocks(g->corr_n * g->corr_K, g->corr_K);
@@ -1570,15 +1567,9 @@ int sicp_accumulate_batch(sicp_handle* hs, int32_t n, const double* qt, double* 
     fill_acc(g, h->ts[0].h_batch[p].a);
     fill_pose(qt + 7 * p, h->ts[0].h_batch[p].a.pose);
     h->ts[0].h_batch[p].nb = nb;
-    h->ts[0].h_batch[p].item_begin = n_items;
-    n_items += nb;
     HIPCHECK(hipStreamSynchronize(g->stream));  // the pair's correspondences are complete
   }
-  h->ts[0].h_bhdr->n_pairs = n; h->ts[0].h_bhdr->n_items = n_items; h->ts[0].h_bhdr->pad_[0] = h->ts[0].h_bhdr->pad_[1] = 0;
-  {  // developer aid (timing only, wrong sums): the launch without its gather traffic
-    static const bool no_gather = std::getenv("SICP_ACC_DEBUG_NOGATHER") != nullptr;
-    if (no_gather) h->ts[0].h_bhdr->pad_[0] = 1;
-  }
+  *h->ts[0].h_bhdr = sicp::BatchHeader{n, {0, 0, 0}};
   HIPCHECK(hipMemcpyAsync(h->ts[0].d_bhdr.p, h->ts[0].h_bhdr, sizeof(sicp::BatchHeader), hipMemcpyHostToDevice, h->stream));
   HIPCHECK(hipMemcpyAsync(h->ts[0].d_batch.p, h->ts[0].h_batch, sizeof(sicp::BatchArgs) * n, hipMemcpyHostToDevice, h->stream));
   if (repeat < 1) repeat = 1;

@@ -28,8 +28,8 @@ def test_world_size_2_gloo_dry_run():
         assert out["metric"] == "correspondences/sec" and out["unit"] == "correspondences/s"
         assert out["vs_baseline"] is None and "workload" in out["config"]
     # dry-run step of rank r sleeps 10*(1+r) ms and reports 3 outer iterations of 20000*4 slots for each of
-    # its 64 pairs: the aggregate counts both ranks' correspondences over the slower rank's time
-    corr_per_rank = 2 * 3 * 20000 * 4 * 64
+    # its 256 pairs (the default): the aggregate counts both ranks' correspondences over the slower rank's time
+    corr_per_rank = 2 * 3 * 20000 * 4 * 256
     assert abs(one["value"] * one["ms_per_step"] * 2e-3 - corr_per_rank) < 1e-6 * corr_per_rank
     assert abs(two["value"] * two["ms_per_step"] * 2e-3 - 2 * corr_per_rank) < 1e-6 * corr_per_rank
     assert two["ms_per_step"] > 1.5 * one["ms_per_step"]  # max over ranks, rank 1 is slower
@@ -46,7 +46,7 @@ def test_bare_gpus_flag_fans_out_by_itself():
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "pairs-sharded x2"
-    assert abs(out["value"] * out["ms_per_step"] * 2e-3 - 2 * 2 * 3 * 20000 * 4 * 64) < 1.0
+    assert abs(out["value"] * out["ms_per_step"] * 2e-3 - 2 * 2 * 3 * 20000 * 4 * 256) < 1.0
     # one rank launched for --gpus 2: mismatch, loud failure
     bad = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--dry-run"], cwd=ROOT, env=dict(env, WORLD_SIZE="1", RANK="0"),
                          capture_output=True, text=True, timeout=600)

@@ -27,7 +27,7 @@ print(json.dumps({
     "roofline_leg_last_400_launches": {"n": len(leg), "mean_us": sum(leg) / len(leg), "min_us": min(leg), "max_us": max(leg),
                                        "what": "sicp_accumulate_batch over all 32 pairs, 8 x 50 launches: the launches bench.py brackets with HIP events"},
     "other_launches": {"n": len(rest), "mean_us": sum(rest) / max(1, len(rest)),
-                       "what": "timed region + warm-up + other workloads: 1..32 pairs inside a solve per launch, plus no-op launches at the tail of a tick"},
+                       "what": "timed region + warm-up + other workloads: 1..128 pairs inside a solve per launch, plus no-op launches at the tail of a tick"},
     "bench_roofline_avg_launch_us_same_run": bench["roofline"]["avg_launch_us"],
 }, indent=1))
 PY
