@@ -608,3 +608,55 @@ def test_align_batch_of_sixty_pairs_one_tick_group():
     finally:
         for e in engines:
             e.close()
+
+
+def test_align_batch_of_more_pairs_than_one_launch_holds():
+    """A launch evaluates at most 128 pairs: in a batch of 150 the others wait with their search done
+    and join as slots free up.  Same bits and counters as lone aligns."""
+    rng = np.random.default_rng(12)
+    engines, singles = [], []
+    try:
+        for k in range(150):
+            n = int(rng.integers(300, 1200))
+            tgt = rng.uniform(0, 6, (n, 3)).astype(np.float32)
+            tgt[:, 2] = (0.1 * np.sin(tgt[:, 0]) + 0.05 * tgt[:, 1]).astype(np.float32)
+            R = Rotation.from_rotvec(rng.normal(0, 0.01, 3)).as_matrix()
+            src = ((tgt.astype(np.float64) - rng.normal(0, 0.02, 3)) @ R).astype(np.float32)
+            e, p = make_engine(sicp.MODE_GICP)
+            e.set_source(src, None); e.set_target(tgt, None)
+            engines.append(e)
+            singles.append(e.align())
+        for k, ((qb, sb), (q1, s1)) in enumerate(zip(sicp.align_batch(engines), singles)):
+            assert np.array_equal(qb, q1), k
+            assert sb["outer_iters"] == s1["outer_iters"] and sb["total_evals"] == s1["total_evals"]
+    finally:
+        for e in engines:
+            e.close()
+
+
+def test_accumulate_batch_with_long_workgroup_ranges():
+    """48 pairs x 60K points x K = 4: 5640 chunks over the 512 persistent workgroups = 11 per workgroup --
+    ranges that span pair boundaries (several segments) and exceed the 8 chunks whose wave sums are
+    parked in LDS between two combining passes.  Every pair's 28 sums equal its lone evaluation."""
+    ident = np.array([0, 0, 0, 1, 0, 0, 0.0])
+    ps, ls, pt, lt, T, cm = synth.lidar_pair(seed=6, n_points=60000)
+    rng = np.random.default_rng(13)
+    engines, ref, qts = [], [], []
+    try:
+        for k in range(48):
+            e, p = make_engine(sicp.MODE_EM, 11, cm)
+            if k == 0:
+                e.set_source(ps, ls); e.set_target(pt, lt)
+            else:  # the same two clouds, shared: 48 handles, 2 clouds
+                e.share_cloud(sicp.SOURCE, engines[0], sicp.SOURCE); e.share_cloud(sicp.TARGET, engines[0], sicp.TARGET)
+            e.correspondences(ident)
+            qt = mat_to_qt(T)
+            qt[4:] += rng.normal(0, 0.01, 3)  # every pair is evaluated at its own pose
+            engines.append(e); qts.append(qt); ref.append(e.accumulate(qt))
+        out, ms = sicp.accumulate_batch(engines, np.array(qts))
+        for p in range(len(engines)):
+            assert np.array_equal(out[p], ref[p]), p
+        assert len({tuple(r) for r in ref}) == 48
+    finally:
+        for e in engines:
+            e.close()
