@@ -434,8 +434,36 @@ __device__ __forceinline__ float quad_bound(const u64 (&bk)[K]) {
   return fminf(quad_min(own_k), quad_max(own_m));
 }
 
+// K = 4: branch-free.  The lane's four candidates are sorted among themselves (5 compare-exchanges) and
+// merged with its ascending list the bitonic way: min(list[i], cand[3 - i]) are the four smallest of the
+// eight, as a bitonic sequence that two more rounds of compare-exchanges sort -- 22 v_min / v_max_f64
+// instead of four guarded insertions (a 64-bit compare, an exec-mask branch and a 7-instruction carry
+// chain each; some lane of the wave almost always inserts, so the wave almost always ran them all).
+// Candidates beyond the quad bound may now enter a lane's list; they are beyond the true K-th
+// distance, so the merged result -- the K smallest keys of everything seen -- is the same.
+__device__ __forceinline__ void scan_leaf_quad4(const float4* __restrict__ pts, float px, float py, float pz, u64 (&bk)[4], float& wd) {
+  float4 t[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) t[p] = pts[4 * p];
+  u64 c[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) c[p] = make_key(l2_simple(px, py, pz, t[p].x, t[p].y, t[p].z), __float_as_uint(t[p].w));
+  key_cswap(c[0], c[1]); key_cswap(c[2], c[3]); key_cswap(c[0], c[2]); key_cswap(c[1], c[3]); key_cswap(c[1], c[2]);
+  double l[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const double a = __longlong_as_double((long long)bk[i]), b = __longlong_as_double((long long)c[3 - i]);
+    asm("v_min_f64 %0, %1, %2" : "=v"(l[i]) : "v"(a), "v"(b));
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) bk[i] = (u64)__double_as_longlong(l[i]);
+  key_cswap(bk[0], bk[2]); key_cswap(bk[1], bk[3]); key_cswap(bk[0], bk[1]); key_cswap(bk[2], bk[3]);
+  wd = quad_bound<4>(bk);
+}
+
 template <int K>
 __device__ __forceinline__ void scan_leaf_quad(const float4* __restrict__ pts, float px, float py, float pz, u64 (&bk)[K], float& wd) {
+  if constexpr (K == 4) { scan_leaf_quad4(pts, px, py, pz, bk, wd); return; }
   float4 t[4];
 #pragma unroll
   for (int p = 0; p < 4; ++p) t[p] = pts[4 * p];  // lane s of the quad takes points s, s+4, s+8, s+12: a mixed quarter
