@@ -200,7 +200,7 @@ struct BatchHeader {
   int pad_[3];
 };
 
-// [accumulate_stream, lm_step_batch] x len of a lock-step batch as an instantiated graph with explicit
+// [accumulate, lm_step_batch] x len of a lock-step batch as an instantiated graph with explicit
 // kernel nodes and fixed grids (solve_kernels.hip)
 constexpr int kMaxBatchLen = 32;
 struct BatchGraph {

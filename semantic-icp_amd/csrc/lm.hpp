@@ -13,7 +13,7 @@
 //     while (s.status == LM_RUNNING) { evaluate out28 at s.pose;  lm_feed(s, out28); }
 // so the same code drives the host loop (sicp_api.cpp) and the device-resident solve, where
 // lm_feed runs in a one-block kernel right after each accumulate kernel and the host only looks at
-// s.status once per batch of launches (solve_kernels.hip: lm_step_kernel).
+// s.status once per batch of launches (solve_kernels.hip: lm_step_batch_kernel).
 //
 // Unlike Ceres, one evaluation returns cost, gradient and H together, so an accepted step does
 // not need a second sweep at the same point (Ceres evaluates the candidate cost first and the
