@@ -9,14 +9,13 @@
 // Design notes (MI355X).  The correspondence slots of a pair are cut into CHUNKS of 512 m groups of
 // SG slots (SG = 4 slots of one source point for K = 4 / 20, 2 source points for K = 1; m = 1 up to
 // 2M slots): a chunk is what one 256-lane workgroup sums -- every lane takes 2 m groups, 256 apart, in
-// ascending order, then the 28 sums go through an LDS transpose and DPP row reductions into
-// partials[28][n_chunks].  The chunk is the unit of reproducibility: whoever evaluates it (one
-// workgroup per chunk for a pair alone, a persistent workgroup walking over the chunks of all pairs
-// of a lock-step batch) performs the same additions in the same order, so a pair gets the same bits
-// alone and in a batch, run after run.  No floating-point atomics.  Points are read as 48-byte
-// records {x, y, z f32 | nx, ny, nz f64} -- one gather per target instead of six.  Nothing here is
-// GEMM shaped: no MFMA.  The file is compiled with -ffp-contract=off; fused multiply-adds are
-// re-enabled per function where the float64 algebra only needs tolerance-level parity.
+// ascending order; every wave then sums its own lanes (LDS transpose + DPP), and the four waves' sums
+// are joined in a fixed order into column `chunk` of partials[28][n_chunks].  The chunk is the unit of
+// reproducibility: ONE kernel evaluates it for every caller (a pair alone is a batch of one), so a
+// pair gets the same bits alone and in a batch, run after run.  No floating-point atomics.  Points are
+// read as 48-byte records {x, y, z f32 | nx, ny, nz f64} -- one gather per target instead of six.
+// Nothing here is GEMM shaped: no MFMA.  The file is compiled with -ffp-contract=off; fused
+// multiply-adds are re-enabled per function where the float64 algebra only needs tolerance-level parity.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -869,7 +868,7 @@ hipError_t launch_se3_ops(int op, int n, const double* in, double* out, hipStrea
 int accumulate_blocks(int total, int K) { return acc_geometry(total, acc_slots_per_group(K)).n_chunks; }
 
 // ---- the batched evaluation --------------------------------------------------------------------
-static void* accumulate_stream_fn(int K, int use_sqloss) {
+static void* accumulate_fn(int K, int use_sqloss) {
   switch (K) {
     case 1: return use_sqloss ? (void*)accumulate_staged_kernel<1, true, 256> : (void*)accumulate_staged_kernel<1, false, 256>;
     case 4: return use_sqloss ? (void*)accumulate_staged_kernel<4, true, 256> : (void*)accumulate_staged_kernel<4, false, 256>;
@@ -878,7 +877,7 @@ static void* accumulate_stream_fn(int K, int use_sqloss) {
   }
 }
 
-int accumulate_stream_grid() {
+int accumulate_grid() {
   // persistent workgroups: two per CU (two waves per SIMD).  SICP_ACC_GRID is a tuning aid.
   static const int grid = [] {
     const char* e = getenv("SICP_ACC_GRID");
@@ -896,10 +895,10 @@ static size_t stream_smem_bytes(int capacity, int K) {
 }
 
 hipError_t launch_accumulate_batch(int K, int use_sqloss, const BatchHeader* hdr, const BatchArgs* batch, int capacity, hipStream_t st) {
-  void* fn = accumulate_stream_fn(K, use_sqloss);
+  void* fn = accumulate_fn(K, use_sqloss);
   if (!fn) return hipErrorInvalidValue;
   void* args[] = {(void*)&hdr, (void*)&batch};
-  return hipLaunchKernel(fn, dim3(accumulate_stream_grid()), dim3(256), args, stream_smem_bytes(capacity, K), st);
+  return hipLaunchKernel(fn, dim3(accumulate_grid()), dim3(256), args, stream_smem_bytes(capacity, K), st);
 }
 
 hipError_t launch_lm_step_batch(const BatchHeader* hdr, const BatchArgs* batch, int capacity, hipStream_t st) {
@@ -914,7 +913,7 @@ hipError_t launch_finalize_batch(const BatchArgs* batch, int n, double* out28, h
   return hipGetLastError();
 }
 
-// [accumulate_stream, lm_step_batch] x len as an instantiated graph with explicit kernel nodes.  Both
+// [accumulate, lm_step_batch] x len as an instantiated graph with explicit kernel nodes.  Both
 // grids are fixed (persistent workgroups; one step block per slot of the batch buffers) and the
 // kernels read the number of active pairs / items from the header in HBM, so the graph only depends
 // on the buffers' addresses: it is built once per batch context.
@@ -927,7 +926,7 @@ void batch_graph_destroy(BatchGraph& g) {
 hipError_t batch_graph_prepare(BatchGraph& g, int K, int use_sqloss, const BatchHeader* hdr, const BatchArgs* batch, int capacity, int len,
                                int* built) {
   *built = 0;
-  void* fn = accumulate_stream_fn(K, use_sqloss);
+  void* fn = accumulate_fn(K, use_sqloss);
   if (capacity <= 0 || len < 1 || len > kMaxBatchLen || !fn) return hipErrorInvalidValue;
   if (g.exec && g.K == K && g.sqloss == use_sqloss && g.len == len && g.batch == batch && g.hdr == hdr && g.capacity == capacity) return hipSuccess;
   batch_graph_destroy(g);
@@ -935,7 +934,7 @@ hipError_t batch_graph_prepare(BatchGraph& g, int K, int use_sqloss, const Batch
   hipKernelNodeParams pa, ps;
   memset(&pa, 0, sizeof pa);
   pa.func = fn;
-  pa.gridDim = dim3(accumulate_stream_grid());
+  pa.gridDim = dim3(accumulate_grid());
   pa.blockDim = dim3(256);
   pa.sharedMemBytes = (unsigned)stream_smem_bytes(capacity, K);
   pa.kernelParams = args;
