@@ -467,12 +467,30 @@ __device__ __forceinline__ void scan_leaf_quad(const float4* __restrict__ pts, f
   float4 t[4];
 #pragma unroll
   for (int p = 0; p < 4; ++p) t[p] = pts[4 * p];  // lane s of the quad takes points s, s+4, s+8, s+12: a mixed quarter
+  if constexpr (K >= 8) {
+    // Long lists: an insertion is 2 K instructions and the WAVE runs it whenever any of its 64 lanes
+    // inserts.  The lane's 4 candidates are sorted first (10 instructions); a lane then inserts them in
+    // ascending order, and a candidate that fails (beyond the quad bound or the lane's own K-th key) is
+    // followed only by larger ones -- so the wave stops at the first round in which no lane inserts,
+    // instead of running all four insertions almost every time.
+    u64 c[4];
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const float d = l2_simple(px, py, pz, t[p].x, t[p].y, t[p].z);
-    if (!(d > wd)) {  // beyond the quad bound it cannot be among the K nearest
-      const u64 key = make_key(d, __float_as_uint(t[p].w));
-      if (key < bk[K - 1]) key_insert<K>(bk, key);
+    for (int p = 0; p < 4; ++p) c[p] = make_key(l2_simple(px, py, pz, t[p].x, t[p].y, t[p].z), __float_as_uint(t[p].w));
+    key_cswap(c[0], c[1]); key_cswap(c[2], c[3]); key_cswap(c[0], c[2]); key_cswap(c[1], c[3]); key_cswap(c[1], c[2]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool pass = !(key_dist(c[r]) > wd) && c[r] < bk[K - 1];
+      if (__ballot(pass) == 0) break;
+      if (pass) key_insert<K>(bk, c[r]);
+    }
+  } else {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const float d = l2_simple(px, py, pz, t[p].x, t[p].y, t[p].z);
+      if (!(d > wd)) {  // beyond the quad bound it cannot be among the K nearest
+        const u64 key = make_key(d, __float_as_uint(t[p].w));
+        if (key < bk[K - 1]) key_insert<K>(bk, key);
+      }
     }
   }
   wd = quad_bound<K>(bk);
