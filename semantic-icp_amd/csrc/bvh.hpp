@@ -108,19 +108,30 @@ SICP_HD inline uint64_t curve_code_coarse(float x, float y, float z, float lox, 
   return h << (3 * (21 - BITS));
 }
 
-// levels of the implicit tree over n points (node counts only depend on n)
+// Levels of the implicit tree over n points.  The tree is COMPLETE: 4^top leaves (top = the smallest
+// height that holds the ceil(n / 16) real ones), 4^(top - L) nodes on level L, leaves first.  Leaves
+// beyond the real ones hold sentinel points (+inf, caller index -1) and, like every node without a real
+// point below it, an inverted box (lo = +inf, hi = -inf: its distance bound is +inf).  So a walk needs
+// no node counts and no clamps, and a level's offset is arithmetic (level_offset) instead of a table
+// load in the dependent chain of every node visit.
 inline TreeLevels make_levels(int n) {
   TreeLevels lv;
   std::memset(&lv, 0, sizeof lv);
-  int cnt = std::max(1, (n + kLeaf - 1) / kLeaf), off = 0, L = 0;
-  for (;;) {
-    lv.off[L] = off; lv.cnt[L] = cnt;
-    off += cnt; ++L;
-    if (cnt == 1 || L == kMaxLevels) break;
-    cnt = (cnt + kFan - 1) / kFan;
+  const int real_leaves = std::max(1, (n + kLeaf - 1) / kLeaf);
+  int top = 0;
+  while ((1 << (2 * top)) < real_leaves && top + 1 < kMaxLevels) ++top;
+  int off = 0;
+  for (int L = 0; L <= top; ++L) {
+    lv.off[L] = off; lv.cnt[L] = 1 << (2 * (top - L));
+    off += lv.cnt[L];
   }
-  lv.n_levels = L;
+  lv.n_levels = top + 1;
   return lv;
+}
+// offset of level L in a complete tree of height top: sum of 4^(top - i), i < L
+SICP_HD inline int level_offset(int top, int L) {
+  const unsigned t4 = 1u << (2 * (top + 1));
+  return (int)((t4 - (t4 >> (2 * L))) / 3u);
 }
 inline int total_nodes(const TreeLevels& lv) { return lv.off[lv.n_levels - 1] + lv.cnt[lv.n_levels - 1]; }
 

@@ -633,13 +633,13 @@ __device__ __forceinline__ int xcd_contiguous_block(int bid, int nblk) {
   return xcd < r ? xcd * (q + 1) + loc : r * (q + 1) + (xcd - r) * q + loc;
 }
 
+// (the tree is complete -- bvh.hpp: make_levels -- so every child exists; the ones without a real point
+// below them have inverted boxes, i.e. lb = +inf)
 __device__ __forceinline__ unsigned child_mask_packet(const float4* __restrict__ blo, const float4* __restrict__ bhi, int child_off,
-                                                      int child_cnt, int parent, int sub, float px, float py, float pz, float wd,
-                                                      float& lb) {
-  const int c = parent * kFan + sub;
-  const int node = child_off + min(c, child_cnt - 1);
+                                                      int parent, int sub, float px, float py, float pz, float wd, float& lb) {
+  const int node = child_off + parent * kFan + sub;
   lb = box_lb(blo[node], bhi[node], px, py, pz);
-  const bool ok = c < child_cnt && !(lb > wd);  // lb == wd may hide an equal distance with a lower index
+  const bool ok = !(lb > wd);  // lb == wd may hide an equal distance with a lower index
   u64 b = __ballot(ok);                         // bit 4*q + c
   b |= b >> 32; b |= b >> 16; b |= b >> 8; b |= b >> 4;
   return (unsigned)b & 15u;
@@ -754,31 +754,37 @@ __device__ __forceinline__ void knn_packet_body(const KnnArgs& a, int wg, int n_
     // the leaf's box is not loaded a second time -- one dependent load less per leaf visit, and the
     // launch lasts as long as its longest chain of dependent loads.
     float child_lb;
-    masks = (u64)child_mask_packet(blo, bhi, a.tree.lv.off[L], a.tree.lv.cnt[L], 0, sub, px, py, pz, wd, child_lb) << (4 * L);
+    // scalar state kept lean (this bookkeeping is half of the walk's instructions): sh = 4 * level, the
+    // level's sibling bits are always zero when the walk descends into it (they were consumed on the way
+    // up), unsigned arithmetic for the shifts
+    const unsigned t4 = 1u << (2 * (top + 1));  // level_offset(top, l) = (t4 - (t4 >> 2 l)) / 3
+    unsigned sh = 4u * (unsigned)L, ubase = 0u;
+    const unsigned sh_top = sh;
+    masks = (u64)child_mask_packet(blo, bhi, level_offset(top, L), 0, sub, px, py, pz, wd, child_lb) << sh;
     for (;;) {
       int leaf = -1;
       for (;;) {
-        const unsigned m = (unsigned)(masks >> (4 * L)) & 15u;
+        const unsigned m = (unsigned)(masks >> sh) & 15u;
         if (m == 0) {
-          if (L == top - 1) break;
-          ++L;
-          base = (base / kFan) & ~(kFan - 1);
+          if (sh == sh_top) break;
+          sh += 4u;
+          ubase = (ubase >> 2) & ~3u;
           continue;
         }
-        const int c = __ffs(m) - 1;
-        masks &= ~(1ull << (4 * L + c));
-        const int node = base + c;
-        if (L == 1 && node == seed) continue;
-        if (L == 0) {
+        const unsigned c = (unsigned)__ffs(m) - 1u;
+        masks ^= 1ull << (sh + c);
+        const unsigned node = ubase + c;
+        if (sh == 0u) {
           // the bounds may have tightened since the parent's test; the lanes with sub == c hold this leaf's
-          if (__ballot(sub == c && !(child_lb > wd)) != 0) { leaf = node; break; }
-        } else {
-          ++n_box;
-          const unsigned cm = child_mask_packet(blo, bhi, a.tree.lv.off[L - 1], a.tree.lv.cnt[L - 1], node, sub, px, py, pz, wd, child_lb);
-          --L;
-          masks = (masks & ~(15ull << (4 * L))) | ((u64)cm << (4 * L));
-          base = node * kFan;
+          if (__ballot((unsigned)sub == c && !(child_lb > wd)) != 0) { leaf = (int)node; break; }
+          continue;
         }
+        if (sh == 4u && node == (unsigned)seed) continue;
+        ++n_box;
+        sh -= 4u;
+        const unsigned cm = child_mask_packet(blo, bhi, (int)((t4 - (t4 >> (sh >> 1))) / 3u), (int)node, sub, px, py, pz, wd, child_lb);
+        masks |= (u64)cm << sh;
+        ubase = node * kFan;
       }
       if (leaf < 0) break;
       scan_leaf_quad<K>(pts + (size_t)leaf * kLeaf, px, py, pz, bk, wd);

@@ -353,8 +353,8 @@ int prepare_cloud(sicp_context* h, Cloud& c) {
     sicp::BuildSegment& g = segs[sg];
     g.off = c.seg_off[sg]; g.cnt = counts[sg];
     c.seg_off[sg + 1] = g.off + g.cnt;
-    g.padded = std::max(1, (g.cnt + sicp::kLeaf - 1) / sicp::kLeaf) * sicp::kLeaf;
     g.lv = sicp::make_levels(g.cnt);
+    g.padded = g.lv.cnt[0] * sicp::kLeaf;  // every leaf of the complete tree owns 16 point slots (sentinels beyond the real points)
     g.pt_begin = pt_total; g.node_begin = node_total; g.code_begin = code_total;
     pt_total += g.padded; node_total += sicp::total_nodes(g.lv); code_total += g.lv.cnt[0];
     float ext = 0.f;
