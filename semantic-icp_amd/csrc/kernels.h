@@ -239,6 +239,14 @@ int accumulate_blocks(int total, int K);  // chunks of a pair with `total` slots
 hipError_t launch_accumulate_batch(int K, int use_sqloss, const BatchHeader* hdr, const BatchArgs* batch, int capacity, hipStream_t st);
 hipError_t launch_lm_step_batch(const BatchHeader* hdr, const BatchArgs* batch, int capacity, hipStream_t st);
 hipError_t launch_finalize_batch(const BatchArgs* batch, int n, double* out28, hipStream_t st);
+// pairs that start an inner solve with the next tick: their LM states are initialised ON the device from
+// one small upload (states[j.pair] = lm_init(j.opt, j.start)) instead of one 800-byte copy per pair
+struct LmJoin {
+  int pair, pad_;
+  double start[7];
+  LmOptions opt;
+};
+hipError_t launch_lm_init(const LmJoin* joins, int n, LmState* states, hipStream_t st);
 hipError_t launch_count_active(const int* idx, int n, unsigned long long* out, hipStream_t st);
 // test hook: csrc/se3.hpp on the device, one lane per item (op = SICP_SE3_*; in/out strides per op)
 hipError_t launch_se3_ops(int op, int n, const double* in, double* out, hipStream_t st);

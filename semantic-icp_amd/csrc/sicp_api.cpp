@@ -205,6 +205,8 @@ struct TickSet {
   DevBuf<sicp::BatchHeader> d_bhdr;
   sicp::BatchHeader* h_bhdr = nullptr;
   sicp::BatchArgs* h_batch = nullptr;
+  sicp::LmJoin* h_join = nullptr;  // pinned: the pairs that join with the next tick
+  DevBuf<sicp::LmJoin> d_join;
   int cap = 0;
   sicp::BatchGraph graph;
   std::vector<int> tick_act;  // the pairs whose arguments d_batch currently holds
@@ -891,10 +893,13 @@ int tickset_reserve(sicp_context* h, TickSet& S, int n) {
   HIPCHECK(S.d_batch.reserve(n));
   HIPCHECK(S.d_bhdr.reserve(1));
   if (!S.h_bhdr) HIPCHECK(hipHostMalloc((void**)&S.h_bhdr, sizeof(sicp::BatchHeader), hipHostMallocDefault));
+  HIPCHECK(S.d_join.reserve(n));
   if (S.cap < n) {
     if (S.h_batch) (void)hipHostFree(S.h_batch);
-    S.h_batch = nullptr; S.cap = 0;
+    if (S.h_join) (void)hipHostFree(S.h_join);
+    S.h_batch = nullptr; S.h_join = nullptr; S.cap = 0;
     HIPCHECK(hipHostMalloc((void**)&S.h_batch, sizeof(sicp::BatchArgs) * n, hipHostMallocDefault));
+    HIPCHECK(hipHostMalloc((void**)&S.h_join, sizeof(sicp::LmJoin) * n, hipHostMallocDefault));
     S.cap = n;
   }
   return SICP_OK;
@@ -991,9 +996,16 @@ struct BatchGuard {
 // states of pairs [lo, hi) into h_bstates); the caller synchronises M when it wants the result.
 int tick_launch(sicp_context* h, TickSet& S, hipStream_t M, sicp_handle* hs, int lo, int hi, const std::vector<int>& act,
                 const std::vector<int>& joining, const double (*start)[7], int len) {
-  for (int p : joining) {
-    sicp::lm_init(h->h_bstates[p], lm_options(hs[p]->params), start[p]);
-    HIPCHECK(hipMemcpyAsync(h->d_bstates.p + p, h->h_bstates + p, sizeof(sicp::LmState), hipMemcpyHostToDevice, M));
+  if (!joining.empty()) {  // their LM states are initialised on the device: one upload + one tiny kernel
+    int k = 0;
+    for (int p : joining) {
+      sicp::LmJoin& J = S.h_join[k++];
+      J.pair = p; J.pad_ = 0;
+      std::memcpy(J.start, start[p], sizeof J.start);
+      J.opt = lm_options(hs[p]->params);
+    }
+    HIPCHECK(hipMemcpyAsync(S.d_join.p, S.h_join, sizeof(sicp::LmJoin) * joining.size(), hipMemcpyHostToDevice, M));
+    HIPCHECK(sicp::launch_lm_init(S.d_join.p, (int)joining.size(), h->d_bstates.p, M));
   }
   // the argument array in HBM only changes when the set of pairs inside a solve does
   const bool same_set = S.tick_valid && joining.empty() && S.tick_act == act;
@@ -1163,6 +1175,7 @@ int sicp_destroy(sicp_handle h) {
   if (h->h_lm) (void)hipHostFree(h->h_lm);
   for (TickSet& S : h->ts) {
     if (S.h_batch) (void)hipHostFree(S.h_batch);
+    if (S.h_join) (void)hipHostFree(S.h_join);
     if (S.h_bhdr) (void)hipHostFree(S.h_bhdr);
     sicp::batch_graph_destroy(S.graph);
   }

@@ -907,6 +907,21 @@ hipError_t launch_lm_step_batch(const BatchHeader* hdr, const BatchArgs* batch, 
   return hipGetLastError();
 }
 
+__global__ __launch_bounds__(64) void lm_init_kernel(const LmJoin* __restrict__ joins, int n, LmState* __restrict__ states) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const LmJoin j = joins[k];
+  LmState s;
+  lm_init(s, j.opt, j.start);
+  states[j.pair] = s;
+}
+
+hipError_t launch_lm_init(const LmJoin* joins, int n, LmState* states, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(lm_init_kernel, dim3((n + 63) / 64), dim3(64), 0, st, joins, n, states);
+  return hipGetLastError();
+}
+
 hipError_t launch_finalize_batch(const BatchArgs* batch, int n, double* out28, hipStream_t st) {
   if (n <= 0) return hipSuccess;
   hipLaunchKernelGGL(finalize_batch_kernel, dim3(n), dim3(REDUCE_THREADS), 0, st, batch, out28);
