@@ -304,6 +304,15 @@ int set_device(sicp_context* h) {
 }
 
 // ---- cloud layout -----------------------------------------------------------------------------
+// A cloud's upload is recorded in an event on the uploading handle's stream, and the cloud may outlive
+// that handle (it is shared, or goes back to the pool).  Waiting for an event whose stream has been
+// destroyed is not safe with this runtime (it intermittently answers "event last recorded in a
+// capturing stream"), so a handle settles every cloud it lets go of while its streams still exist.
+void settle_cloud(Cloud& c) {
+  if (c.pending && c.ready_ev) (void)hipEventSynchronize(c.ready_ev);
+  c.pending = false;
+}
+
 int cloud_wait(sicp_context* h, Cloud& c) {
   if (c.pending) {
     HIPCHECK(hipEventSynchronize(c.ready_ev));
@@ -1170,6 +1179,8 @@ int sicp_destroy(sicp_handle h) {
   if (!h) return SICP_OK;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (auto& c : h->cl)
+    if (c) settle_cloud(*c);  // before the streams go (see settle_cloud)
   if (h->h_out28) (void)hipHostFree(h->h_out28);
   if (h->h_count) (void)hipHostFree(h->h_count);
   if (h->h_lm) (void)hipHostFree(h->h_lm);
@@ -1242,7 +1253,10 @@ int sicp_set_cloud(sicp_handle h, int which, int32_t n, const float* x, const fl
   if (!h || (which != SICP_SOURCE && which != SICP_TARGET) || n < 0) return SICP_ERR_INVALID_ARGUMENT;
   if (n > 0 && (!x || !y || !z)) return SICP_ERR_INVALID_ARGUMENT;
   SICPCHECK(set_device(h));
-  if (h->cl[which].use_count() > 1) h->cl[which] = acquire_cloud(h->device);  // shared with another handle: leave theirs alone
+  if (h->cl[which].use_count() > 1) {  // shared with another handle: leave theirs alone
+    settle_cloud(*h->cl[which]);
+    h->cl[which] = acquire_cloud(h->device);
+  }
   Cloud& c = h->cloud(which);
   SICPCHECK(cloud_wait(h, c));  // a previous upload may still be reading the staging buffers
   c.n = n;
@@ -1290,6 +1304,7 @@ int sicp_share_cloud(sicp_handle h, int which, sicp_handle from, int from_which)
     return SICP_ERR_INVALID_ARGUMENT;
   }
   if (!from->cloud(from_which).is_set) return SICP_ERR_NOT_READY;
+  if (h->cl[which] && h->cl[which] != from->cl[from_which]) settle_cloud(*h->cl[which]);
   h->cl[which] = from->cl[from_which];
   h->corr_valid = false;
   h->hint_ok = false;

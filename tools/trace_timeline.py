@@ -31,7 +31,7 @@ for b in range(nb):
 # optional 4th/5th argument: zoom window [from_ms, to_ms) relative to the start of the analysed span, fine bins
 if len(sys.argv) > 5:
     z0, z1 = t0 + float(sys.argv[4]) * 1e6, t0 + float(sys.argv[5]) * 1e6
-    fb = 0.25e6
+    fb = float(sys.argv[6]) * 1e6 if len(sys.argv) > 6 else 0.25e6
     nz = int((z1 - z0) / fb)
     za = [collections.Counter() for _ in range(nz)]
     for s, e, k in ev:
@@ -42,6 +42,6 @@ if len(sys.argv) > 5:
             be = z0 + (b + 1) * fb
             za[b][k] += min(e, be) - s
             s = be; b += 1
-    print("zoom (0.25 ms bins)")
+    print(f"zoom ({fb / 1e6} ms bins)")
     for b in range(nz):
-        print(f"{(z0 - t0) / 1e6 + b * 0.25:7.2f}  " + " ".join(f"{za[b][k] / fb:6.2f}" for k in kinds))
+        print(f"{(z0 - t0) / 1e6 + b * fb / 1e6:7.2f}  " + " ".join(f"{za[b][k] / fb:6.2f}" for k in kinds))

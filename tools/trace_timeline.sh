@@ -8,4 +8,4 @@ timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl_$tag -- pyth
 f=$(find /tmp/tl_$tag -name '*kernel_trace.csv' 2>/dev/null | head -1)
 if [ -z "$f" ]; then echo "no trace"; tail -3 gpurun_out/tl_${tag}.err; exit 1; fi
 tail -1 gpurun_out/tl_${tag}.json | cut -c1-200
-python3 tools/trace_timeline.py "$f" $bin $last $ZOOM0 $ZOOM1
+python3 tools/trace_timeline.py "$f" $bin $last $ZOOM0 $ZOOM1 $ZOOMBIN
