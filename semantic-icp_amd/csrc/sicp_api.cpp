@@ -931,9 +931,15 @@ int batch_reserve(sicp_context* h, int n) {
   return SICP_OK;
 }
 
-// slice of the batch a pair belongs to: SICP_BATCH_PARTS (default 4) contiguous slices of >= 2 pairs
-int batch_slice(int p, int n) {
-  static const int want = [] { const char* e = std::getenv("SICP_BATCH_PARTS"); return e ? std::atoi(e) : 4; }();
+// slice of the batch a pair belongs to: SICP_BATCH_PARTS contiguous slices of >= 2 pairs (default: 2 for
+// K > 1, 4 for K = 1).  Measured at the end of round 2 (100K-point pairs; G corr/s at 1 / 2 / 3 / 4 slices):
+// EM-ICP K = 4: 16 pairs 1.22 / 1.26 / 1.09 / 1.04, 64 pairs 1.49 / 1.55 / 1.55 / 1.46, 256 pairs 1.71 / 1.81 /
+// 1.81 / 1.74 -- two streams of job launches overlap one slice's small kernels with the other's search
+// tails, more of them only split the search launches into smaller, tail-bound ones; SE3-GICP K = 1 (cheap
+// searches, short accumulate launches) at 256 pairs: 0.71 with 2 slices, 0.78 with 4.
+int batch_slice(int p, int n, int knn) {
+  static const int env = [] { const char* e = std::getenv("SICP_BATCH_PARTS"); return e ? std::atoi(e) : 0; }();
+  const int want = env > 0 ? env : knn <= 1 ? 4 : 2;
   const int parts = std::max(1, std::min(std::min(want, kParts), n / 2));
   return (int)((long long)p * parts / n);
 }
@@ -1396,7 +1402,7 @@ int sicp_align_batch(sicp_handle* hs, int32_t n, const double* init_qt, double* 
   const unsigned long long epoch = next_epoch();
   for (int p = 0; p < n; ++p) {
     hs[p]->epoch = epoch;
-    jc.slice = batch_slice(p, n);
+    jc.slice = batch_slice(p, n, P.knn);
     SICPCHECK(align_begin(hs[p], stats != nullptr));
   }
   if (one_launch) {
@@ -1516,7 +1522,7 @@ int sicp_align_batch(sicp_handle* hs, int32_t n, const double* init_qt, double* 
       if (phase[p] != NEED_SEARCH) continue;
       std::memcpy(o[p].est, o[p].cur, sizeof o[p].est);
       if (P.mode == SICP_MODE_SEMANTIC) o[p].count++;
-      jc.slice = batch_slice(p - G.lo, G.hi - G.lo);
+      jc.slice = batch_slice(p - G.lo, G.hi - G.lo, P.knn);
       SICPCHECK(run_correspondences(hs[p], o[p].cur, P.knn, true));
       phase[p] = JOINING;
       search_round[p] = G.round;
