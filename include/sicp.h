@@ -199,7 +199,7 @@ int sicp_align(sicp_handle h, const double init_qt[7], double out_qt[7],
                int32_t* outer_iters, sicp_stats* stats);
 /* n independent align() calls -- one handle per scan pair, all on one device, same mode /
  * knn / solver knobs -- batched continuously: every launch of the inner solve evaluates the
- * pairs that are inside a solve (up to 128; with more, the others wait with their search done),
+ * pairs that are inside a solve (up to 256; with more, the others wait with their search done),
  * the searches of the pairs between two solves run between the launches (what
  * exec/kitti_eval.cc:124-249 does pair after pair).  Per pair the result is bit-identical to
  * sicp_align on that handle.  init_qt, out_qt: n*7; outer_iters (nullable): n; stats

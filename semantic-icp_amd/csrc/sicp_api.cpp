@@ -715,7 +715,8 @@ void fill_acc(sicp_context* h, sicp::AccArgs& a) {
   a.partials = h->partials.p;
 }
 
-constexpr int kMaxActivePairs = 128;  // per-pair constants of the batched kernel live in LDS
+// pairs one launch evaluates (12 bytes of LDS each in the accumulate kernel).  SICP_MAX_ACTIVE: tuning aid.
+const int kMaxActivePairs = [] { const char* e = std::getenv("SICP_MAX_ACTIVE"); const int v = e ? std::atoi(e) : 256; return std::min(std::max(v, 1), 512); }();
 int batch_reserve(sicp_context* h, int n);
 int run_tick(sicp_context* h, hipStream_t M, sicp_handle* hs, int n, const std::vector<int>& act, const std::vector<int>& joining,
              const double (*start)[7], int len);

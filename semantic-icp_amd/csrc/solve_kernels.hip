@@ -596,7 +596,7 @@ __global__ __launch_bounds__(BS, SICP_ACC_OCC) void accumulate_staged_kernel(con
   __syncthreads();
   // equal ranges; with fewer chunks than workgroups, one chunk each for the FIRST workgroups (they are
   // dispatched to different CUs; spreading b * T / G would put two working groups on some CUs and none
-  // on others).  T <= 128 pairs x 1024 chunks and gridDim.x < 2^12: the products fit 32 bits.
+  // on others).  T <= 512 pairs x 1024 chunks and gridDim.x < 2^12: the products fit 32 bits.
   const unsigned T = (unsigned)total_running, G = gridDim.x, b = blockIdx.x;
   int item = T < G ? (int)b : (int)(b * T / G);
   const int item_end = T < G ? (b < T ? (int)b + 1 : (int)b) : (int)((b + 1) * T / G);

@@ -611,12 +611,12 @@ def test_align_batch_of_sixty_pairs_one_tick_group():
 
 
 def test_align_batch_of_more_pairs_than_one_launch_holds():
-    """A launch evaluates at most 128 pairs: in a batch of 150 the others wait with their search done
+    """A launch evaluates at most 256 pairs: in a batch of 280 the others wait with their search done
     and join as slots free up.  Same bits and counters as lone aligns."""
     rng = np.random.default_rng(12)
     engines, singles = [], []
     try:
-        for k in range(150):
+        for k in range(280):
             n = int(rng.integers(300, 1200))
             tgt = rng.uniform(0, 6, (n, 3)).astype(np.float32)
             tgt[:, 2] = (0.1 * np.sin(tgt[:, 0]) + 0.05 * tgt[:, 1]).astype(np.float32)
