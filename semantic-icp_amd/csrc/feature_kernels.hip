@@ -142,11 +142,48 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a) {
   a.proj[e] = temp;
 }
 
+// The same projection, one LANE PER POINT (C <= PROJ_CMAX): the point's C counts are read once and turned
+// into their table values, CM and the table sit in LDS (broadcast reads), the C results of a point are
+// formed in registers -- every one the same ascending sum of separately rounded products as above, so the
+// same bits -- and leave through LDS as one coalesced block.  The lane-per-output form above issues three
+// loads per term (33 per output, 36 M per 100K-point cloud) and was bound by that: 18 us per cloud.
+constexpr int PROJ_CMAX = 16;
+__device__ __forceinline__ void proj_rows_body(const ProjArgs& a) {
+  __shared__ double s_cm[PROJ_CMAX * PROJ_CMAX];
+  __shared__ double s_hval[64];
+  __shared__ double s_out[256 * PROJ_CMAX];
+  const int C = a.C;
+  for (int k = threadIdx.x; k < C * C; k += 256) s_cm[k] = a.cm[k];
+  for (int k = threadIdx.x; k <= 32; k += 256) s_hval[k] = a.hval[k];  // counts are at most k_cov <= 32 (the buffer carries slack: DevBuf)
+  __syncthreads();
+  const int i0 = blockIdx.x * 256, i = i0 + (int)threadIdx.x;
+  if (i0 >= a.n) return;
+  if (i < a.n) {
+    const uint8_t* h = a.hist + (size_t)i * C;
+    double hv[PROJ_CMAX];
+#pragma unroll
+    for (int r = 0; r < PROJ_CMAX; ++r) hv[r] = r < C ? s_hval[h[r]] : 0.0;
+    for (int s = 0; s < C; ++s) {
+      double temp = 0.0;
+#pragma unroll
+      for (int r = 0; r < PROJ_CMAX; ++r)
+        if (r < C) temp += hv[r] * s_cm[r * C + s];
+      s_out[threadIdx.x * C + s] = temp;
+    }
+  }
+  __syncthreads();
+  const int valid = min(256, a.n - i0) * C;
+  double* out = a.proj + (size_t)i0 * C;
+  for (int k = threadIdx.x; k < valid; k += 256) out[k] = s_out[k];
+}
+
 // ------------------------------------------------------------------------------------------
 // EM weight: label posterior from the confusion matrix x the (bool) geometric gate
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void proj_kernel(ProjArgs a) { proj_body(a); }
 __global__ __launch_bounds__(256) void proj_jobs_kernel(ProjJobs jobs) { proj_body(jobs.job[blockIdx.y]); }
+__global__ __launch_bounds__(256) void proj_rows_kernel(ProjArgs a) { proj_rows_body(a); }
+__global__ __launch_bounds__(256) void proj_rows_jobs_kernel(ProjJobs jobs) { proj_rows_body(jobs.job[blockIdx.y]); }
 
 __device__ __forceinline__ void em_weight_body(const WeightArgs& a) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -252,7 +289,8 @@ hipError_t launch_cov(const CovArgs& a, hipStream_t st) {
 hipError_t launch_proj(const ProjArgs& a, hipStream_t st) {
   const int total = a.n * a.C;
   if (total <= 0) return hipSuccess;
-  hipLaunchKernelGGL(proj_kernel, dim3((total + 255) / 256), dim3(256), 0, st, a);
+  if (a.C <= PROJ_CMAX) hipLaunchKernelGGL(proj_rows_kernel, dim3((a.n + 255) / 256), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(proj_kernel, dim3((total + 255) / 256), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 
@@ -280,10 +318,15 @@ hipError_t launch_proj_jobs(const ProjArgs* jobs, int n, hipStream_t st) {
   for (int b = 0; b < n; b += kMaxSmallJobs) {
     const int cnt = n - b < kMaxSmallJobs ? n - b : kMaxSmallJobs;
     ProjJobs J;
-    int mx = 0;
-    for (int i = 0; i < cnt; ++i) { J.job[i] = jobs[b + i]; const int t = jobs[b + i].n * jobs[b + i].C; mx = t > mx ? t : mx; }
+    int mx = 0, mx_n = 0, mx_c = 0;
+    for (int i = 0; i < cnt; ++i) {
+      J.job[i] = jobs[b + i];
+      const int t = jobs[b + i].n * jobs[b + i].C;
+      mx = t > mx ? t : mx; mx_n = jobs[b + i].n > mx_n ? jobs[b + i].n : mx_n; mx_c = jobs[b + i].C > mx_c ? jobs[b + i].C : mx_c;
+    }
     if (mx <= 0) continue;
-    hipLaunchKernelGGL(proj_jobs_kernel, dim3((mx + 255) / 256, cnt), dim3(256), 0, st, J);
+    if (mx_c <= PROJ_CMAX) hipLaunchKernelGGL(proj_rows_jobs_kernel, dim3((mx_n + 255) / 256, cnt), dim3(256), 0, st, J);
+    else hipLaunchKernelGGL(proj_jobs_kernel, dim3((mx + 255) / 256, cnt), dim3(256), 0, st, J);
   }
   return hipGetLastError();
 }
