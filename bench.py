@@ -8,7 +8,7 @@ subsampled to exactly 100 000 x 100 000 points -- the metric point of configs[1]
 A "step" registers one batch of independent scan pairs on each GPU: `--pairs-in-flight` S pairs
 (default 256 = ~30 GB of the 288 GB: the stragglers of a batch -- a pair that needs 500 evaluations
 when the median needs 150 -- weigh less the larger it is: 1.39 G corr/s at 32 pairs, 1.54 at 64, 1.69 at
-128, 1.83-1.84 at 256, 1.84 at 512), every one a DIFFERENT pair (its own street, ego-motion and noise: seeds
+128, 1.84-1.87 at 256, 1.84 at 512), every one a DIFFERENT pair (its own street, ego-motion and noise: seeds
 2 + S*rank + k) and a complete align() (covariances of both clouds + every outer ICP iteration:
 transform -> kNN -> EM weights -> inner LM solve) on its own handle, with all clouds already
 resident in HBM when the timed region starts.  Independent pairs are the reference's unit of work
