@@ -58,7 +58,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 N_POINTS = 100_000
 K_CORR = 4
 N_CLASSES = 11
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02", "pmc_hbm_traffic.json")
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r03")   # committed rocprofv3 summaries of this round's build
 
 
 def parse_args():
@@ -80,6 +80,10 @@ def parse_args():
     ap.add_argument("--sequence-pairs", type=int, default=128, help="registrations of the end-to-end sequence leg (0 = skip)")
     ap.add_argument("--timed-only", action="store_true", help="skip the other workloads / roofline / CPU legs (for tracing the timed region)")
     ap.add_argument("--dry-run", action="store_true", help="exercise the multi-process plumbing without a GPU")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="allow more ranks than visible devices (rank r uses device local_rank %% n_devices): the real N > 1 code path on a "
+                         "one-GPU box; the ranks then share the GPU, so the value is no scaling number")
+    ap.add_argument("--full-size-pairs", type=int, default=16, help="pairs of the full-size config-2 / config-3 batches (0 = skip)")
     return ap.parse_args()
 
 
@@ -115,7 +119,8 @@ class Dist:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.pg = None
         if self.world > 1:
-            import torch  # noqa: F401  (imported before libsicp so that both share one HIP runtime)
+            # gloo on CPU tensors only: torch never initialises HIP in this process (no .cuda(), no device query), so
+            # libsicp is the only user of the GPU and it does not matter which of the two is loaded first
             import torch.distributed as dist
 
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -141,7 +146,10 @@ class Dist:
             self.pg.destroy_process_group()
 
 
-# ---- synthetic data (worker processes: forked before this process touches the GPU) ---------------
+# ---- synthetic data ----------------------------------------------------------------------------------
+# ALL of it is generated at the top of main(): worker processes are forked while this process is still
+# single-threaded -- before torch.distributed starts its gloo threads and before libsicp loads the HIP
+# runtime (a fork of a process that holds a live, multi-threaded HIP runtime inherits its locks).
 def pair_motion(seed: int):
     """Ego-motion of the pair with this seed: seed 2 is the r01 pair (1 m, 2 deg); the others vary in
     forward step and yaw, so the pairs of a batch need different numbers of iterations."""
@@ -166,6 +174,22 @@ def gen_scan(job):
     return p, l
 
 
+def gen_full_scan_pair(seed):
+    """config 2: a full KITTI-like scan pair (~142K x 142K points, not subsampled)"""
+    import synth
+
+    src, sl, tgt, tl, T_gt, cm = synth.lidar_pair(seed=seed, n_points=None, motion=pair_motion(seed))
+    return src, sl, tgt, tl
+
+
+def gen_rgbd_pair(seed):
+    """config 3: a 640x480 RGB-D frame pair (307 200 x 307 200 points, 13 classes)"""
+    import synth
+
+    src, sl, tgt, tl, T_gt = synth.rgbd_pair(seed=seed)[:5]
+    return src, sl, tgt, tl
+
+
 def pool_map(fn, jobs, world):
     import concurrent.futures as cf
     import multiprocessing as mp
@@ -178,10 +202,10 @@ def pool_map(fn, jobs, world):
 
 
 # ---- legs outside the timed region ------------------------------------------------------------------
-def cpu_baseline(src, sl, tgt, tl, cm):
+def cpu_baseline(src, sl, tgt, tl, cm, repeats=3):
     """The CPU restatement of the reference PCL-KdTree + Ceres path (the oracle), timed on this
     host on the rank-0 pair: kNN + problem build on 1 thread (em_icp.hpp:57-156), residual /
-    Jacobian evaluation on 8 threads (em_icp.hpp:166)."""
+    Jacobian evaluation on 8 threads (em_icp.hpp:166).  `repeats` runs, the median is reported."""
     import numpy as np
 
     import oracle_lib as O
@@ -191,17 +215,22 @@ def cpu_baseline(src, sl, tgt, tl, cm):
     p.use_kdtree = 1
     threads = min(8, os.cpu_count() or 1)
     p.num_threads = threads
-    t0 = time.perf_counter()
-    qt, st = O.align(p, src, sl, tgt, tl, cm, np.array([0, 0, 0, 1, 0, 0, 0.0]))
-    dt = time.perf_counter() - t0
+    runs = []
+    for _ in range(max(1, repeats)):
+        t0 = time.perf_counter()
+        qt, st = O.align(p, src, sl, tgt, tl, cm, np.array([0, 0, 0, 1, 0, 0, 0.0]))
+        runs.append((time.perf_counter() - t0, st))
+    runs.sort(key=lambda r: r[0])
+    dt, st = runs[len(runs) // 2]
     return {
         "value": st["total_corr"] / dt,
         "unit": "correspondences/s",
         "cores": threads,
         "kind": "port",
-        "sample": f"1 full align() of the rank-0 pair of the batch ({len(src)}x{len(tgt)}): {st['outer_iters']} outer iterations, "
-                  f"{st['total_evals']} residual sweeps, {dt:.1f} s; kd-tree kNN + problem build on 1 thread, "
+        "sample": f"median of {len(runs)} full align() calls of the rank-0 pair of the batch ({len(src)}x{len(tgt)}): {st['outer_iters']} outer iterations, "
+                  f"{st['total_evals']} residual sweeps, {dt:.1f} s each ({', '.join(f'{r[0]:.2f}' for r in runs)} s); kd-tree kNN + problem build on 1 thread, "
                   f"residual/Jacobian sweeps on {threads} threads (host has {os.cpu_count()} cores)",
+        "runs_s": [r[0] for r in runs],
         "ms_per_icp_iter": 1e3 * (dt - st["t_cov_s"]) / max(1, st["outer_iters"]),
         "cov_ms": 1e3 * st["t_cov_s"],
         "pose": [float(v) for v in qt],
@@ -230,7 +259,7 @@ def run_batch_steps(sicp, engines, steps, warmup, sync):
     return time.perf_counter() - t0, agg, per_pair_outer, per_pair_evals, qts
 
 
-def sequence_leg(sicp, device, params, cm, n_pairs, batch, n_points, seed):
+def sequence_leg(sicp, device, params, cm, scans, batch, n_points):
     """Config-5 stand-in: `n_pairs` consecutive registrations of a scan sequence (scan p+1 onto scan p,
     the loop of exec/kitti_eval.cc:124-249), END TO END: every scan is uploaded once (sicp_set_cloud:
     H2D + search-tree build), shared as the source of one registration and the target of the next
@@ -239,7 +268,7 @@ def sequence_leg(sicp, device, params, cm, n_pairs, batch, n_points, seed):
     thread uploads the next batch's scans."""
     import numpy as np
 
-    scans = pool_map(gen_scan, [(seed, i, n_points) for i in range(n_pairs + 1)], 1)
+    n_pairs = len(scans) - 1
     p = sicp.SicpParams.from_buffer_copy(params)
     p.reuse_features = 1
     n_batches = (n_pairs + batch - 1) // batch
@@ -313,12 +342,48 @@ def sequence_leg(sicp, device, params, cm, n_pairs, batch, n_points, seed):
     }
 
 
+def full_size_leg(sicp, device, mode, pairs, C, cm, epsilon, label):
+    """A closed batch of full-size pairs (config 2 / config 3 of BASELINE.json) through one sicp_align_batch call."""
+    p = sicp.default_params(mode)
+    p.num_classes = C if mode == sicp.MODE_EM else 0
+    if epsilon is not None:
+        p.epsilon = epsilon
+    E = []
+    for src, sl, tgt, tl in pairs:
+        e = sicp.Engine(device, p)
+        if mode == sicp.MODE_EM:
+            e.set_confusion(cm)
+        lab = mode != sicp.MODE_GICP
+        e.set_source(src, sl if lab else None)
+        e.set_target(tgt, tl if lab else None)
+        E.append(e)
+    dt, a, o, ev, _ = run_batch_steps(sicp, E, 2, 1, lambda: [e.synchronize() for e in E])
+    for e in E:
+        e.close()
+    npts = sum(len(pr[0]) for pr in pairs) / len(pairs)
+    return {"workload": f"{label}: {len(pairs)} different pairs of ~{int(npts)} points through one sicp_align_batch call",
+            "value": a["total_corr"] / dt, "unit": "correspondences/s", "ms_per_step": 1e3 * dt / 2, "pairs_per_s": 2 * len(pairs) / dt,
+            "ms_per_pair": 1e3 * dt / (2 * len(pairs)), "outer_iters_per_align": a["outer_iters"] / (2 * len(pairs)),
+            "busy_fraction": a["total_evals"] / max(1, a["lockstep_slots"])}
+
+
+def load_profile_json(name):
+    path = os.path.join(PROFILE_DIR, name)
+    if os.path.exists(path):
+        try:
+            return json.load(open(path))
+        except Exception:
+            return None
+    return None
+
+
 def main():
     args = parse_args()
     fan_out_if_needed(args)
-    dist = Dist()
-    if dist.world != max(1, args.gpus):
-        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={dist.world}: launch N ranks for --gpus N")
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != max(1, args.gpus):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch N ranks for --gpus N")
     import numpy as np
 
     import synth
@@ -330,13 +395,19 @@ def main():
     cm = synth.confusion_matrix(N_CLASSES)
     ident = np.array([0, 0, 0, 1, 0, 0, 0.0])
     # weak scaling: every rank registers its own S pairs; all pairs of the job are different
-    seeds = [2 + S * dist.rank + (0 if args.same_pair else k) for k in range(S)]
-    if args.dry_run:
-        pairs = None
-    elif args.same_pair:
-        pairs = [gen_pair((seeds[0], n))] * S
-    else:
-        pairs = pool_map(gen_pair, [(sd, n) for sd in seeds], dist.world)
+    seeds = [2 + S * rank + (0 if args.same_pair else k) for k in range(S)]
+    extras = rank == 0 and world == 1 and not args.timed_only and not args.dry_run
+    # ---- every worker pool runs HERE: nothing has started a thread or touched the GPU yet -----------
+    pairs = scans = full_pairs = rgbd_pairs = None
+    if not args.dry_run:
+        pairs = [gen_pair((seeds[0], n))] * S if args.same_pair else pool_map(gen_pair, [(sd, n) for sd in seeds], world)
+        if extras and em:
+            if args.sequence_pairs > 0:
+                scans = pool_map(gen_scan, [(5, i, n) for i in range(args.sequence_pairs + 1)], 1)
+            if args.full_size_pairs > 0:
+                full_pairs = pool_map(gen_full_scan_pair, [1000 + k for k in range(args.full_size_pairs)], 1)
+                rgbd_pairs = pool_map(gen_rgbd_pair, [3 + k for k in range(args.full_size_pairs)], 1)
+    dist = Dist()   # gloo (threads) only from here on
 
     engines, sicp, device = [], None, 0
     if args.dry_run:
@@ -352,9 +423,9 @@ def main():
         ndev = sicp.device_count()
         if ndev < 1:
             raise SystemExit("bench.py: no HIP device visible (there is no CPU fallback)")
-        if dist.world > ndev:
-            raise SystemExit(f"bench.py: --gpus {dist.world} but only {ndev} HIP device(s) visible")
-        device = dist.local_rank
+        if dist.world > ndev and not args.oversubscribe:
+            raise SystemExit(f"bench.py: --gpus {dist.world} but only {ndev} HIP device(s) visible (--oversubscribe shares them)")
+        device = dist.local_rank % ndev
         p = sicp.default_params(sicp.MODE_EM if em else sicp.MODE_GICP)
         p.num_classes = N_CLASSES if em else 0
         p.profile = args.profile
@@ -393,6 +464,8 @@ def main():
     evals_all = dist.reduce(float(agg["total_evals"]), "sum")
     slots_all = dist.reduce(float(agg["lockstep_slots"]), "sum")
     outer_all = dist.reduce(float(agg["outer_iters"]), "sum")
+    seed_lo = dist.reduce(float(min(seeds)), "min")
+    seed_hi = dist.reduce(float(max(seeds)), "max")
 
     out = None
     if dist.rank == 0:
@@ -417,11 +490,19 @@ def main():
                 "workload": wl,
                 "points": n, "K": K, "classes": N_CLASSES if em else 0, "parallelism": f"pairs-sharded x{dist.world}",
                 "pairs_in_flight_per_gpu": S,
+                "seeds_min_max": [int(seed_lo), int(seed_hi)],
+                "oversubscribed": bool(args.oversubscribe),
                 "step": f"{S} full align() calls per GPU (covariances of both clouds + all outer ICP iterations each), "
                         "registered together by one sicp_align_batch call (continuous batching)",
             },
             "pairs_per_s": S * dist.world * steps / elapsed_max,
-            "ms_per_icp_iter": 1e3 * elapsed_max * dist.world * S / max(1.0, outer_all),
+            # three meanings of "ms per outer ICP iteration" (BASELINE.json's second metric), spelled out:
+            #   in_batch_wall : wall time between two outer iterations of ONE pair while it shares the GPU with the other S - 1
+            #   amortised     : GPU wall time per outer iteration completed on that GPU (all pairs) = 1 / throughput
+            #   alone         : one pair alone on the GPU, the reference's call pattern (filled in below at N = 1)
+            "ms_per_icp_iter_in_batch_wall": 1e3 * elapsed_max * dist.world * S / max(1.0, outer_all),
+            "ms_per_icp_iter_amortised": 1e3 * elapsed_max * dist.world / max(1.0, outer_all),
+            "ms_per_icp_iter_alone": None,
             "outer_iters_per_align": outer_all / (steps * S * dist.world),
             "accumulate_passes_per_outer_iter": evals_all / max(1.0, outer_all),
             "lockstep": {
@@ -436,7 +517,7 @@ def main():
         }
 
     single = others = None
-    if engines and dist.rank == 0 and not args.timed_only and dist.world == 1:
+    if engines and extras:
         engine = engines[0]
         others = []
         # --- one pair alone on the GPU: the reference's own call pattern (latency) ---------------------
@@ -452,6 +533,7 @@ def main():
         single = {"workload": f"one pair alone (sicp_align, the reference's call pattern), {'EM-ICP K=4' if em else 'SE3-GICP K=1'}, {n}x{n}",
                   "value": sc / dt1, "unit": "correspondences/s", "ms_per_align": 1e3 * dt1 / reps,
                   "ms_per_icp_iter": 1e3 * dt1 / max(1, so), "outer_iters": so / reps}
+        out["ms_per_icp_iter_alone"] = single["ms_per_icp_iter"]
         others.append(single)
         # --- the other registration class of exec/kitti_eval.cc on the same pairs ----------------------
         alt = sicp.default_params(sicp.MODE_GICP if em else sicp.MODE_EM)
@@ -471,52 +553,62 @@ def main():
                        "busy_fraction": a2["total_evals"] / max(1, a2["lockstep_slots"])})
         for e in alt_engines:
             e.close()
+        # --- the full-size configs of BASELINE.json as batches ------------------------------------------
+        if full_pairs:
+            others.append(full_size_leg(sicp, device, sicp.MODE_EM, full_pairs, N_CLASSES, cm, None,
+                                        f"config 2 at full size: EM-ICP K={K_CORR} C={N_CLASSES} on whole KITTI-like scans (not subsampled)"))
+        if rgbd_pairs:
+            others.append(full_size_leg(sicp, device, sicp.MODE_SEMANTIC, rgbd_pairs, 13, None, None,
+                                        "config 3: SemanticICP (per-class K=1 search, Cauchy 1.5; exec/nyu_eval.cc:139) on 640x480 RGB-D frame pairs, 13 classes"))
+            others.append(full_size_leg(sicp, device, sicp.MODE_EM, rgbd_pairs, 13, synth.confusion_matrix(13), 1e-6,
+                                        "config 3: EM-ICP K=4 C=13 eps=1e-6 (exec/scenenet_eval.cc:174) on the same RGB-D frame pairs"))
         # --- end-to-end sequence (cloud upload + tree build inside the timed region) ------------------
-        if args.sequence_pairs > 0 and em:
-            others.append(sequence_leg(sicp, device, engine.get_params(), cm, args.sequence_pairs, 32, n, seed=5))
+        if scans:
+            others.append(sequence_leg(sicp, device, engine.get_params(), cm, scans, 32, n))
         out["other_workloads"] = others
 
         # --- rooflines (SURVEY.md 8d per-unit bytes x units per launch / HIP-event duration) ----------
         # accumulate: the path's HBM-model kernel (24 B per source point + 32 B per correspondence and
-        # pass).  The timed region runs it as accumulate_batch_kernel, one launch per LM evaluation for
-        # all pairs that still iterate; here the launch over all S pairs is timed alone with HIP events
-        # on its stream (sicp_accumulate_batch: 50 launches back to back between two events)
-        L = min(S, 32)  # the launch shape of round 1's roofline and of the committed PMC passes: 32 pairs
-        for e, q in zip(engines[:L], qts[:L]):
+        # pass).  The timed region runs it once per LM evaluation over all pairs that still iterate (up to
+        # 256 per launch); here the launch is timed alone with HIP events on its stream
+        # (sicp_accumulate_batch: 50 launches back to back between two events) at BOTH shapes: over
+        # min(S, 256) pairs -- the launch of the timed region, the headline `roofline` -- and over 32
+        # pairs, the shape of rounds 1 and 2.
+        for e, q in zip(engines[:min(S, 256)], qts[:min(S, 256)]):
             e.correspondences(q)
-        acc_ms_l = []
-        for _ in range(8):
-            _, ms = sicp.accumulate_batch(engines[:L], np.array(qts[:L]), repeat=50)
-            acc_ms_l.append(ms)
-        acc_us = 1e3 * float(np.mean(acc_ms_l[2:]))
-        acc_bytes = L * (24 * n + 32 * K * n)
-        acc_gbs = acc_bytes / (acc_us * 1e-6) / 1e9
+        acc = {}
+        for L in sorted({min(S, 256), min(S, 32)}):
+            ms_l = []
+            for _ in range(6):
+                _, ms = sicp.accumulate_batch(engines[:L], np.array(qts[:L]), repeat=50 if L <= 32 else 10)
+                ms_l.append(ms)
+            us = 1e3 * float(np.mean(ms_l[2:]))
+            b = L * (24 * n + 32 * K * n)
+            acc[L] = {"pairs_per_launch": L, "avg_launch_us": us, "algorithmic_bytes_per_launch": b, "achieved": b / (us * 1e-6) / 1e9,
+                      "frac": b / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "launches_timed": (50 if L <= 32 else 10) * len(ms_l[2:])}
+        L = max(acc)
         traffic, traffic_src = None, None
-        if os.path.exists(TRAFFIC_FILE):
-            try:
-                t = json.load(open(TRAFFIC_FILE))
-                key = f"accumulate_batch_K{K}_pairs{L}_n{n}"
-                if key in t:
-                    traffic = t[key]["bytes_per_launch"]
-                    traffic_src = (f"profiles/r02/pmc_hbm_traffic.json:{key}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same launch "
-                                   "(tools/run_fetch_calibration.sh), FETCH_SIZE x2 as calibrated on this access pattern; from the committed profile, "
-                                   "not measured in this run")
-            except Exception:
-                pass
+        t = load_profile_json("pmc_hbm_traffic.json")
+        key = f"accumulate_batch_K{K}_pairs{L}_n{n}"
+        if t and key in t:
+            traffic = t[key]["bytes_per_launch"]
+            traffic_src = (f"{os.path.relpath(PROFILE_DIR, ROOT)}/pmc_hbm_traffic.json:{key}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same "
+                           "launch of this build (tools/pmc_accumulate.sh), FETCH_SIZE x2 as calibrated on this access pattern; from the committed "
+                           "profile, not measured in this run")
         out["roofline"] = {
             "kernel": f"accumulate_staged_kernel<K={K}> (Mahalanobis residual + 6-DoF Jacobian + robust loss -> 28 sums per pair; persistent "
-                      f"workgroups over contiguous chunk ranges, LDS-staged gathers, wave-private reductions; one launch per LM evaluation, timed here over {L} pairs of the batch)",
-            "bound": "hbm", "achieved": acc_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": acc_gbs / HBM_PEAK_GBS,
+                      f"workgroups over contiguous chunk ranges, LDS-staged gathers, wave-private reductions; one launch per LM evaluation, timed here "
+                      f"over {L} pairs: the launch shape of the timed region)",
+            "bound": "hbm", "achieved": acc[L]["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": acc[L]["frac"],
             "traffic": traffic, "traffic_source": traffic_src,
-            "avg_launch_us": acc_us, "launches_timed": 50 * len(acc_ms_l[2:]), "algorithmic_bytes_per_launch": acc_bytes,
-            "pairs_per_launch": L,
-            "note": "the memory side moves ~0.96x the algorithmic bytes (no re-reads).  Measured anatomy of the launch "
-                    "(profiles/r02/r02_accumulate_anatomy.txt, DESIGN.md section 3.1): its memory pipeline alone (no arithmetic) takes ~90 us, "
-                    "its arithmetic + reduction alone (all loads cache hits; 205 VALU instructions per correspondence, FP64) ~96 us, "
-                    "both together ~120 us: two waves per SIMD overlap the two imperfectly",
+            "avg_launch_us": acc[L]["avg_launch_us"], "launches_timed": acc[L]["launches_timed"],
+            "algorithmic_bytes_per_launch": acc[L]["algorithmic_bytes_per_launch"], "pairs_per_launch": L,
+            "other_launch_shapes": [acc[k] for k in sorted(acc) if k != L],
         }
+        # the search kernels: HIP-event durations measured here (one pair alone), counter-based figures
+        # (HBM bytes, instruction counts) from the committed PMC passes of this build
         pp = engine.get_params()
-        pp.profile = 1  # SICP_PROFILE_NN: the correspondence-search kernel alone, 20 launches at the final pose
+        pp.profile = 1 | 2  # SICP_PROFILE_NN | SICP_PROFILE_COV: the search kernels alone
         engine.set_params(pp)
         b0 = engine.stats()
         for _ in range(20):
@@ -526,13 +618,15 @@ def main():
         engine.set_params(pp)
         avg_ms = (b1["nn_kernel_ms"] - b0["nn_kernel_ms"]) / max(1, b1["nn_launches"] - b0["nn_launches"])
         alg_bytes = 12 * n + 12 * n + 8 * K * n     # src+tgt xyz once, idx+dist^2 out
-        out["other_kernels"] = [{
-            "kernel": f"bvh_knn_packet_kernel<K={K}> (exact box-tree search, 16 queries per wave share one walk), one pair alone, HIP events",
-            "bound": "hbm", "achieved": alg_bytes / (avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": alg_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms,
-            "algorithmic_bytes_per_launch": alg_bytes,
-            "note": "latency / instruction-issue bound tree walk over an L2-resident cloud, not an HBM stream",
-        }]
+        knn_pmc = load_profile_json("pmc_knn.json") or {}
+        ok = []
+        ent = {"kernel": f"bvh_knn_packet_kernel<{K}> (exact box-tree search, 16 queries per wave share one walk), one pair alone, HIP events",
+               "bound": "issue", "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg_bytes,
+               "algorithmic_GBps": alg_bytes / (avg_ms * 1e-3) / 1e9}
+        ok.append(ent)
+        for name, rec in knn_pmc.items():   # per kernel: counter HBM GB/s and the issue-bound fraction, as measured by tools/pmc_knn.sh
+            ok.append(dict(rec, kernel=name, source=f"{os.path.relpath(PROFILE_DIR, ROOT)}/pmc_knn.json (committed profile of this build)"))
+        out["other_kernels"] = ok
         if not args.no_cpu_baseline and em:
             src, sl, tgt, tl = pairs[0]
             base, oq = cpu_baseline(src, sl, tgt, tl, cm)

@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 #define SICP_VERSION_MAJOR 0
-#define SICP_VERSION_MINOR 2
+#define SICP_VERSION_MINOR 3
 #define SICP_MAX_K_COV 32  /* largest covariance neighbourhood (ctor argument k) */
 
 /* ---- status codes ------------------------------------------------------- */
@@ -175,6 +175,16 @@ int sicp_get_params(sicp_handle h, sicp_params* p);
  * (pcl_2_semantic.h:24-39); all outputs stay in the caller's point order. */
 int sicp_set_cloud(sicp_handle h, int which, int32_t n, const float* x, const float* y,
                    const float* z, const uint32_t* label);
+/* Non-finite points (NaN / Inf in any coordinate, e.g. the invalid pixels of an organized RGB-D
+ * cloud) are accepted and LEFT OUT of the device cloud, as pcl::KdTreeFLANN::setInputCloud
+ * (called by setSourceCloud / setTargetCloud, em_icp.h:50-66) leaves them out of its index: they
+ * are never found as neighbours and -- a NaN query keeps no candidate -- never matched, so they
+ * contribute no residual.  Every per-point output keeps the caller's size and order; for a
+ * dropped point: correspondences idx = -1, d2 = NaN, w = 0; normal / covariance NaN, histogram
+ * 0, neighbour list -1; fused label 0; sicp_transform_source transforms it like any other point.
+ * n_points = what the caller handed over (the size of per-point outputs), n_indexed = the finite
+ * points held on the device.  Either output may be NULL. */
+int sicp_cloud_size(sicp_handle h, int which, int32_t* n_points, int32_t* n_indexed);
 /* same, from buffers already resident on the handle's device */
 int sicp_set_cloud_device(sicp_handle h, int which, int32_t n, const float* x_device,
                           const float* y_device, const float* z_device,
@@ -185,8 +195,12 @@ int sicp_set_cloud_device(sicp_handle h, int which, int32_t n, const float* x_de
  * registration to the next): slot `which` of `h` refers to the SAME device-resident cloud
  * (points, search structure, normals, histograms) as slot `from_which` of `from`; nothing is
  * copied or rebuilt.  Both handles must be on the same device.  Handles that share a cloud may
- * run in one sicp_align_batch, or one after the other, but not concurrently from different host
- * threads. */
+ * run in one sicp_align_batch, or one after the other; two host threads must not ALIGN handles
+ * that share a cloud at the same time.  One thing is safe across threads, because a sequence
+ * driver needs it: while one thread registers handles (sicp_align / sicp_align_batch), another
+ * may upload clouds into OTHER handles and sicp_share_cloud from a handle of the running call --
+ * a shared cloud is never written by an align, a handle that gets a new cloud lets go of the
+ * shared one instead of overwriting it, and the "upload still in flight" flag is atomic. */
 int sicp_share_cloud(sicp_handle h, int which, sicp_handle from, int from_which);
 /* setConfusionMatrix (em_icp.h:68-71); cm is C*C row-major, cm[r*C+s] */
 int sicp_set_confusion(sicp_handle h, int32_t C, const double* cm_rowmajor);
@@ -238,6 +252,16 @@ int sicp_accumulate(sicp_handle h, const double qt[7], double out28[28]);
  * events on handles[0]'s stream; kernel_ms (nullable) = event time / repeat. */
 int sicp_accumulate_batch(sicp_handle* handles, int32_t n, const double* qt, double* out28,
                           int32_t repeat, double* kernel_ms);
+/* the search kernels of n handles as sicp_align_batch launches them (one job per handle and label
+ * segment, up to 8 jobs per launch), issued `repeat` times back to back between two HIP events on
+ * handles[0]'s stream; kernel_ms (nullable) = event time / repeat, for all n searches together.
+ *   what = 0: the correspondence search at poses qt (n*7): transform + K nearest targets + gate
+ *             (em_icp.hpp:46-65); use_hint = 0 starts every walk from the curve position like the first
+ *             search of an align(), 1 from the handle's previous result like the later ones
+ *   what = 1 / 2: the k_cov self-search of the source / target cloud (em_icp.hpp:283-296)
+ * The handles end up as after sicp_correspondences / sicp_covariances. */
+int sicp_search_batch(sicp_handle* handles, int32_t n, const double* qt, int32_t what, int32_t use_hint,
+                      int32_t repeat, double* kernel_ms);
 /* the inner ceres::Solve (em_icp.hpp:162-177) on the current correspondences */
 int sicp_solve(sicp_handle h, const double init_qt[7], double out_qt[7], int32_t* lm_iters,
                int32_t* evals, double* final_cost);

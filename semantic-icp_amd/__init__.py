@@ -151,10 +151,12 @@ def lib():
             "sicp_set_cloud": [C.c_void_p, C.c_int, C.c_int32, _fp, _fp, _fp, _up],
             "sicp_set_cloud_device": [C.c_void_p, C.c_int, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
             "sicp_share_cloud": [C.c_void_p, C.c_int, C.c_void_p, C.c_int],
+            "sicp_cloud_size": [C.c_void_p, C.c_int, _ip, _ip],
             "sicp_set_confusion": [C.c_void_p, C.c_int32, _dp],
             "sicp_align": [C.c_void_p, _dp, _dp, _ip, C.POINTER(SicpStats)],
             "sicp_align_batch": [C.POINTER(C.c_void_p), C.c_int32, _dp, _dp, _ip, C.POINTER(SicpStats)],
             "sicp_accumulate_batch": [C.POINTER(C.c_void_p), C.c_int32, _dp, _dp, C.c_int32, _dp],
+            "sicp_search_batch": [C.POINTER(C.c_void_p), C.c_int32, _dp, C.c_int32, C.c_int32, C.c_int32, _dp],
             "sicp_transform_source": [C.c_void_p, _dp, _fp, _fp, _fp],
             "sicp_fused_labels": [C.c_void_p, _dp, _up],
             "sicp_covariances": [C.c_void_p, C.c_int, _dp, _dp, _bp, _ip],
@@ -262,6 +264,12 @@ class Engine:
         histograms) in slot `other_which` of `other`; nothing is copied or rebuilt."""
         self._check(lib().sicp_share_cloud(self._h, which, other._h, other_which), "sicp_share_cloud")
         self.n[which] = other.n[other_which]
+
+    def cloud_size(self, which: int):
+        """(points handed over, finite points held in the device index)"""
+        a, b = C.c_int32(0), C.c_int32(0)
+        self._check(lib().sicp_cloud_size(self._h, which, C.byref(a), C.byref(b)), "sicp_cloud_size")
+        return a.value, b.value
 
     def set_cloud_device(self, which: int, n: int, x_dev: int, y_dev: int, z_dev: int, label_dev: int | None = None):
         """sicp_set_cloud_device: SoA float32 / uint32 buffers resident on the handle's device (raw addresses)."""
@@ -381,3 +389,19 @@ def accumulate_batch(engines, qts, repeat: int = 1):
     if rc != 0:
         raise RuntimeError(f"sicp_accumulate_batch failed: {_strerror(rc)} ({rc})")
     return out, ms.value
+
+
+def search_batch(engines, qts=None, what: int = 0, use_hint: bool = True, repeat: int = 1):
+    """sicp_search_batch: the search kernels of every engine as one job launch (what = 0 the K-correspondence
+    search at poses qts, 1 / 2 the k_cov self-search of the source / target cloud), issued `repeat` times.
+    Returns kernel milliseconds per repetition (all engines' searches together)."""
+    n = len(engines)
+    if qts is None:
+        qts = np.tile(np.array([0, 0, 0, 1, 0, 0, 0], dtype=np.float64), (n, 1))
+    qts = np.ascontiguousarray(qts, dtype=np.float64).reshape(n, 7)
+    ms = C.c_double(0.0)
+    rc = lib().sicp_search_batch(_handles(engines), n, _ptr(qts, _dp), what, 1 if use_hint else 0, repeat, C.byref(ms))
+    if rc != 0:
+        msgs = "; ".join(m for m in (lib().sicp_last_error(e._h).decode() for e in engines) if m)
+        raise RuntimeError(f"sicp_search_batch failed: {_strerror(rc)} ({rc}) {msgs}")
+    return ms.value

@@ -89,7 +89,13 @@ struct HostBuf {
 };
 
 struct Cloud {
-  int n = 0;
+  int n = 0;         // points on the device (the finite ones: what the search index holds)
+  int n_caller = 0;  // points the caller handed over (what every per-point output is sized by)
+  // Non-finite points are left out of the device cloud, as pcl::KdTreeFLANN::setInputCloud leaves them
+  // out of its index (em_icp.h:50-66): keep[i] = caller index of device-side input point i (empty when
+  // nothing was dropped), drop_i / drop_xyz = the dropped points themselves (for the final_cloud output).
+  std::vector<int> keep, drop_i;
+  std::vector<float> drop_xyz;
   bool is_set = false, has_label = false;
   HostBuf<float> hx, hy, hz;  // caller order (pinned: the staging buffers of the upload)
   HostBuf<uint32_t> hl;
@@ -135,19 +141,25 @@ struct Cloud {
   // the upload + tree build is left running on the uploading handle's stream: whoever uses the cloud
   // next (any handle, any stream, or the host reading `perm`) waits for this event first
   hipEvent_t ready_ev = nullptr;
-  bool pending = false;
+  // set by the uploading thread, cleared by whoever waits first (a sequence driver uploads the next
+  // batch's scans on a second host thread while the main thread registers clouds that share them)
+  std::atomic<bool> pending{false};
   ~Cloud() { if (ready_ev) (void)hipEventDestroy(ready_ev); }
   int n_seg() const { return (int)seg_label.size(); }
-  int caller_index(int d) const { return perm[d]; }
+  int caller_index(int d) const { return keep.empty() ? perm[d] : keep[perm[d]]; }
 };
 
 // Clouds (with all their device and pinned buffers) are recycled through a per-device pool: a scan
 // sequence uploads a new cloud per registration, and allocating / freeing ~25 buffers each time would
 // serialise the pipeline (hipFree synchronises the device).  The pool is never destroyed (it may
 // outlive the HIP runtime at process exit); sicp_release_pool frees what it holds.
+constexpr int kPoolDevices = 64;
+// parked clouds per device beyond which a released cloud is freed instead (two batches of 256 pairs with
+// their own source and target clouds fit; ~11 MB of HBM and ~2 MB of pinned memory per 100K-point cloud)
+constexpr size_t kPoolCap = 1024;
 struct CloudPool {
   std::mutex m;
-  std::vector<Cloud*> free_list[64];
+  std::vector<Cloud*> free_list[kPoolDevices];
 };
 CloudPool& cloud_pool() {
   static CloudPool* pool = new CloudPool;
@@ -156,19 +168,27 @@ CloudPool& cloud_pool() {
 
 std::shared_ptr<Cloud> acquire_cloud(int device) {
   CloudPool& pool = cloud_pool();
-  const int slot = device & 63;
+  const int slot = device % kPoolDevices;
   Cloud* c = nullptr;
   {
     std::lock_guard<std::mutex> lock(pool.m);
     if (!pool.free_list[slot].empty()) { c = pool.free_list[slot].back(); pool.free_list[slot].pop_back(); }
   }
   if (!c) c = new Cloud();
-  return std::shared_ptr<Cloud>(c, [slot](Cloud* dead) {
-    dead->n = 0; dead->is_set = false; dead->has_label = false; dead->layout = -1;
+  return std::shared_ptr<Cloud>(c, [slot, device](Cloud* dead) {
+    dead->n = 0; dead->n_caller = 0; dead->is_set = false; dead->has_label = false; dead->layout = -1;
+    dead->keep.clear(); dead->drop_i.clear(); dead->drop_xyz.clear();
     dead->feat_valid = false; dead->proj_valid = false; dead->feat_epoch = 0; dead->proj_cm_id = 0;
     CloudPool& pl = cloud_pool();
-    std::lock_guard<std::mutex> lock(pl.m);
-    pl.free_list[slot].push_back(dead);
+    {
+      std::lock_guard<std::mutex> lock(pl.m);
+      if (pl.free_list[slot].size() < kPoolCap) { pl.free_list[slot].push_back(dead); return; }
+    }
+    // the pool is full: free this one (hipFree synchronises the device -- only beyond the cap)
+    int cur = -1;
+    const bool switched = hipGetDevice(&cur) == hipSuccess && cur != device && hipSetDevice(device) == hipSuccess;
+    delete dead;
+    if (switched) (void)hipSetDevice(cur);
   });
 }
 
@@ -577,6 +597,9 @@ int compute_features(sicp_context* h, Cloud& c, bool with_hist, hipStream_t stre
   const int k = P.k_cov, n = c.n;
   const size_t m = (size_t)(n > 0 ? n : 1);
   HIPCHECK(c.rec.reserve(m));
+  // an empty cloud still has one (all-zero) record: the accumulate kernel evaluates dead slots on record 0
+  // and weights them by exactly zero, which needs finite values there
+  if (n == 0) HIPCHECK(hipMemsetAsync(c.rec.p, 0, sizeof(sicp::PointRec), stream));
   HIPCHECK(c.nn.reserve(m * k));
   if (with_hist) HIPCHECK(c.hist.reserve(m * P.num_classes));
   // the packet search writes the lists rank-major ([k][n]): coalesced stores there and coalesced
@@ -1089,7 +1112,9 @@ int count_active(sicp_context* h) {
 // =================================================================================================
 extern "C" {
 
-const char* sicp_version(void) { return "semantic-icp_amd 0.1 (gfx950)"; }
+#define SICP_STR2(x) #x
+#define SICP_STR(x) SICP_STR2(x)
+const char* sicp_version(void) { return "semantic-icp_amd " SICP_STR(SICP_VERSION_MAJOR) "." SICP_STR(SICP_VERSION_MINOR) " (gfx950)"; }
 
 const char* sicp_strerror(int s) {
   switch (s) {
@@ -1218,11 +1243,14 @@ int sicp_destroy(sicp_handle h) {
 }
 
 int sicp_release_pool(int device_id) {
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return SICP_ERR_NO_DEVICE;
+  if (device_id < 0 || device_id >= n_dev) return SICP_ERR_INVALID_ARGUMENT;
   CloudPool& pool = cloud_pool();
   std::vector<Cloud*> dead;
   {
     std::lock_guard<std::mutex> lock(pool.m);
-    dead.swap(pool.free_list[device_id & 63]);
+    dead.swap(pool.free_list[device_id % kPoolDevices]);
   }
   if (!dead.empty() && hipSetDevice(device_id) != hipSuccess) return SICP_ERR_NO_DEVICE;
   for (Cloud* c : dead) delete c;
@@ -1266,14 +1294,40 @@ int sicp_set_cloud(sicp_handle h, int which, int32_t n, const float* x, const fl
   }
   Cloud& c = h->cloud(which);
   SICPCHECK(cloud_wait(h, c));  // a previous upload may still be reading the staging buffers
-  c.n = n;
-  HIPCHECK(c.hx.assign(x, n)); HIPCHECK(c.hy.assign(y, n)); HIPCHECK(c.hz.assign(z, n));
+  // Non-finite points (the NaNs of an organized RGB-D cloud) never enter the device cloud:
+  // pcl::KdTreeFLANN::setInputCloud (em_icp.h:50-66) leaves them out of the search index, so the
+  // reference can neither find them as neighbours nor -- a NaN query keeps no candidate -- match them.
+  // Everything below works on the finite points; outputs are mapped back to the caller's indices.
+  c.n_caller = n;
+  c.keep.clear(); c.drop_i.clear(); c.drop_xyz.clear();
+  int n_bad = 0;
+  for (int i = 0; i < n; ++i) n_bad += !(std::isfinite(x[i]) && std::isfinite(y[i]) && std::isfinite(z[i]));
   c.has_label = label != nullptr;
-  HIPCHECK(c.hl.assign(label, label ? n : 0));
+  if (n_bad == 0) {
+    HIPCHECK(c.hx.assign(x, n)); HIPCHECK(c.hy.assign(y, n)); HIPCHECK(c.hz.assign(z, n));
+    HIPCHECK(c.hl.assign(label, label ? n : 0));
+    c.n = n;
+  } else {
+    const int m = n - n_bad;
+    HIPCHECK(c.hx.resize(m)); HIPCHECK(c.hy.resize(m)); HIPCHECK(c.hz.resize(m)); HIPCHECK(c.hl.resize(label ? m : 0));
+    c.keep.reserve(m); c.drop_i.reserve(n_bad); c.drop_xyz.reserve((size_t)3 * n_bad);
+    for (int i = 0; i < n; ++i) {
+      if (std::isfinite(x[i]) && std::isfinite(y[i]) && std::isfinite(z[i])) {
+        const size_t k = c.keep.size();
+        c.hx[k] = x[i]; c.hy[k] = y[i]; c.hz[k] = z[i];
+        if (label) c.hl[k] = label[i];
+        c.keep.push_back(i);
+      } else {
+        c.drop_i.push_back(i);
+        c.drop_xyz.push_back(x[i]); c.drop_xyz.push_back(y[i]); c.drop_xyz.push_back(z[i]);
+      }
+    }
+    c.n = m;
+  }
   c.label_min = 0xffffffffu; c.label_max = 0;
-  for (int i = 0; i < (label ? n : 0); ++i) {
-    c.label_min = std::min(c.label_min, label[i]);
-    c.label_max = std::max(c.label_max, label[i]);
+  for (size_t i = 0; i < c.hl.size(); ++i) {
+    c.label_min = std::min(c.label_min, c.hl[i]);
+    c.label_max = std::max(c.label_max, c.hl[i]);
   }
   c.is_set = true;
   c.layout = -1;
@@ -1315,6 +1369,15 @@ int sicp_share_cloud(sicp_handle h, int which, sicp_handle from, int from_which)
   h->cl[which] = from->cl[from_which];
   h->corr_valid = false;
   h->hint_ok = false;
+  return SICP_OK;
+}
+
+int sicp_cloud_size(sicp_handle h, int which, int32_t* n_points, int32_t* n_indexed) {
+  if (!h || (which != SICP_SOURCE && which != SICP_TARGET)) return SICP_ERR_INVALID_ARGUMENT;
+  const Cloud& c = h->cloud(which);
+  if (!c.is_set) return SICP_ERR_NOT_READY;
+  if (n_points) *n_points = c.n_caller;
+  if (n_indexed) *n_indexed = c.n;
   return SICP_OK;
 }
 
@@ -1625,6 +1688,57 @@ int sicp_accumulate_batch(sicp_handle* hs, int32_t n, const double* qt, double* 
   return SICP_OK;
 }
 
+int sicp_search_batch(sicp_handle* hs, int32_t n, const double* qt, int32_t what, int32_t use_hint, int32_t repeat, double* kernel_ms) {
+  if (!hs || n < 1 || what < 0 || what > 2 || (what == 0 && !qt)) return SICP_ERR_INVALID_ARGUMENT;
+  sicp_context* h = hs[0];
+  SICPCHECK(set_device(h));
+  for (int p = 0; p < n; ++p) {
+    if (!hs[p] || hs[p]->device != h->device || !same_solver(hs[p]->params, h->params) || hs[p]->params.nn_method != 1) return SICP_ERR_INVALID_ARGUMENT;
+    sicp_context* g = hs[p];
+    {
+      sicp_context* h = g;  // (HIPCHECK / SICPCHECK report into the handle they run on)
+      SICPCHECK(check_ready(h, false));
+      SICPCHECK(prepare_cloud(h, h->cloud(0)));
+      SICPCHECK(prepare_cloud(h, h->cloud(1)));
+      HIPCHECK(hipStreamSynchronize(h->stream));
+    }
+  }
+  // the handles' own stage drivers collect the jobs exactly as sicp_align_batch makes them
+  JobCollector jc;
+  {
+    BatchGuard guard(hs, n, &jc, h->stream);
+    for (int p = 0; p < n; ++p) {
+      sicp_context* g = hs[p];
+      jc.slice = 0;
+      if (what == 0) {
+        if (!use_hint) g->hint_ok = false;
+        const int rc = run_correspondences(g, qt + 7 * p, g->params.knn, false);
+        if (rc != SICP_OK) return rc;
+      } else {
+        g->epoch = next_epoch();
+        const int rc = compute_features(g, g->cloud(what == 1 ? SICP_SOURCE : SICP_TARGET), g->params.mode == SICP_MODE_EM);
+        if (rc != SICP_OK) return rc;
+      }
+    }
+  }
+  if (repeat < 1) repeat = 1;
+  const int L = jc.knn_K;
+  HIPCHECK(hipEventRecord(h->ev0, h->stream));
+  for (int r = 0; r < repeat; ++r)
+    if (!jc.knn[0].empty()) HIPCHECK(sicp::launch_bvh_knn_packet_jobs(L, jc.knn[0].data(), (int)jc.knn[0].size(), h->stream));
+  HIPCHECK(hipEventRecord(h->ev1, h->stream));
+  // whatever consumes the searches (covariances, histograms, projections) runs once, so the handles stay consistent
+  jc.knn[0].clear();
+  SICPCHECK(flush_jobs(h, jc, h->stream));
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  if (kernel_ms) {
+    float ms = 0.f;
+    HIPCHECK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    *kernel_ms = (double)ms / repeat;
+  }
+  return SICP_OK;
+}
+
 int sicp_transform_source(sicp_handle h, const double qt[7], float* ox, float* oy, float* oz) {
   if (!h || !qt || !ox || !oy || !oz) return SICP_ERR_INVALID_ARGUMENT;
   SICPCHECK(set_device(h));
@@ -1649,6 +1763,15 @@ int sicp_transform_source(sicp_handle h, const double qt[7], float* ox, float* o
   for (int d = 0; d < n; ++d) {
     const int i = S.caller_index(d);
     ox[i] = bx[d]; oy[i] = by[d]; oz[i] = bz[d];
+  }
+  // the non-finite points that never went to the device: the same float arithmetic, here
+  for (size_t k = 0; k < S.drop_i.size(); ++k) {
+    const int i = S.drop_i[k];
+    const float px = S.drop_xyz[3 * k], py = S.drop_xyz[3 * k + 1], pz = S.drop_xyz[3 * k + 2];
+    const float* m = Mf.m;
+    // (this file is compiled with -ffp-contract=off: separately rounded products and sums, like transform_float_kernel)
+    auto row = [&](int r) { return ((m[4 * r] * px + m[4 * r + 1] * py) + m[4 * r + 2] * pz) + m[4 * r + 3]; };
+    ox[i] = row(0); oy[i] = row(1); oz[i] = row(2);
   }
   return SICP_OK;
 }
@@ -1680,6 +1803,13 @@ int sicp_covariances(sicp_handle h, int which, double* cov9, double* normal3, ui
   }
   HIPCHECK(hipStreamSynchronize(h->stream));
   const double ome = 1.0 - P.epsilon;
+  for (int i : c.drop_i) {  // points outside the index have no neighbourhood (the reference's values for them are undefined)
+    const double nan = std::numeric_limits<double>::quiet_NaN();
+    if (normal3) for (int a = 0; a < 3; ++a) normal3[3 * (size_t)i + a] = nan;
+    if (cov9) for (int a = 0; a < 9; ++a) cov9[9 * (size_t)i + a] = nan;
+    if (hist) std::memset(hist + (size_t)i * P.num_classes, 0, P.num_classes);
+    if (nn_idx) for (int j = 0; j < k; ++j) nn_idx[(size_t)i * k + j] = -1;
+  }
   for (int d = 0; d < n; ++d) {
     const int i = c.caller_index(d);
     const double v[3] = {rec[d].nx, rec[d].ny, rec[d].nz};
@@ -1720,6 +1850,13 @@ int sicp_correspondences(sicp_handle h, const double qt[7], int32_t* idx, float*
     if (h->corr_weighted) HIPCHECK(hipMemcpyAsync(hw.data(), h->w.p, sizeof(double) * slots, hipMemcpyDeviceToHost, h->stream));
   }
   HIPCHECK(hipStreamSynchronize(h->stream));
+  for (int i : S.drop_i)  // a non-finite source point has no correspondences
+    for (int c = 0; c < K; ++c) {
+      const size_t o = (size_t)i * K + c;
+      if (idx) idx[o] = -1;
+      if (d2) d2[o] = std::numeric_limits<float>::quiet_NaN();
+      if (w) w[o] = 0.0;
+    }
   for (int d = 0; d < n; ++d) {
     const int i = S.caller_index(d);
     for (int c = 0; c < K; ++c) {
@@ -1785,6 +1922,7 @@ int sicp_fused_labels(sicp_handle h, const double qt[7], uint32_t* out_labels) {
   std::vector<uint32_t> tmp(S.n);
   if (S.n > 0) HIPCHECK(hipMemcpyAsync(tmp.data(), h->tmpl.p, sizeof(uint32_t) * S.n, hipMemcpyDeviceToHost, h->stream));
   HIPCHECK(hipStreamSynchronize(h->stream));
+  for (int i : S.drop_i) out_labels[i] = 0;  // no correspondences, no fused label (labels are 1-based: em_icp.hpp:265)
   for (int d = 0; d < S.n; ++d) out_labels[S.caller_index(d)] = tmp[d];
   return SICP_OK;
 }

@@ -86,13 +86,13 @@ int main(int argc, char** argv) {
         pcl::PointCloud<pcl::PointXYZ>::Ptr cloudAnoL(new pcl::PointCloud<pcl::PointXYZ>), cloudBnoL(new pcl::PointCloud<pcl::PointXYZ>);
         pcl::io::loadPCDFile<pcl::PointXYZ>(pcd_fns[indxSource], *cloudAnoL);
         go[b] = gi[b].get();
-        go[b]->setSourceCloud(cloudAnoL);
         if (shared) {
-          go[b]->setTargetCloudSharedWithSourceOf(*gi[prev_slot]);
+          go[b]->setTargetCloudSharedWithSourceOf(*gi[prev_slot]);  // before this slot's own source is replaced (prev_slot may be b)
         } else {
           pcl::io::loadPCDFile<pcl::PointXYZ>(pcd_fns[indxTarget], *cloudBnoL);
           go[b]->setTargetCloud(cloudBnoL);
         }
+        go[b]->setSourceCloud(cloudAnoL);
         finalGi[b].reset(new pcl::PointCloud<pcl::PointXYZ>);
         prev_slot = b;
       }

@@ -31,14 +31,19 @@ class GICP {
   // of a *different* scan there -- SURVEY.md quirk Q7 -- which this engine therefore ignores.)
   // The covariance vectors align() fills (impl/gicp.hpp:33-34) are fetched from the GPU on the
   // first getSourceCovariances() / getTargetCovariances() call after an align(), not inside it.
+  // Every setter also forgets the "covariances of the last align() are still on the GPU" state: until
+  // the next align() the getters hand back exactly what the reference would (a fresh empty vector, or
+  // the caller's own), never the previous cloud's values.
   inline void setSourceCloud(const PointCloudPtr& cloud) {
     sourceCloud_ = cloud;
     sourceKdTree_ = KdTreePtr(new KdTree());
     sourceKdTree_->setInputCloud(sourceCloud_);
     sourceCovariances_ = MatricesVectorPtr(new MatricesVector());
+    source_cov_stale_ = false;
   }
   inline void setSourceCloud(const PointCloudPtr& cloud, const KdTreePtr& tree, const MatricesVectorPtr& covs) {
     sourceCloud_ = cloud; sourceKdTree_ = tree; sourceCovariances_ = covs;
+    source_cov_stale_ = false;
   }
   inline void setTargetCloud(const PointCloudPtr& cloud) {
     shared_target_from_ = nullptr;
@@ -46,18 +51,24 @@ class GICP {
     targetKdTree_ = KdTreePtr(new KdTree());
     targetKdTree_->setInputCloud(targetCloud_);
     targetCovariances_ = MatricesVectorPtr(new MatricesVector());
+    target_cov_stale_ = false;
   }
   inline void setTargetCloud(const PointCloudPtr& cloud, const KdTreePtr& tree, const MatricesVectorPtr& covs) {
     shared_target_from_ = nullptr;
     targetCloud_ = cloud; targetKdTree_ = tree; targetCovariances_ = covs;
+    target_cov_stale_ = false;
   }
   // Engine extensions for scan sequences: the target of this registration is the source cloud of
   // `other` as it lives on the GPU after other's align() (one upload, tree and covariance set per scan;
   // what the 3-argument overloads above exist for), and keepFeatures(true) keeps the covariances of a
   // cloud across align() calls instead of recomputing them (impl/gicp.hpp:33-34; same values).
+  // Call it BEFORE other.setSourceCloud(next scan) when `other` is this very object's slot of the
+  // previous batch: the host-side target pointer is taken from other's current source here.
   inline void setTargetCloudSharedWithSourceOf(GICP& other) {
     targetCloud_ = other.sourceCloud_;
     shared_target_from_ = &other;
+    targetCovariances_ = MatricesVectorPtr(new MatricesVector());
+    target_cov_stale_ = false;
   }
   inline void keepFeatures(bool on) { reuse_features_ = on; }
   inline KdTreePtr getSourceKdTree() { return sourceKdTree_; }
@@ -150,7 +161,10 @@ class GICP {
     if (!stale) return;
     stale = false;
     sicp_handle h = engine_.get();
-    const int n = (int)(which == SICP_SOURCE ? sourceCloud_ : targetCloud_)->size();
+    // sized by the cloud that IS on the device (what sicp_covariances writes), not by a host pointer
+    // that may have been replaced since the align()
+    int32_t n = 0;
+    detail::check(sicp_cloud_size(h, which, &n, nullptr), h, "sicp_cloud_size");
     if (!out) out = MatricesVectorPtr(new MatricesVector());
     out->resize(n);
     if (n == 0) return;

@@ -76,14 +76,29 @@ def robustified(T, mode, a, src, sn, tgt, tn, pairs, w, eps):
     return sq * r, sq[:, None] * J, 0.5 * float(rho.sum())
 
 
+def qr_step(stacked, rhs):
+    """The DENSE_QR route spelled out: Householder QR of the stacked system, then back substitution.  A zero
+    pivot (an exactly rank-deficient system) is a failed linear solve -- Ceres' LevenbergMarquardtStrategy
+    reports LINEAR_SOLVER_FAILURE when the step is not finite, and the minimizer counts an invalid step."""
+    Q, R = np.linalg.qr(stacked)
+    y = Q.T @ rhs
+    d = np.zeros(R.shape[0])
+    for i in range(R.shape[0] - 1, -1, -1):
+        if R[i, i] == 0.0:
+            return None
+        d[i] = (y[i] - R[i, i + 1:] @ d[i + 1:]) / R[i, i]
+    return d
+
+
 def solve(mode, a, src, sn, tgt, tn, pairs, w, eps, init_qt, max_iterations=400, gradient_tolerance=1e-11,
-          function_tolerance=1e-11):
-    """Returns (qt, trace) with trace = list of (cost, radius, candidate cost, accepted) per step attempt."""
+          function_tolerance=1e-11, initial_radius=INITIAL_RADIUS, min_lm_diagonal=MIN_LM_DIAGONAL, linear_solver="lstsq"):
+    """Returns (qt, trace) with trace = list of (cost, radius, candidate cost, accepted) per step attempt
+    (accepted: 1 = accepted, 0 = rejected or the attempt at which a tolerance ended the solve, -1 = invalid)."""
     T = qt_to_mat(init_qt)
     f, J, cost = robustified(T, mode, a, src, sn, tgt, tn, pairs, w, eps)
     # Jacobi scaling (jacobi_scaling = true): columns scaled by 1 / (1 + ||J_col||), computed once
     col_scale = 1.0 / (1.0 + np.sqrt((J * J).sum(axis=0)))
-    mu, nu = INITIAL_RADIUS, 2.0
+    mu, nu = initial_radius, 2.0
     x = mat_to_qt(T)
     x_norm = np.linalg.norm(x)
     trace = []
@@ -99,14 +114,19 @@ def solve(mode, a, src, sn, tgt, tn, pairs, w, eps, init_qt, max_iterations=400,
         it += 1
         Js = J * col_scale[None, :]
         if diag is None:
-            diag = np.clip((Js * Js).sum(axis=0), MIN_LM_DIAGONAL, MAX_LM_DIAGONAL)
+            diag = np.clip((Js * Js).sum(axis=0), min_lm_diagonal, MAX_LM_DIAGONAL)
         # LM step: min || Js d + f ||^2 + || sqrt(diag / mu) d ||^2 as ONE stacked least-squares problem
         stacked = np.vstack([Js, np.diag(np.sqrt(diag / mu))])
         rhs = np.concatenate([-f, np.zeros(6)])
-        d, *_ = np.linalg.lstsq(stacked, rhs, rcond=None)
-        model = Js @ d
-        model_cost_change = -float(model @ (f + 0.5 * model))
-        if not (model_cost_change > 0.0) or not np.isfinite(d).all():
+        if linear_solver == "qr":
+            d = qr_step(stacked, rhs)
+        else:
+            d, *_ = np.linalg.lstsq(stacked, rhs, rcond=None)
+        model_cost_change = 0.0
+        if d is not None:
+            model = Js @ d
+            model_cost_change = -float(model @ (f + 0.5 * model))
+        if d is None or not (model_cost_change > 0.0) or not np.isfinite(d).all():
             trace.append((cost, mu, cost, -1))
             invalid += 1
             if invalid >= MAX_INVALID:

@@ -1,0 +1,221 @@
+"""GPU tests (-m gpu) of inputs at the edge of what the reference accepts: non-finite points (the NaNs of
+an organized RGB-D cloud -- pcl::KdTreeFLANN::setInputCloud leaves them out of its index,
+em_icp.h:50-66 / SURVEY appendix A.3), an all-coincident cloud, a one-point cloud, an empty source.
+The checker is the oracle run on the cloud WITHOUT the non-finite points, with indices mapped back."""
+import importlib
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import synth
+from np_ref import mat_to_qt
+from test_gpu_surface import IDENT, make_engine, oracle_params, pose_delta
+
+pytestmark = pytest.mark.gpu
+
+sicp = importlib.import_module("semantic-icp_amd")
+
+
+def poison(xyz, rng, frac=0.03):
+    """every kind of non-finite point: NaN in one coordinate, NaN in all, +inf, -inf"""
+    xyz = xyz.copy()
+    bad = np.sort(rng.choice(len(xyz), max(4, int(frac * len(xyz))), replace=False))
+    kinds = rng.integers(0, 4, len(bad))
+    for i, k in zip(bad, kinds):
+        if k == 0:
+            xyz[i, rng.integers(0, 3)] = np.nan
+        elif k == 1:
+            xyz[i] = np.nan
+        elif k == 2:
+            xyz[i, rng.integers(0, 3)] = np.inf
+        else:
+            xyz[i, rng.integers(0, 3)] = -np.inf
+    keep = np.isfinite(xyz).all(axis=1)
+    assert (~keep).sum() == len(bad)
+    return xyz, keep
+
+
+@pytest.mark.parametrize("mode", [sicp.MODE_EM, sicp.MODE_GICP])
+@pytest.mark.parametrize("where", ["source", "target", "both"])
+def test_non_finite_points_are_left_out_of_the_index_like_pcl(mode, where):
+    src, sl, tgt, tl, T_gt, cm = synth.lidar_pair(seed=11, n_points=6000)
+    rng = np.random.default_rng(5)
+    ks = np.ones(len(src), bool)
+    kt = np.ones(len(tgt), bool)
+    if where in ("source", "both"):
+        src, ks = poison(src, rng)
+    if where in ("target", "both"):
+        tgt, kt = poison(tgt, rng)
+    em = mode == sicp.MODE_EM
+    C = 11 if em else 0
+    K = 4 if em else 1
+    with make_engine(mode, C, cm if em else None) as e:
+        e.set_source(src, sl if em else None)
+        e.set_target(tgt, tl if em else None)
+        assert e.cloud_size(sicp.SOURCE) == (len(src), int(ks.sum()))
+        assert e.cloud_size(sicp.TARGET) == (len(tgt), int(kt.sum()))
+        idx, d2, w = e.correspondences(IDENT)
+        cov, nrm, hist, nn = e.covariances(sicp.TARGET, want_hist=em, want_nn=True)
+        qt, st = e.align(IDENT)
+        moved = e.transform_source(qt)
+        fused = e.fused_labels(qt) if em else None
+    # ---- the checker sees only the finite points; map its indices back to the caller's
+    ms, mt = np.nonzero(ks)[0], np.nonzero(kt)[0]
+    oi, od = O.knn(O.transform_points(np.eye(4), src[ks]), tgt[kt], K, kdtree=True)
+    live = od < np.float32(250)
+    want = np.where(live, mt[oi], -1)
+    assert np.array_equal(idx[ks], want)
+    assert np.array_equal(d2[ks], od)
+    assert (idx[~ks] == -1).all() and np.isnan(d2[~ks]).all() and (w[~ks] == 0).all()
+    # neighbourhoods of the target: lists over the finite points, nothing for the dropped ones
+    noi, _ = O.knn(tgt[kt], tgt[kt], 20, kdtree=True)
+    assert np.array_equal(nn[kt], mt[noi])
+    assert (nn[~kt] == -1).all() and np.isnan(nrm[~kt]).all() and np.isnan(cov[~kt]).all()
+    if em:
+        assert (hist[~kt] == 0).all() and (hist[kt].sum(axis=1) == 20).all()
+    # the registration is the registration of the finite points
+    op = oracle_params(O.MODE_EM if em else O.MODE_GICP, C)
+    oq, ost = O.align(op, src[ks], sl[ks] if em else None, tgt[kt], tl[kt] if em else None, cm if em else None, IDENT)
+    rot, tr = pose_delta(oq, qt)
+    assert rot < 1e-7 and tr < 1e-7, (rot, tr)
+    assert st["outer_iters"] == ost["outer_iters"] and st["total_corr"] == ost["total_corr"] and st["total_active"] == ost["total_active"]
+    # final cloud: every caller point transformed (a non-finite one stays non-finite)
+    M = O.se3_matrix(qt).astype(np.float32)
+    assert moved.shape == src.shape
+    with np.errstate(invalid="ignore"):
+        ref = ((M[:3, 0] * src[:, 0:1] + M[:3, 1] * src[:, 1:2]) + M[:3, 2] * src[:, 2:3]) + M[:3, 3]
+    assert np.array_equal(moved[ks], ref[ks])
+    assert not np.isfinite(moved[~ks]).all(axis=1).any()
+    if em:
+        of = O.fused_labels(op, src[ks], sl[ks], tgt[kt], tl[kt], cm, qt)
+        assert np.array_equal(fused[ks], of) and (fused[~ks] == 0).all()
+
+
+def test_all_points_non_finite_is_an_empty_cloud():
+    src, sl, tgt, tl, T_gt, cm = synth.lidar_pair(seed=11, n_points=3000)
+    bad = np.full_like(tgt, np.nan)
+    with make_engine(sicp.MODE_GICP) as e:
+        e.set_source(src)
+        e.set_target(bad)
+        assert e.cloud_size(sicp.TARGET) == (len(bad), 0)
+        with pytest.raises(sicp.SicpError) as err:
+            e.align(IDENT)
+        assert err.value.status == sicp.ERR_TOO_FEW_POINTS
+
+
+@pytest.mark.parametrize("mode", [sicp.MODE_EM, sicp.MODE_GICP])
+def test_empty_source_is_solved_trivially(mode):
+    """no residual blocks: Ceres returns the start pose, mse = 0, one outer iteration (em_icp.hpp:179-187)"""
+    src, sl, tgt, tl, T_gt, cm = synth.lidar_pair(seed=11, n_points=3000)
+    em = mode == sicp.MODE_EM
+    start = np.array([0.02, -0.01, 0.03, 0.0, 0.4, -0.2, 0.1])
+    start[3] = np.sqrt(1 - (start[:3] ** 2).sum())
+    for empty in (np.zeros((0, 3), np.float32), np.full((7, 3), np.nan, np.float32)):
+        lab = np.ones(len(empty), np.uint32)
+        with make_engine(mode, 11 if em else 0, cm if em else None) as e:
+            e.set_source(empty, lab if em else None)
+            e.set_target(tgt, tl if em else None)
+            qt, st = e.align(start)
+            assert np.array_equal(qt, start) and st["outer_iters"] == 1 and st["total_corr"] == 0 and np.isfinite(st["final_cost"])
+            assert e.transform_source(qt).shape == empty.shape
+            # and the handle is still good for a real cloud afterwards
+            e.set_source(src, sl if em else None)
+            q2, s2 = e.align(IDENT)
+        op = oracle_params(O.MODE_EM if em else O.MODE_GICP, 11 if em else 0)
+        oq, ost = O.align(op, src, sl if em else None, tgt, tl if em else None, cm if em else None, IDENT)
+        rot, tr = pose_delta(oq, q2)
+        assert rot < 1e-7 and tr < 1e-7 and s2["outer_iters"] == ost["outer_iters"]
+
+
+def test_all_coincident_cloud():
+    """every point of the target at one position: all distances tie (lowest index wins), the covariance is the
+    zero matrix (normal = the last column of U = e_z, like JacobiSVD of 0), the extent of the index is zero"""
+    src, sl, tgt, tl, T_gt, cm = synth.lidar_pair(seed=12, n_points=2000)
+    same = np.tile(np.array([[1.5, -2.25, 0.75]], np.float32), (600, 1))
+    with make_engine(sicp.MODE_GICP) as e:
+        e.set_source(src[:500])
+        e.set_target(same)
+        idx, d2, w = e.correspondences(IDENT)
+        cov, nrm, _, nn = e.covariances(sicp.TARGET, want_nn=True)
+        qt, st = e.align(IDENT)
+    oi, od = O.knn(src[:500], same, 1, kdtree=False)
+    assert np.array_equal(d2, od) and (idx[od < np.float32(250)] == 0).all()
+    assert np.array_equal(nn, np.tile(np.arange(20, dtype=np.int32), (600, 1)))   # 20 ties: the lowest indices, ascending
+    ocov, onrm, _ = O.covariances(same, None, 20, 1e-3, 0)
+    assert np.allclose(np.abs(nrm), np.abs(onrm), atol=1e-12) and np.allclose(cov, ocov, atol=1e-12)
+    op = oracle_params(O.MODE_GICP)
+    oq, ost = O.align(op, src[:500], None, same, None, None, IDENT)
+    rot, tr = pose_delta(oq, qt)
+    assert np.isfinite(qt).all() and st["outer_iters"] == ost["outer_iters"] and rot < 1e-6 and tr < 1e-6, (rot, tr)
+
+
+def test_one_point_clouds():
+    """K = 1 needs one target point; the k = 20 neighbourhood of a lone point is the point itself, divided by k
+    (quirk Q3, em_icp.hpp:317-320).  EM-ICP (K = 4) refuses a one-point target instead of reading past the result."""
+    src, sl, tgt, tl, T_gt, cm = synth.lidar_pair(seed=12, n_points=2000)
+    one = tgt[:1]
+    with make_engine(sicp.MODE_GICP) as e:
+        e.set_source(src[:300])
+        e.set_target(one)
+        idx, d2, w = e.correspondences(IDENT)
+        cov, nrm, _, nn = e.covariances(sicp.TARGET, want_nn=True)
+        qt, st = e.align(IDENT)
+        # one-point SOURCE onto a real target
+        e.set_source(src[:1])
+        e.set_target(tgt)
+        q1, s1 = e.align(IDENT)
+    oi, od = O.knn(src[:300], one, 1, kdtree=False)
+    assert np.array_equal(d2, od) and np.array_equal(idx, np.where(od < np.float32(250), 0, -1))
+    assert nn[0, 0] == 0 and (nn[0, 1:] == -1).all()
+    ocov, onrm, _ = O.covariances(one, None, 20, 1e-3, 0)
+    assert np.allclose(cov, ocov, atol=1e-12)
+    op = oracle_params(O.MODE_GICP)
+    oq, ost = O.align(op, src[:300], None, one, None, None, IDENT)
+    rot, tr = pose_delta(oq, qt)
+    assert st["outer_iters"] == ost["outer_iters"] and rot < 1e-6 and tr < 1e-6, (rot, tr)
+    oq1, ost1 = O.align(op, src[:1], None, tgt, None, None, IDENT)
+    rot, tr = pose_delta(oq1, q1)
+    assert s1["outer_iters"] == ost1["outer_iters"] and rot < 1e-6 and tr < 1e-6, (rot, tr)
+    with make_engine(sicp.MODE_EM, 11, cm) as e:
+        e.set_source(src[:300], sl[:300])
+        e.set_target(one, tl[:1])
+        with pytest.raises(sicp.SicpError) as err:
+            e.align(IDENT)
+        assert err.value.status == sicp.ERR_TOO_FEW_POINTS
+
+
+def test_version_string_and_pool_arguments():
+    assert sicp.version().startswith("semantic-icp_amd 0.3")
+    assert sicp.lib().sicp_release_pool(-1) == sicp.ERR_INVALID_ARGUMENT
+    assert sicp.lib().sicp_release_pool(10_000) == sicp.ERR_INVALID_ARGUMENT
+    assert sicp.lib().sicp_release_pool(0) == sicp.OK
+
+
+@pytest.mark.parametrize("mode", [sicp.MODE_GICP, sicp.MODE_EM])
+def test_inner_solve_through_runs_of_rejected_steps(mode):
+    """The product's trust-region machine (csrc/lm.hpp, device-resident) on a solve that REJECTS steps: the
+    correspondences of a start pose 50 degrees and 6 m off are mostly wrong matches, and Gauss-Newton steps
+    from there overshoot -- runs of rejections (radius / nu, nu doubling), then recovery.  The oracle's loop,
+    whose rejected / invalid branches tests/test_oracle.py compares with an independent loop, must take the
+    same number of iterations and evaluations and end at the same pose."""
+    src, sl, tgt, tl, T_gt, cm = synth.lidar_pair(seed=2, n_points=20000)
+    em = mode == sicp.MODE_EM
+    far = mat_to_qt(synth.pose_matrix(50.0, (0.2, 0.1, 1.0), (5.0, -3.0, 1.0)))
+    for lm_on_device in (1, 0):
+        with make_engine(mode, 11 if em else 0, cm if em else None, lm_on_device=lm_on_device) as e:
+            e.set_source(src, sl if em else None)
+            e.set_target(tgt, tl if em else None)
+            idx, d2, w = e.correspondences(far)
+            qt, info = e.solve(far)
+            cov_s, _, _, _ = e.covariances(sicp.SOURCE)
+            cov_t, _, _, _ = e.covariances(sicp.TARGET)
+        op = oracle_params(O.MODE_EM if em else O.MODE_GICP, 11 if em else 0)
+        oq, tr = O.solve_trace(op, src, cov_s, tgt, cov_t, idx, w, far)
+        acc = tr["accepted"]
+        assert (acc[:-1] == 0).sum() >= 5 and (np.diff(np.nonzero(acc[:-1] == 0)[0]) == 1).any(), acc
+        _, oinfo = O.solve(op, src, cov_s, tgt, cov_t, idx, w, far)
+        assert info["lm_iters"] == oinfo["lm_iters"] and info["evals"] == oinfo["evals"], (info, oinfo)
+        assert np.isclose(info["cost"], oinfo["cost"], rtol=1e-10)
+        rot, trn = pose_delta(oq, qt)
+        assert rot < 1e-7 and trn < 1e-7, (rot, trn)

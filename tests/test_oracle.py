@@ -8,6 +8,7 @@ import pytest
 from scipy.spatial.transform import Rotation
 
 import oracle_lib as O
+import synth
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -219,3 +220,121 @@ def test_lm_step_control_against_an_independent_loop(mode):
     assert np.allclose(ref[:6, 1], tr["radius"][:6], rtol=1e-9, atol=0)
     D = np.linalg.inv(O.se3_matrix(oq)) @ O.se3_matrix(rq)
     assert np.linalg.norm(Rotation.from_matrix(D[:3, :3]).as_rotvec()) < 1e-9 and np.linalg.norm(D[:3, 3]) < 1e-9
+
+
+def _solve_inputs(src, sl, tgt, tl, cm, mode, K, p):
+    C = cm.shape[0]
+    scov, sn, sh = O.covariances(src, sl if mode == "em" else None, 20, p.epsilon, C)
+    tcov, tn, th = O.covariances(tgt, tl if mode == "em" else None, 20, p.epsilon, C)
+    idx, d2 = O.knn(src, tgt, K)
+    idx[~(d2 < np.float32(p.gate_sq))] = -1
+    return scov, sn, sh, tcov, tn, th, idx
+
+
+def _compare_traces(tr, rtr, oq, rq, pose_tol=1e-8, radius_tail_rtol=2e-4):
+    ref = np.array(rtr)
+    assert len(rtr) == len(tr["cost"])
+    assert np.array_equal(ref[:, 3].astype(int), tr["accepted"])           # same accept / reject / invalid sequence
+    assert np.allclose(ref[:, 0], tr["cost"], rtol=1e-9, atol=0)
+    assert np.allclose(ref[:, 2], tr["cand_cost"], rtol=1e-9, atol=0)
+    # (near convergence the step quality is a ratio of differences of nearly equal costs: the radii of two
+    # float64 implementations drift apart there)
+    assert np.allclose(ref[:6, 1], tr["radius"][:6], rtol=1e-9, atol=0)
+    assert np.allclose(ref[:, 1], tr["radius"], rtol=radius_tail_rtol, atol=0)
+    D = np.linalg.inv(O.se3_matrix(oq)) @ O.se3_matrix(rq)
+    assert np.linalg.norm(Rotation.from_matrix(D[:3, :3]).as_rotvec()) < pose_tol and np.linalg.norm(D[:3, 3]) < pose_tol
+
+
+@pytest.mark.parametrize("data", ["golden", "lidar20k"])
+@pytest.mark.parametrize("mode", ["gicp", "em", "semantic"])
+def test_lm_rejected_steps_against_the_independent_loop(mode, data):
+    """The REJECTED-step branch of the trust-region loop (radius /= nu, nu *= 2, the LM diagonal kept; then the
+    recovery after an accepted step: nu = 2, new diagonal) compared step attempt by step attempt with
+    tests/lm_ref.py.  Clean correspondences from a good start never reject a Gauss-Newton step, so the inner
+    solve is started far from the optimum on a correspondence set full of wrong matches (what the first outer
+    iteration of a badly initialised ICP hands to Ceres): runs of consecutive rejections, then progress again.
+    Two data sets: the golden pair and the 20K-point LiDAR pair."""
+    import lm_ref
+    from np_ref import mat_to_qt
+
+    if data == "golden":
+        g = load("align.npz")
+        src, sl, tgt, tl, cm = g["src"], g["sl"], g["tgt"], g["tl"], g["cm"]
+        frac, start, seed = 0.9, synth.pose_matrix(60.0, (1, 2, 3), (3.0, -2.0, 1.0)), 0
+    else:
+        src, sl, tgt, tl, T_gt, cm = synth.lidar_pair(seed=2, n_points=20000)
+        frac, start, seed = 0.3, synth.pose_matrix(25.0, (1, 2, 3), (2.0, -1.0, 0.5)), 1
+    omode = {"gicp": O.MODE_GICP, "em": O.MODE_EM, "semantic": O.MODE_SEMANTIC}[mode]
+    p = O.default_params(omode)
+    p.num_classes = cm.shape[0]
+    # On the LiDAR pair this landscape keeps the solver zig-zagging for 100+ attempts, whose accept / reject
+    # decisions near the end hang on the last digits of nearly equal costs; the first 40 attempts hold a run
+    # of eight rejections and the recovery after it, and both loops then stop at the iteration cap.
+    cap = 400 if data == "golden" else 40
+    p.max_lm_iterations = cap
+    K = 4 if mode == "em" else 1
+    scov, sn, sh, tcov, tn, th, idx = _solve_inputs(src, sl, tgt, tl, cm, mode, K, p)
+    rng = np.random.default_rng(seed)
+    wrong = rng.random(idx.shape) < frac
+    idx[wrong] = rng.integers(0, len(tgt), int(wrong.sum()))
+    w = np.where(idx >= 0, rng.uniform(0.2, 1.0, idx.shape) if mode == "em" else 1.0, 0.0)
+    init = mat_to_qt(start)
+    oq, tr = O.solve_trace(p, src, scov, tgt, tcov, idx, w, init)
+    acc = tr["accepted"]
+    rejected = np.nonzero(acc[:-1] == 0)[0]           # (the last attempt may be the one a tolerance stopped)
+    assert len(rejected) >= 2 and (np.diff(rejected) == 1).any(), acc   # at least one RUN of rejections (nu doubles)
+    assert (acc[rejected[0]:] == 1).any()                               # and accepted steps after it
+    live = idx >= 0
+    pairs = np.stack([np.nonzero(live)[0], idx[live]], axis=1)
+    rq, rtr = lm_ref.solve(mode, p.cauchy_a, src.astype(np.float64), sn, tgt.astype(np.float64), tn, pairs, w[live], p.epsilon, init,
+                           gradient_tolerance=p.gradient_tolerance, function_tolerance=p.function_tolerance, max_iterations=cap)
+    _compare_traces(tr, rtr, oq, rq)
+
+
+@pytest.mark.parametrize("mode", ["gicp", "semantic"])
+def test_lm_invalid_steps_against_the_independent_loop(mode):
+    """The INVALID-step branch (the linear solve fails: radius halved, the attempt repeated without a new
+    evaluation, termination after max_consecutive_invalid_steps).  A registration problem that lives in the
+    plane z = 0 -- points, normals and start pose -- has three Jacobian columns that are exactly zero
+    (z translation, x and y rotation); with min_lm_diagonal = 0 nothing regularises them, Cholesky meets a
+    zero pivot and the QR route a zero diagonal of R: every attempt is invalid, five in a row end the solve.
+    With the default min_lm_diagonal the same problem is solved; both against tests/lm_ref.py."""
+    import lm_ref
+    from np_ref import mat_to_qt
+
+    rng = np.random.default_rng(3)
+    n = 400
+    ang = rng.uniform(0, 2 * np.pi, n)
+    rad = 5.0 + 0.5 * np.sin(3 * ang)
+    tgt = np.stack([rad * np.cos(ang), rad * np.sin(ang), np.zeros(n)], 1).astype(np.float32)
+    tn = np.stack([np.cos(ang + 0.1), np.sin(ang + 0.1), np.zeros(n)], 1)
+    T = synth.pose_matrix(4.0, (0, 0, 1), (0.15, -0.1, 0.0))                  # a motion inside the plane
+    src = (tgt.astype(np.float64) - T[:3, 3]) @ T[:3, :3]
+    src[:, :2] += rng.normal(0, 0.02, (n, 2))                                  # in-plane noise: the minimum is not at cost 0
+    src = src.astype(np.float32)
+    src[:, 2] = 0.0
+    sn = tn @ T[:3, :3]
+    sn[:, 2] = 0.0
+    sn /= np.linalg.norm(sn, axis=1, keepdims=True)
+    omode = {"gicp": O.MODE_GICP, "semantic": O.MODE_SEMANTIC}[mode]
+    p = O.default_params(omode)
+    eye = np.eye(3)[None]
+    scov = eye - (1 - p.epsilon) * sn[:, :, None] * sn[:, None, :]
+    tcov = eye - (1 - p.epsilon) * tn[:, :, None] * tn[:, None, :]
+    idx = np.arange(n, dtype=np.int32)[:, None]
+    w = np.ones((n, 1))
+    pairs = np.stack([np.arange(n), np.arange(n)], 1)
+    init = mat_to_qt(synth.pose_matrix(1.0, (0, 0, 1), (0.05, 0.02, 0.0)))
+    for min_diag, solver in ((0.0, "qr"), (1e-6, "qr")):
+        p.min_lm_diagonal = min_diag
+        oq, tr = O.solve_trace(p, src, scov, tgt, tcov, idx, w, init)
+        rq, rtr = lm_ref.solve(mode, p.cauchy_a, src.astype(np.float64), sn, tgt.astype(np.float64), tn, pairs, w[:, 0], p.epsilon, init,
+                               gradient_tolerance=p.gradient_tolerance, function_tolerance=p.function_tolerance,
+                               min_lm_diagonal=min_diag, linear_solver=solver)
+        if min_diag == 0.0:
+            assert list(tr["accepted"]) == [-1] * 5 and tr["status"] == 2       # LM_INVALID_STEPS
+            assert np.allclose(tr["radius"], 1e4 * 0.5 ** np.arange(5), rtol=0, atol=0)
+            assert np.array_equal(oq, init)
+        else:
+            assert (tr["accepted"] == 1).sum() >= 3 and tr["status"] == 0
+        _compare_traces(tr, rtr, oq, rq, radius_tail_rtol=1e-2)
