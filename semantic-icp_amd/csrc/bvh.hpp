@@ -22,7 +22,7 @@ namespace sicp {
 
 constexpr int kLeaf = 16;        // points per leaf
 constexpr int kFan = 4;          // children per node
-constexpr int kMaxLevels = 14;   // 16 * 4^13 points
+constexpr int kMaxLevels = 12;   // 16 * 4^11 = 67 M points per cloud segment
 
 struct TreeLevels {
   int n_levels;            // >= 1

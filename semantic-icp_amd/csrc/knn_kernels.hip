@@ -645,12 +645,36 @@ __device__ __forceinline__ unsigned child_mask_packet(const float4* __restrict__
   return (unsigned)b & 15u;
 }
 
+// The leaf a search starts at: the last leaf whose first curve index is <= qc (leaf 0 when there is none).
+// 16-ary search of the sorted first indices of the 4^top leaves of the complete tree (the padding leaves
+// carry the largest index): lanes 1..15 probe one separator each, a ballot counts the ones at or below qc --
+// two tree levels per dependent load instead of the one bit of a binary search (13 loads at 100K points).
+__device__ __forceinline__ int locate_leaf(const u64* __restrict__ codes, int top, u64 qc, int lane) {
+  int lo = 0, shift = 2 * top;  // the answer lies in [lo, lo + 2^shift)
+  const int i = lane & 15;
+  while (shift > 0) {
+    const int s = shift >= 4 ? shift - 4 : 0;  // this round's step is 2^s leaves: 16 parts (4 in a last odd round)
+    const bool probe = i >= 1 && i < (1 << (shift - s));
+    const u64 c = probe ? codes[lo + (i << s)] : ~0ull;
+    const u64 below = __ballot(probe && c <= qc) & 0xfffeull;  // sorted: the set bits are a prefix of lanes 1..15
+    lo += __popcll(below) << s;
+    shift = s;
+  }
+  return lo;
+}
+
+constexpr int kWalkLevels = kMaxLevels - 1;  // levels that carry sibling bounds (every level but the root)
+
 // WPB waves (packets) per workgroup: one-wave workgroups are launched too slowly to fill the chip
 // (6250 of them at 100K queries: ~1.5 waves per SIMD resident on average)
 template <int K, int WPB>
 __device__ __forceinline__ void knn_packet_body(const KnnArgs& a, int wg, int n_wg) {
   __shared__ u64 s_merge_all[WPB][16][4][K];
+  // s_lb[L][lane]: lane (q, c)'s lower bound of query q to child c of the node of level L + 1 the walk is
+  // below -- the bounds of the siblings that wait on every level of the current path
+  __shared__ float s_lb_all[WPB][kWalkLevels][64];
   u64 (&s_merge)[16][4][K] = s_merge_all[threadIdx.x >> 6];
+  float (&s_lb)[kWalkLevels][64] = s_lb_all[threadIdx.x >> 6];
   const int lane = threadIdx.x & 63, sub = lane & 3, slot = lane >> 2;
   const int bid = xcd_contiguous_block(wg, n_wg) * WPB + (int)(threadIdx.x >> 6);
   if (bid * 16 >= a.q_count) return;  // a surplus wave of the last workgroup (no barrier below is block-wide)
@@ -665,126 +689,118 @@ __device__ __forceinline__ void knn_packet_body(const KnnArgs& a, int wg, int n_
   const float4* __restrict__ blo = a.tree.box_lo + a.tree.node_begin;
   const float4* __restrict__ bhi = a.tree.box_hi + a.tree.node_begin;
   const int top = a.tree.lv.n_levels - 1;
-  const int n_leaf = a.tree.lv.cnt[0];
 
-  // --- seed group: the level-1 node at the packet's position on the curve
-  int seed = 0;
-  if (top >= 1) {
-    if (a.self) {
-      seed = bid / kFan;  // the 16 queries ARE leaf `bid`
-    } else {
-      // (1) the previous search of these queries, when there is one: the leaf of a previous nearest
-      // neighbour (outer iterations move the pose little) -- one load instead of a curve transform
-      // The hint is only trusted while it is still close: the query's distance to its previous
-      // nearest neighbour must not have grown beyond twice what it was (after the first solve of an
-      // align() the pose jumps, and a stale hint is a worse seed than the curve position).
-      int hint_leaf = -1;
-      if (a.seed_hint) {
-        const size_t hq = (size_t)(a.q_begin + q) * a.hint_K;
-        const int prev = a.seed_hint[hq];
-        bool ok = prev >= a.t_begin && prev < a.t_begin + a.tree.n;
-        if (ok && a.out_d) {
-          const float4 hp = a.tree.pts4[a.tree.pt_begin + (prev - a.t_begin)];
-          ok = l2_simple(px, py, pz, hp.x, hp.y, hp.z) <= 4.0f * a.out_d[hq] + 1e-12f;
-        }
-        const u64 m = __ballot(ok);
-        if (m) {
-          const u64 upper = m >> 32;  // prefer a query from the middle of the packet
-          const int src = upper ? 32 + __ffsll((unsigned long long)upper) - 1 : __ffsll((unsigned long long)m) - 1;
-          hint_leaf = (__builtin_amdgcn_readlane(prev, src) - a.t_begin) / kLeaf;
-        }
-      }
-      if (hint_leaf >= 0) {
-        seed = hint_leaf / kFan;
-      } else {
-        // (2) binary search of the middle query's (10 bits per axis) curve index in the leaves' first
-        // indices, on the scalar unit (uniform addresses: ~13 dependent scalar loads).  A 64-ary
-        // ballot search is three rounds instead of thirteen but every round is 64 scattered vector
-        // loads per wave: in a batch launch those were +60 % memory transactions and +67 % time.
-        const u64 qc_lane = curve_code_coarse<10>(px, py, pz, a.tree.lo[0], a.tree.lo[1], a.tree.lo[2], a.tree.scale);
-        const u64 qc = ((u64)(unsigned)__builtin_amdgcn_readlane((int)(qc_lane >> 32), 32) << 32) |
-                       (unsigned)__builtin_amdgcn_readlane((int)qc_lane, 32);
-        const u64* __restrict__ codes = a.tree.leaf_code + a.tree.code_begin;
-        int lo_i = 0, hi_i = n_leaf - 1;  // last leaf whose first index is <= qc, else 0
-        while (lo_i < hi_i) {
-          const int mid = (lo_i + hi_i + 1) >> 1;
-          if (codes[mid] <= qc) lo_i = mid; else hi_i = mid - 1;
-        }
-        seed = lo_i / kFan;
-      }
-    }
-    seed = __builtin_amdgcn_readfirstlane(seed);
-  }
-  {
-    const int l0 = seed * kFan, l1 = min(l0 + kFan, n_leaf);  // a one-leaf tree: leaf 0
-    if (K >= 16 && l1 - l0 == kFan) {
-      // K = 20: the 16 seed candidates of a lane all enter its (empty) list.  Sixteen insertions are
-      // 16 x 39 instructions; writing them into the first 16 slots and sorting those with a
-      // 63-comparator network is 126 (same list: the keys are unique up to identical padding keys).
-      if constexpr (K >= 16) {
-#pragma unroll
-        for (int l = 0; l < kFan; ++l) {
-          const float4* __restrict__ lp = pts + (size_t)(l0 + l) * kLeaf;
-#pragma unroll
-          for (int p = 0; p < 4; ++p) {
-            const float4 t = lp[4 * p];
-            bk[4 * l + p] = make_key(l2_simple(px, py, pz, t.x, t.y, t.z), __float_as_uint(t.w));
-          }
-        }
-        key_sort16<K>(bk);
-        wd = quad_bound<K>(bk);
-      }
-    } else {
-#pragma unroll 1
-      for (int l = l0; l < l1; ++l) scan_leaf_quad<K>(pts + (size_t)l * kLeaf, px, py, pz, bk, wd);
-    }
-  }
-
-  // --- shared depth-first walk: all of this state is wave-uniform.  Two nested loops: the inner
-  // one only moves through the tree (scalar state, box tests) until it stands on a leaf some
-  // query needs, the outer one scans that leaf -- so the K-entry lists are carried by exactly one
-  // loop with one back edge (with `continue`s in a single loop the compiler kept up to three
-  // copies of the lists alive and moved them at every edge).
+  // --- One shared depth-first walk; all of its state is wave-uniform (scalar registers): the level, the first
+  // sibling's index and 4 sibling bits per level.  A launch lasts as long as its longest chain of DEPENDENT
+  // loads (PMC, profiles/r03: 4.4 of 8 waves per SIMD resident, a third of their time waiting for memory), so
+  // the walk is built to have few of them:
+  //   (1) the seed leaf -- the packet's own leaf for the covariance self-search, else the leaf at the middle
+  //       query's curve position, found by a 16-ary search (locate_leaf: 4 loads at 100K points, was 13);
+  //   (2) the whole root-to-seed path AT ONCE: the node indices on it are arithmetic, so the sibling boxes of
+  //       every level are loaded together (one round trip per 4 levels), tested, and their lower bounds left
+  //       in LDS -- the walk starts standing on the seed leaf with the complete stack of waiting siblings;
+  //   (3) the seed leaf's points give every query a first bound;
+  //   (4) from then on a waiting sibling is RE-TESTED with its stored bounds against the queries' current
+  //       bounds when its turn comes (no load), and a node is only loaded when some query still needs it.
+  // (Round 2: binary search, four seed leaves one after the other, then a walk from the root that entered
+  // siblings whose test was out of date: ~41 dependent loads per packet in the median.  A first attempt at
+  // (1) in this round -- descend from the root into the child nearest to the middle query -- halved the
+  // chain and doubled the visits: Hilbert-ordered boxes overlap, lb = 0 does not say where the neighbours are.)
   int n_box = 0, n_scan = 0;  // statistics (a.dbg), dead code otherwise
-  if (top >= 2) {
+  if (top == 0) {
+    scan_leaf_quad<K>(pts, px, py, pz, bk, wd);
+    ++n_scan;
+  } else {
+    int seed_leaf;
+    if (a.self) {
+      seed_leaf = bid;  // the 16 queries ARE leaf `bid`
+    } else {
+      const u64 qc_lane = curve_code_coarse<10>(px, py, pz, a.tree.lo[0], a.tree.lo[1], a.tree.lo[2], a.tree.scale);
+      const u64 qc = ((u64)(unsigned)__builtin_amdgcn_readlane((int)(qc_lane >> 32), 32) << 32) |
+                     (unsigned)__builtin_amdgcn_readlane((int)qc_lane, 32);
+      seed_leaf = locate_leaf(a.tree.leaf_code + a.tree.code_begin, top, qc, lane);
+    }
+    seed_leaf = __builtin_amdgcn_readfirstlane(seed_leaf);
     u64 masks = 0;  // 4 sibling bits per level
-    int L = top - 1, base = 0;
-    // lane (q, sub)'s lower bound of query q to child `sub` of the node expanded last.  When that node is
-    // a parent of leaves the bounds are kept for the leaves' own (re)test against the tightened lists:
-    // the leaf's box is not loaded a second time -- one dependent load less per leaf visit, and the
-    // launch lasts as long as its longest chain of dependent loads.
-    float child_lb;
-    // scalar state kept lean (this bookkeeping is half of the walk's instructions): sh = 4 * level, the
-    // level's sibling bits are always zero when the walk descends into it (they were consumed on the way
-    // up), unsigned arithmetic for the shifts
+    float cur_lb = 0.f;  // this lane's bound for child `sub` on the level the walk stands on
+    constexpr int PB = 4;  // levels per round trip of the path phase
+    for (int L0 = 0; L0 < top; L0 += PB) {
+      float4 lo[PB], hi[PB];
+#pragma unroll
+      for (int i = 0; i < PB; ++i) {  // (levels past the top are clamped: loaded, not used)
+        const int L = min(L0 + i, top - 1);
+        const int node = level_offset(top, L) + (((seed_leaf >> (2 * L)) & ~3) + sub);
+        lo[i] = blo[node];
+        hi[i] = bhi[node];
+      }
+#pragma unroll
+      for (int i = 0; i < PB; ++i) {
+        const int L = L0 + i;
+        if (L < top) {
+          const float lb = box_lb(lo[i], hi[i], px, py, pz);
+          s_lb[L][lane] = lb;
+          if (L == 0) cur_lb = lb;
+          u64 b = __ballot(lb < INFINITY);  // (a node without a real point below it has lb = +inf)
+          b |= b >> 32; b |= b >> 16; b |= b >> 8; b |= b >> 4;
+          const unsigned m4 = ((unsigned)b & 15u) & ~(1u << ((seed_leaf >> (2 * L)) & 3));  // the path's own node is not waiting
+          masks |= (u64)m4 << (4 * L);
+          ++n_box;
+        }
+      }
+    }
+    // the seed: one leaf; for the long lists the whole group of four, sorted by a network
+    if constexpr (K >= 16) {
+      // the 16 seed candidates of a lane all enter its (empty) list.  Sixteen insertions are 16 x 39
+      // instructions; writing them into the first 16 slots and sorting those with a 63-comparator network is
+      // 126 (same list: the keys are unique up to identical padding keys).
+      const int l0 = seed_leaf & ~3;
+#pragma unroll
+      for (int l = 0; l < kFan; ++l) {
+        const float4* __restrict__ lp = pts + (size_t)(l0 + l) * kLeaf;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const float4 t = lp[4 * p];
+          bk[4 * l + p] = make_key(l2_simple(px, py, pz, t.x, t.y, t.z), __float_as_uint(t.w));
+        }
+      }
+      key_sort16<K>(bk);
+      wd = quad_bound<K>(bk);
+      masks &= ~15ull;
+      n_scan += 4;
+    } else {
+      scan_leaf_quad<K>(pts + (size_t)seed_leaf * kLeaf, px, py, pz, bk, wd);
+      ++n_scan;
+    }
+    unsigned sh = 0u, ubase = (unsigned)seed_leaf & ~3u;
+    const unsigned sh_top = 4u * (unsigned)(top - 1);
     const unsigned t4 = 1u << (2 * (top + 1));  // level_offset(top, l) = (t4 - (t4 >> 2 l)) / 3
-    unsigned sh = 4u * (unsigned)L, ubase = 0u;
-    const unsigned sh_top = sh;
-    masks = (u64)child_mask_packet(blo, bhi, level_offset(top, L), 0, sub, px, py, pz, wd, child_lb) << sh;
+    // Two nested loops: the inner one only moves through the tree (scalar state, box tests) until it stands
+    // on a leaf some query needs, the outer one scans that leaf -- so the K-entry lists are carried by
+    // exactly one loop with one back edge (with `continue`s in a single loop the compiler keeps several
+    // copies of the lists alive and moves them at every edge: 218 instead of 52 registers at K = 20).
     for (;;) {
       int leaf = -1;
       for (;;) {
         const unsigned m = (unsigned)(masks >> sh) & 15u;
-        if (m == 0) {
+        if (m == 0) {  // this level is done: back to the parent's siblings
           if (sh == sh_top) break;
           sh += 4u;
           ubase = (ubase >> 2) & ~3u;
+          cur_lb = s_lb[sh >> 2][lane];
           continue;
         }
         const unsigned c = (unsigned)__ffs(m) - 1u;
         masks ^= 1ull << (sh + c);
+        // the bounds have tightened since the siblings were tested; the lanes with sub == c hold this one's
+        if (__ballot((unsigned)sub == c && !(cur_lb > wd)) == 0) continue;
         const unsigned node = ubase + c;
-        if (sh == 0u) {
-          // the bounds may have tightened since the parent's test; the lanes with sub == c hold this leaf's
-          if (__ballot((unsigned)sub == c && !(child_lb > wd)) != 0) { leaf = (int)node; break; }
-          continue;
-        }
-        if (sh == 4u && node == (unsigned)seed) continue;
+        if (sh == 0u) { leaf = (int)node; break; }
         ++n_box;
         sh -= 4u;
-        const unsigned cm = child_mask_packet(blo, bhi, (int)((t4 - (t4 >> (sh >> 1))) / 3u), (int)node, sub, px, py, pz, wd, child_lb);
-        masks |= (u64)cm << sh;
         ubase = node * kFan;
+        const unsigned cm = child_mask_packet(blo, bhi, (int)((t4 - (t4 >> (sh >> 1))) / 3u), (int)node, sub, px, py, pz, wd, cur_lb);
+        masks |= (u64)cm << sh;  // (a level's sibling bits are zero when the walk descends into it)
+        s_lb[sh >> 2][lane] = cur_lb;
       }
       if (leaf < 0) break;
       scan_leaf_quad<K>(pts + (size_t)leaf * kLeaf, px, py, pz, bk, wd);
