@@ -221,6 +221,58 @@ int sicp_align(sicp_handle h, const double init_qt[7], double out_qt[7],
 int sicp_align_batch(sicp_handle* handles, int32_t n, const double* init_qt, double* out_qt,
                      int32_t* outer_iters, sicp_stats* stats);
 
+/* ---- registration streams: an OPEN sequence of scan pairs --------------------------------------
+ * The unit the reference iterates over is one align() per loop trip (exec/kitti_eval.cc:124-249:
+ * ~4.5K stride-3 pairs of one odometry sequence, every scan the source of one registration and the
+ * target of the next).  A stream is the continuous batching of sicp_align_batch without the closed
+ * batch: registrations are submitted as their scans arrive and come out as they converge, up to
+ * max_in_flight of them share the GPU, and a pair that needs 500 LM evaluations does not hold back the
+ * batch it happened to be submitted with.  Per pair the result is bit-identical to sicp_align.
+ *
+ *   sicp_stream_create(device, params, max_in_flight, &s)   mode, K, tolerances ... of every registration
+ *   sicp_stream_set_confusion(s, C, cm)                      SICP_MODE_EM
+ *   id = sicp_stream_add_cloud(s, n, x, y, z, label)         setSourceCloud / setTargetCloud
+ *        (em_icp.h:50-66): copies the cloud into pinned memory and queues upload + search-tree
+ *        build on the stream's own HIP stream, beside the running registrations; returns at once.
+ *        A cloud may take part in any number of registrations: it is uploaded and indexed once
+ *        and its normals / histograms are computed once (what setSourceCloud(cloud, kdtree, covs),
+ *        gicp.h:48-56, exists for).
+ *   ticket = sicp_stream_submit(s, source_id, target_id, init_qt)   align(final, init); blocks
+ *        while max_in_flight registrations are already waiting (back-pressure)
+ *   sicp_stream_release_cloud(s, id)                         the caller is done with it; it is
+ *        recycled when its last registration has finished
+ *   sicp_stream_poll(s, wait, max, results, &n)              finished registrations, in order of
+ *        completion: wait = 0 returns what is there, 1 waits for at least one result (or for the
+ *        stream to run dry), 2 waits until everything submitted so far has finished
+ *
+ * A library-owned worker thread advances the registrations; submit / add_cloud / poll may be called
+ * from any thread(s).  Requires the default engine (nn_method 1, lm_on_device 1, profile 0).
+ * No reference counterpart. */
+typedef struct sicp_stream_ctx* sicp_stream;
+typedef struct sicp_stream_result {
+  int64_t ticket;       /* what sicp_stream_submit returned */
+  int32_t status;       /* SICP_OK, or why this registration could not run */
+  int32_t outer_iters;  /* getOuterIter() */
+  double qt[7];         /* getFinalTransFormation() */
+  sicp_stats stats;     /* as from sicp_align, except total_active (0: not counted in a stream) */
+} sicp_stream_result;
+int sicp_stream_create(int device_id, const sicp_params* params, int32_t max_in_flight, sicp_stream* out);
+int sicp_stream_destroy(sicp_stream s);  /* registrations still in flight are abandoned */
+int sicp_stream_set_confusion(sicp_stream s, int32_t C, const double* cm_rowmajor);
+int sicp_stream_add_cloud(sicp_stream s, int32_t n, const float* x, const float* y, const float* z,
+                          const uint32_t* label, int64_t* cloud_id);
+int sicp_stream_release_cloud(sicp_stream s, int64_t cloud_id);
+int sicp_stream_submit(sicp_stream s, int64_t source_id, int64_t target_id, const double init_qt[7],
+                       int64_t* ticket);
+int sicp_stream_poll(sicp_stream s, int32_t wait, int32_t max_results, sicp_stream_result* results,
+                     int32_t* n_results);
+/* counters since creation: registrations submitted / finished, and -- over the finished ones -- their
+ * own LM evaluations and the evaluation launches they sat through (busy fraction = the ratio).  Any
+ * output may be NULL. */
+int sicp_stream_counters(sicp_stream s, int64_t* submitted, int64_t* completed, int64_t* busy_evals,
+                         int64_t* slot_evals);
+const char* sicp_stream_last_error(sicp_stream s);
+
 /* the final_cloud output of align (em_icp.hpp:192-198): source transformed by
  * float(matrix(qt)); ox/oy/oz are host buffers of n_source floats */
 int sicp_transform_source(sicp_handle h, const double qt[7], float* ox, float* oy, float* oz);

@@ -97,6 +97,16 @@ class SicpStats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved0"}
 
 
+class SicpStreamResult(C.Structure):
+    _fields_ = [
+        ("ticket", C.c_int64),
+        ("status", C.c_int32),
+        ("outer_iters", C.c_int32),
+        ("qt", C.c_double * 7),
+        ("stats", SicpStats),
+    ]
+
+
 class SicpError(RuntimeError):
     def __init__(self, status, where, detail=""):
         self.status = status
@@ -140,6 +150,8 @@ def lib():
         _lib.sicp_last_error.restype = C.c_char_p
         _lib.sicp_last_error.argtypes = [C.c_void_p]
         _lib.sicp_version.restype = C.c_char_p
+        _lib.sicp_stream_last_error.restype = C.c_char_p
+        _lib.sicp_stream_last_error.argtypes = [C.c_void_p]
         for name, args in {
             "sicp_device_count": [C.POINTER(C.c_int)],
             "sicp_create": [C.c_int, C.POINTER(C.c_void_p)],
@@ -165,6 +177,14 @@ def lib():
             "sicp_solve": [C.c_void_p, _dp, _dp, _ip, _ip, _dp],
             "sicp_se3_device": [C.c_void_p, C.c_int, C.c_int32, _dp, _dp],
             "sicp_get_stats": [C.c_void_p, C.POINTER(SicpStats)],
+            "sicp_stream_create": [C.c_int, C.POINTER(SicpParams), C.c_int32, C.POINTER(C.c_void_p)],
+            "sicp_stream_destroy": [C.c_void_p],
+            "sicp_stream_set_confusion": [C.c_void_p, C.c_int32, _dp],
+            "sicp_stream_add_cloud": [C.c_void_p, C.c_int32, _fp, _fp, _fp, _up, C.POINTER(C.c_int64)],
+            "sicp_stream_release_cloud": [C.c_void_p, C.c_int64],
+            "sicp_stream_submit": [C.c_void_p, C.c_int64, C.c_int64, _dp, C.POINTER(C.c_int64)],
+            "sicp_stream_poll": [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(SicpStreamResult), C.POINTER(C.c_int32)],
+            "sicp_stream_counters": [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
             "sicp_synchronize": [C.c_void_p],
         }.items():
             fn = getattr(_lib, name)
@@ -405,3 +425,79 @@ def search_batch(engines, qts=None, what: int = 0, use_hint: bool = True, repeat
         msgs = "; ".join(m for m in (lib().sicp_last_error(e._h).decode() for e in engines) if m)
         raise RuntimeError(f"sicp_search_batch failed: {_strerror(rc)} ({rc}) {msgs}")
     return ms.value
+
+
+class Stream:
+    """sicp_stream_*: an open sequence of registrations on one device (continuous batching without the closed
+    batch).  add_cloud() uploads and indexes a scan once; submit() queues source -> target; poll() hands back
+    finished registrations as (ticket, qt, stats) in order of completion."""
+
+    def __init__(self, device: int, params: SicpParams, max_in_flight: int = 256, confusion=None):
+        self._s = C.c_void_p()
+        st = lib().sicp_stream_create(device, C.byref(params), max_in_flight, C.byref(self._s))
+        if st != OK:
+            self._s = C.c_void_p()
+            raise SicpError(st, "sicp_stream_create")
+        if confusion is not None:
+            cm = np.ascontiguousarray(confusion, dtype=np.float64)
+            self._check(lib().sicp_stream_set_confusion(self._s, cm.shape[0], _ptr(cm, _dp)), "sicp_stream_set_confusion")
+
+    def _check(self, st, where):
+        if st != OK:
+            raise SicpError(st, where, lib().sicp_stream_last_error(self._s).decode())
+
+    def close(self):
+        if getattr(self, "_s", None) and self._s.value:
+            lib().sicp_stream_destroy(self._s)
+            self._s = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def add_cloud(self, xyz, labels=None) -> int:
+        xyz = np.asarray(xyz)
+        x, y, z = (np.ascontiguousarray(xyz[:, i], dtype=np.float32) for i in range(3))
+        lab = None if labels is None else np.ascontiguousarray(labels, dtype=np.uint32)
+        cid = C.c_int64(0)
+        self._check(lib().sicp_stream_add_cloud(self._s, x.shape[0], _ptr(x, _fp), _ptr(y, _fp), _ptr(z, _fp), _ptr(lab, _up), C.byref(cid)),
+                    "sicp_stream_add_cloud")
+        return cid.value
+
+    def release_cloud(self, cloud_id: int):
+        self._check(lib().sicp_stream_release_cloud(self._s, cloud_id), "sicp_stream_release_cloud")
+
+    def submit(self, source_id: int, target_id: int, init_qt=None) -> int:
+        init = np.array([0, 0, 0, 1, 0, 0, 0], dtype=np.float64) if init_qt is None else np.ascontiguousarray(init_qt, dtype=np.float64)
+        t = C.c_int64(0)
+        self._check(lib().sicp_stream_submit(self._s, source_id, target_id, _ptr(init, _dp), C.byref(t)), "sicp_stream_submit")
+        return t.value
+
+    def poll(self, wait: int = 0, max_results: int = 1024):
+        buf = (SicpStreamResult * max_results)()
+        n = C.c_int32(0)
+        self._check(lib().sicp_stream_poll(self._s, wait, max_results, buf, C.byref(n)), "sicp_stream_poll")
+        return [(r.ticket, r.status, np.array(r.qt[:]), r.stats.as_dict()) for r in buf[: n.value]]
+
+    def drain(self):
+        """everything submitted so far, finished"""
+        out = self.poll(wait=2)
+        while True:
+            more = self.poll(wait=0)
+            if not more:
+                return out
+            out += more
+
+    def counters(self):
+        a, b, c, d = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        self._check(lib().sicp_stream_counters(self._s, C.byref(a), C.byref(b), C.byref(c), C.byref(d)), "sicp_stream_counters")
+        return dict(submitted=a.value, completed=b.value, busy_evals=c.value, slot_evals=d.value,
+                    busy_fraction=(c.value / d.value) if d.value else 0.0)

@@ -669,12 +669,15 @@ constexpr int kWalkLevels = kMaxLevels - 1;  // levels that carry sibling bounds
 // (6250 of them at 100K queries: ~1.5 waves per SIMD resident on average)
 template <int K, int WPB>
 __device__ __forceinline__ void knn_packet_body(const KnnArgs& a, int wg, int n_wg) {
-  __shared__ u64 s_merge_all[WPB][16][4][K];
-  // s_lb[L][lane]: lane (q, c)'s lower bound of query q to child c of the node of level L + 1 the walk is
-  // below -- the bounds of the siblings that wait on every level of the current path
-  __shared__ float s_lb_all[WPB][kWalkLevels][64];
-  u64 (&s_merge)[16][4][K] = s_merge_all[threadIdx.x >> 6];
-  float (&s_lb)[kWalkLevels][64] = s_lb_all[threadIdx.x >> 6];
+  // One wave-private LDS region, used twice: during the walk it holds s_lb[L][lane] = lane (q, c)'s lower
+  // bound of query q to child c of the node of level L + 1 the walk is below -- the bounds of the siblings
+  // that wait on every level of the current path; at the end the quad's four lists are merged through it.
+  // (As two arrays the K = 20 kernel needs 26 KB per two-wave workgroup: 3 waves per SIMD.)
+  constexpr size_t kMergeBytes = sizeof(u64) * 16 * 4 * K, kLbBytes = sizeof(float) * kWalkLevels * 64;
+  constexpr size_t kWaveBytes = kMergeBytes > kLbBytes ? kMergeBytes : kLbBytes;
+  __shared__ __attribute__((aligned(16))) unsigned char s_wave_all[WPB][kWaveBytes];
+  u64 (&s_merge)[16][4][K] = *reinterpret_cast<u64 (*)[16][4][K]>(s_wave_all[threadIdx.x >> 6]);
+  float (&s_lb)[kWalkLevels][64] = *reinterpret_cast<float (*)[kWalkLevels][64]>(s_wave_all[threadIdx.x >> 6]);
   const int lane = threadIdx.x & 63, sub = lane & 3, slot = lane >> 2;
   const int bid = xcd_contiguous_block(wg, n_wg) * WPB + (int)(threadIdx.x >> 6);
   if (bid * 16 >= a.q_count) return;  // a surplus wave of the last workgroup (no barrier below is block-wide)

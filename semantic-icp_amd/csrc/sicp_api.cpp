@@ -181,6 +181,10 @@ std::shared_ptr<Cloud> acquire_cloud(int device) {
   }
   if (!c) c = new Cloud();
   return std::shared_ptr<Cloud>(c, [slot, device](Cloud* dead) {
+    // (a stream's cloud may be dropped without any handle having waited for its upload on the host: settle it
+    // while the uploading stream still exists -- see settle_cloud)
+    if (dead->pending && dead->ready_ev) (void)hipEventSynchronize(dead->ready_ev);
+    dead->pending = false;
     dead->n = 0; dead->n_caller = 0; dead->is_set = false; dead->has_label = false; dead->layout = -1;
     dead->keep.clear(); dead->drop_i.clear(); dead->drop_xyz.clear();
     dead->feat_valid = false; dead->proj_valid = false; dead->feat_epoch = 0; dead->proj_cm_id = 0;
@@ -291,6 +295,42 @@ struct sicp_context {
   sicp_stats st;
 };
 
+// ---- a registration stream (sicp_stream_*): the continuous batching of sicp_align_batch without the closed
+// batch.  Clouds are uploaded by the submitting thread on the stream's own upload stream; a worker thread owns
+// `cap` handles (slots) and runs the tick loop: admit queued registrations into free slots, one turn, retire.
+struct StreamCloudRef;
+struct sicp_stream_ctx {
+  int device = 0, cap = 0;
+  sicp_params params;
+  int C = 0;
+  std::vector<double> cm;
+  std::vector<sicp_context*> slots;      // slots[0] leads: tick sets, LM states, side stream
+  std::vector<hipStream_t> own1, own2;   // the slots' own streams (restored before the handles are destroyed)
+  sicp_context* uploader = nullptr;      // runs the uploads + search-tree builds (caller's thread, own stream)
+  std::mutex up_m;                       // one upload at a time
+  // ---- shared between the caller's threads and the worker, under `m`
+  std::mutex m;
+  std::condition_variable cv_work, cv_done, cv_space;
+  struct Submission {
+    long long ticket;
+    std::shared_ptr<Cloud> src, tgt;
+    double init[7];
+  };
+  std::deque<Submission> queue;
+  std::deque<sicp_stream_result> done;
+  std::unordered_map<long long, std::shared_ptr<Cloud>> clouds;
+  long long next_cloud = 1, next_ticket = 1;
+  long long submitted = 0, completed = 0, busy_evals = 0, slot_evals = 0;
+  int in_flight = 0;
+  bool stop = false;
+  int error = 0;
+  std::string error_msg;
+  // ---- worker only
+  std::vector<long long> slot_ticket;
+  std::vector<double> slot_t0;
+  std::thread worker;
+};
+
 namespace {
 
 #define HIPCHECK(expr)                                                                         \
@@ -350,6 +390,55 @@ int cloud_wait(sicp_context* h, Cloud& c) {
     HIPCHECK(hipEventSynchronize(c.ready_ev));
     c.pending = false;
   }
+  return SICP_OK;
+}
+
+// host side of an upload: the caller's arrays -> the cloud's pinned staging buffers
+int stage_cloud(sicp_context* h, Cloud& c, int32_t n, const float* x, const float* y, const float* z, const uint32_t* label) {
+  if ((long long)n > ((long long)sicp::kLeaf << (2 * (sicp::kMaxLevels - 1)))) {
+    h->last_error = "cloud too large for the search tree (16 * 4^11 = 67 M points per cloud)";
+    return SICP_ERR_INVALID_ARGUMENT;
+  }
+  SICPCHECK(cloud_wait(h, c));  // a previous upload may still be reading the staging buffers
+  // Non-finite points (the NaNs of an organized RGB-D cloud) never enter the device cloud:
+  // pcl::KdTreeFLANN::setInputCloud (em_icp.h:50-66) leaves them out of the search index, so the
+  // reference can neither find them as neighbours nor -- a NaN query keeps no candidate -- match them.
+  // Everything below works on the finite points; outputs are mapped back to the caller's indices.
+  c.n_caller = n;
+  c.keep.clear(); c.drop_i.clear(); c.drop_xyz.clear();
+  int n_bad = 0;
+  for (int i = 0; i < n; ++i) n_bad += !(std::isfinite(x[i]) && std::isfinite(y[i]) && std::isfinite(z[i]));
+  c.has_label = label != nullptr;
+  if (n_bad == 0) {
+    HIPCHECK(c.hx.assign(x, n)); HIPCHECK(c.hy.assign(y, n)); HIPCHECK(c.hz.assign(z, n));
+    HIPCHECK(c.hl.assign(label, label ? n : 0));
+    c.n = n;
+  } else {
+    const int m = n - n_bad;
+    HIPCHECK(c.hx.resize(m)); HIPCHECK(c.hy.resize(m)); HIPCHECK(c.hz.resize(m)); HIPCHECK(c.hl.resize(label ? m : 0));
+    c.keep.reserve(m); c.drop_i.reserve(n_bad); c.drop_xyz.reserve((size_t)3 * n_bad);
+    for (int i = 0; i < n; ++i) {
+      if (std::isfinite(x[i]) && std::isfinite(y[i]) && std::isfinite(z[i])) {
+        const size_t k = c.keep.size();
+        c.hx[k] = x[i]; c.hy[k] = y[i]; c.hz[k] = z[i];
+        if (label) c.hl[k] = label[i];
+        c.keep.push_back(i);
+      } else {
+        c.drop_i.push_back(i);
+        c.drop_xyz.push_back(x[i]); c.drop_xyz.push_back(y[i]); c.drop_xyz.push_back(z[i]);
+      }
+    }
+    c.n = m;
+  }
+  c.label_min = 0xffffffffu; c.label_max = 0;
+  for (size_t i = 0; i < c.hl.size(); ++i) {
+    c.label_min = std::min(c.label_min, c.hl[i]);
+    c.label_max = std::max(c.label_max, c.hl[i]);
+  }
+  c.is_set = true;
+  c.layout = -1;
+  c.feat_valid = false;
+  c.proj_valid = false;
   return SICP_OK;
 }
 
@@ -1441,42 +1530,7 @@ int sicp_set_cloud(sicp_handle h, int which, int32_t n, const float* x, const fl
     h->cl[which] = acquire_cloud(h->device);
   }
   Cloud& c = h->cloud(which);
-  SICPCHECK(cloud_wait(h, c));  // a previous upload may still be reading the staging buffers
-  // Non-finite points (the NaNs of an organized RGB-D cloud) never enter the device cloud:
-  // pcl::KdTreeFLANN::setInputCloud (em_icp.h:50-66) leaves them out of the search index, so the
-  // reference can neither find them as neighbours nor -- a NaN query keeps no candidate -- match them.
-  // Everything below works on the finite points; outputs are mapped back to the caller's indices.
-  c.n_caller = n;
-  c.keep.clear(); c.drop_i.clear(); c.drop_xyz.clear();
-  int n_bad = 0;
-  for (int i = 0; i < n; ++i) n_bad += !(std::isfinite(x[i]) && std::isfinite(y[i]) && std::isfinite(z[i]));
-  c.has_label = label != nullptr;
-  if (n_bad == 0) {
-    HIPCHECK(c.hx.assign(x, n)); HIPCHECK(c.hy.assign(y, n)); HIPCHECK(c.hz.assign(z, n));
-    HIPCHECK(c.hl.assign(label, label ? n : 0));
-    c.n = n;
-  } else {
-    const int m = n - n_bad;
-    HIPCHECK(c.hx.resize(m)); HIPCHECK(c.hy.resize(m)); HIPCHECK(c.hz.resize(m)); HIPCHECK(c.hl.resize(label ? m : 0));
-    c.keep.reserve(m); c.drop_i.reserve(n_bad); c.drop_xyz.reserve((size_t)3 * n_bad);
-    for (int i = 0; i < n; ++i) {
-      if (std::isfinite(x[i]) && std::isfinite(y[i]) && std::isfinite(z[i])) {
-        const size_t k = c.keep.size();
-        c.hx[k] = x[i]; c.hy[k] = y[i]; c.hz[k] = z[i];
-        if (label) c.hl[k] = label[i];
-        c.keep.push_back(i);
-      } else {
-        c.drop_i.push_back(i);
-        c.drop_xyz.push_back(x[i]); c.drop_xyz.push_back(y[i]); c.drop_xyz.push_back(z[i]);
-      }
-    }
-    c.n = m;
-  }
-  c.label_min = 0xffffffffu; c.label_max = 0;
-  for (size_t i = 0; i < c.hl.size(); ++i) {
-    c.label_min = std::min(c.label_min, c.hl[i]);
-    c.label_max = std::max(c.label_max, c.hl[i]);
-  }
+  SICPCHECK(stage_cloud(h, c, n, x, y, z, label));
   c.is_set = true;
   c.layout = -1;
   c.feat_valid = false;
@@ -1743,6 +1797,302 @@ int sicp_accumulate_batch(sicp_handle* hs, int32_t n, const double* qt, double* 
     HIPCHECK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     *kernel_ms = (double)ms / repeat;
   }
+  return SICP_OK;
+}
+
+// =================================================================================================
+// registration streams
+// =================================================================================================
+}  // extern "C"
+
+namespace {
+
+void stream_fail(sicp_stream_ctx* S, int rc, const std::string& msg) {
+  std::lock_guard<std::mutex> lock(S->m);
+  if (S->error == SICP_OK) { S->error = rc; S->error_msg = msg; }
+  S->cv_done.notify_all();
+  S->cv_space.notify_all();
+}
+
+// The worker: admit queued registrations into free slots, one turn of the continuous batching
+// (BatchRun::turn: finish the tick in flight, queue the searches of the pairs between two solves, launch
+// the next tick), retire the pairs that have converged.  One iteration per tick.
+void stream_worker(sicp_stream_ctx* S) {
+  if (hipSetDevice(S->device) != hipSuccess) { stream_fail(S, SICP_ERR_NO_DEVICE, "hipSetDevice"); return; }
+  sicp_context* L = S->slots[0];
+  BatchRun run;
+  run.L = L; run.hs = S->slots.data(); run.P = S->params; run.one_launch = true; run.want_stats = false;
+  run.resize(S->cap);
+  run.len = std::min(S->params.lm_batch > 0 ? S->params.lm_batch : 8, sicp::kMaxBatchLen);
+  run.side = L->side_stream;
+  TickGroup G;
+  G.lo = 0; G.hi = S->cap; G.M = S->own1[0]; G.S = &L->ts[0]; G.side_done = L->side_done;
+  JobCollector jc;
+  for (sicp_context* g : S->slots) g->collect = &jc;
+  std::vector<int> free_slots;
+  for (int p = S->cap - 1; p >= 0; --p) free_slots.push_back(p);
+  std::vector<sicp_stream_ctx::Submission> fresh;
+  std::vector<int> fresh_slot;
+  std::vector<sicp_stream_result> out;
+  for (;;) {
+    // ---- admit
+    fresh.clear(); fresh_slot.clear();
+    {
+      std::unique_lock<std::mutex> lock(S->m);
+      S->cv_work.wait(lock, [&] { return S->stop || !S->queue.empty() || S->in_flight > 0; });
+      if (S->stop) return;
+      while (!S->queue.empty() && !free_slots.empty()) {
+        fresh.push_back(std::move(S->queue.front()));
+        S->queue.pop_front();
+        fresh_slot.push_back(free_slots.back());
+        free_slots.pop_back();
+        ++S->in_flight;
+      }
+      if (!fresh.empty()) S->cv_space.notify_all();
+    }
+    out.clear();
+    for (size_t k = 0; k < fresh.size(); ++k) {
+      const int p = fresh_slot[k];
+      sicp_context* h = S->slots[p];
+      // the slot lets go of its previous pair's clouds and takes this pair's
+      h->cl[0] = fresh[k].src;
+      h->cl[1] = fresh[k].tgt;
+      h->corr_valid = false;
+      h->epoch = next_epoch();
+      S->slot_ticket[p] = fresh[k].ticket;
+      S->slot_t0[p] = now_ms();
+      jc.slice = batch_slice(p, S->cap, S->params.knn);
+      int rc = check_ready(h, false);
+      if (rc == SICP_OK) rc = align_begin(h, false);
+      if (rc != SICP_OK) {  // this registration cannot run (too few points, bad labels ...): report it, free the slot
+        sicp_stream_result r;
+        std::memset(&r, 0, sizeof r);
+        r.ticket = fresh[k].ticket; r.status = rc;
+        std::memcpy(r.qt, fresh[k].init, sizeof r.qt);
+        out.push_back(r);
+        free_slots.push_back(p);
+        if (rc == SICP_ERR_HIP) { stream_fail(S, rc, h->last_error); return; }
+        continue;
+      }
+      run.start_pair(p, fresh[k].init);
+    }
+    // the new pairs' features (self-searches, covariances, projections): one launch per kind, on the side
+    // stream, beside the tick in flight and ahead of the pairs' first searches
+    if (!fresh.empty()) {
+      const int rc = flush_jobs(L, jc, run.side);
+      if (rc != SICP_OK) { stream_fail(S, rc, L->last_error); return; }
+    }
+    // ---- one turn
+    {
+      const int rc = run.turn(G, jc);
+      if (rc != SICP_OK) { stream_fail(S, rc, L->last_error); return; }
+    }
+    // ---- retire
+    long long busy = 0, slots_sat = 0;
+    for (int p = 0; p < S->cap; ++p) {
+      if (run.phase[p] != PAIR_DONE) continue;
+      sicp_context* h = S->slots[p];
+      sicp_stream_result r;
+      std::memset(&r, 0, sizeof r);
+      r.ticket = S->slot_ticket[p];
+      r.status = SICP_OK;
+      h->st.outer_iters = S->params.mode == SICP_MODE_SEMANTIC ? run.o[p].count : run.o[p].outer;
+      h->st.t_total_ms = now_ms() - S->slot_t0[p];
+      r.outer_iters = h->st.outer_iters;
+      std::memcpy(r.qt, run.o[p].cur, sizeof r.qt);
+      r.stats = h->st;
+      busy += h->st.total_evals; slots_sat += h->st.lockstep_slots;
+      out.push_back(r);
+      run.phase[p] = PAIR_FREE;
+      free_slots.push_back(p);
+    }
+    if (!out.empty()) {
+      std::lock_guard<std::mutex> lock(S->m);
+      for (const sicp_stream_result& r : out) S->done.push_back(r);
+      S->in_flight -= (int)out.size();
+      S->completed += (long long)out.size();
+      S->busy_evals += busy; S->slot_evals += slots_sat;
+      S->cv_done.notify_all();
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int sicp_stream_create(int device_id, const sicp_params* params, int32_t max_in_flight, sicp_stream* out) {
+  if (!out || !params || max_in_flight < 1 || max_in_flight > 4096) return SICP_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  if (params->nn_method != 1 || params->lm_on_device == 0 || params->profile != 0) return SICP_ERR_INVALID_ARGUMENT;
+  std::unique_ptr<sicp_stream_ctx> S(new (std::nothrow) sicp_stream_ctx());
+  if (!S) return SICP_ERR_OUT_OF_MEMORY;
+  S->device = device_id;
+  S->cap = max_in_flight;
+  S->params = *params;
+  S->params.reuse_features = 1;  // a stream's cloud keeps its normals / histograms: computed with its first registration
+  S->params.lm_on_device = 1;
+  auto cleanup = [&](int rc) {
+    for (size_t k = 0; k < S->slots.size(); ++k) {
+      sicp_context* g = S->slots[k];
+      g->collect = nullptr; g->stream = S->own1[k]; g->stream2 = S->own2[k];
+      sicp_destroy(g);
+    }
+    if (S->uploader) sicp_destroy(S->uploader);
+    return rc;
+  };
+  int rc = sicp_create(device_id, &S->uploader);
+  if (rc != SICP_OK) return cleanup(rc);
+  rc = sicp_set_params(S->uploader, &S->params);
+  if (rc != SICP_OK) return cleanup(rc);
+  for (int p = 0; p < S->cap; ++p) {
+    sicp_context* g = nullptr;
+    rc = sicp_create(device_id, &g);
+    if (rc != SICP_OK) return cleanup(rc);
+    S->slots.push_back(g);
+    S->own1.push_back(g->stream);
+    S->own2.push_back(g->stream2);
+    rc = sicp_set_params(g, &S->params);
+    if (rc != SICP_OK) return cleanup(rc);
+  }
+  {  // the leader's batch machinery (what sicp_align_batch sets up per call)
+    sicp_context* h = S->slots[0];
+    rc = batch_reserve(h, S->cap);
+    if (rc != SICP_OK) return cleanup(rc);
+    h->ts[0].tick_valid = false;
+    if (!h->side_stream) {
+      if (hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking) != hipSuccess ||
+          hipEventCreateWithFlags(&h->side_done, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&h->main_done, hipEventDisableTiming) != hipSuccess)
+        return cleanup(SICP_ERR_HIP);
+    }
+    // every slot's own launches (memsets of the semantic search, cloud waits) go to the side stream
+    for (sicp_context* g : S->slots) { g->stream = h->side_stream; g->stream2 = h->side_stream; g->wait_on_device = true; }
+  }
+  S->slot_ticket.assign(S->cap, 0);
+  S->slot_t0.assign(S->cap, 0.0);
+  S->worker = std::thread(stream_worker, S.get());
+  *out = S.release();
+  return SICP_OK;
+}
+
+int sicp_stream_destroy(sicp_stream S) {
+  if (!S) return SICP_OK;
+  {
+    std::lock_guard<std::mutex> lock(S->m);
+    S->stop = true;
+    S->cv_work.notify_all();
+    S->cv_space.notify_all();
+    S->cv_done.notify_all();
+  }
+  if (S->worker.joinable()) S->worker.join();
+  (void)hipSetDevice(S->device);
+  if (!S->slots.empty() && S->slots[0]->side_stream) (void)hipStreamSynchronize(S->slots[0]->side_stream);
+  for (size_t k = 0; k < S->slots.size(); ++k) (void)hipStreamSynchronize(S->own1[k]);
+  if (S->uploader) (void)hipStreamSynchronize(S->uploader->stream);
+  // the clouds go back to the pool once nothing refers to them: settle their uploads while the upload stream exists
+  for (auto& kv : S->clouds) settle_cloud(*kv.second);
+  for (auto& q : S->queue) { settle_cloud(*q.src); settle_cloud(*q.tgt); }
+  for (size_t k = 0; k < S->slots.size(); ++k) {
+    sicp_context* g = S->slots[k];
+    g->collect = nullptr; g->stream = S->own1[k]; g->stream2 = S->own2[k];
+    sicp_destroy(g);
+  }
+  S->clouds.clear();
+  S->queue.clear();
+  if (S->uploader) sicp_destroy(S->uploader);
+  delete S;
+  return SICP_OK;
+}
+
+const char* sicp_stream_last_error(sicp_stream S) { return S ? S->error_msg.c_str() : ""; }
+
+int sicp_stream_set_confusion(sicp_stream S, int32_t C, const double* cm) {
+  if (!S || C < 1 || C > 255 || !cm) return SICP_ERR_INVALID_ARGUMENT;
+  {
+    std::lock_guard<std::mutex> lock(S->m);
+    if (S->submitted > 0) return SICP_ERR_INVALID_ARGUMENT;  // before the first registration
+  }
+  for (size_t k = 0; k < S->slots.size(); ++k) {
+    // (sicp_set_confusion uploads on the handle's stream and waits for it: the slot's own stream, not the side stream)
+    sicp_context* g = S->slots[k];
+    hipStream_t keep = g->stream;
+    g->stream = S->own1[k];
+    int rc = sicp_set_confusion(g, C, cm);
+    if (rc == SICP_OK) rc = ensure_hval(g, S->params.k_cov);  // (one small upload + wait per slot, here rather than in the worker)
+    g->stream = keep;
+    if (rc != SICP_OK) return rc;
+  }
+  return sicp_set_confusion(S->uploader, C, cm);
+}
+
+int sicp_stream_add_cloud(sicp_stream S, int32_t n, const float* x, const float* y, const float* z, const uint32_t* label, int64_t* cloud_id) {
+  if (!S || !cloud_id || n < 0 || (n > 0 && (!x || !y || !z))) return SICP_ERR_INVALID_ARGUMENT;
+  if (S->params.mode != SICP_MODE_GICP && !label) return SICP_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> up(S->up_m);
+  sicp_context* h = S->uploader;
+  SICPCHECK(set_device(h));
+  std::shared_ptr<Cloud> c = acquire_cloud(S->device);
+  SICPCHECK(stage_cloud(h, *c, n, x, y, z, label));
+  SICPCHECK(prepare_cloud(h, *c));  // H2D + search-tree build queued on the upload stream; ready_ev recorded
+  std::lock_guard<std::mutex> lock(S->m);
+  const long long id = S->next_cloud++;
+  S->clouds.emplace(id, std::move(c));
+  *cloud_id = id;
+  return SICP_OK;
+}
+
+int sicp_stream_release_cloud(sicp_stream S, int64_t cloud_id) {
+  if (!S) return SICP_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lock(S->m);
+  return S->clouds.erase(cloud_id) ? SICP_OK : SICP_ERR_INVALID_ARGUMENT;
+}
+
+int sicp_stream_submit(sicp_stream S, int64_t source_id, int64_t target_id, const double init_qt[7], int64_t* ticket) {
+  if (!S || !init_qt) return SICP_ERR_INVALID_ARGUMENT;
+  std::unique_lock<std::mutex> lock(S->m);
+  if (S->error != SICP_OK) return S->error;
+  auto a = S->clouds.find(source_id), b = S->clouds.find(target_id);
+  if (a == S->clouds.end() || b == S->clouds.end()) return SICP_ERR_INVALID_ARGUMENT;
+  S->cv_space.wait(lock, [&] { return S->stop || S->error != SICP_OK || (int)S->queue.size() < S->cap; });
+  if (S->error != SICP_OK) return S->error;
+  if (S->stop) return SICP_ERR_INVALID_ARGUMENT;
+  sicp_stream_ctx::Submission q;
+  q.ticket = S->next_ticket++;
+  q.src = a->second; q.tgt = b->second;
+  std::memcpy(q.init, init_qt, sizeof q.init);
+  S->queue.push_back(std::move(q));
+  ++S->submitted;
+  if (ticket) *ticket = S->next_ticket - 1;
+  S->cv_work.notify_all();
+  return SICP_OK;
+}
+
+int sicp_stream_poll(sicp_stream S, int32_t wait, int32_t max_results, sicp_stream_result* results, int32_t* n_results) {
+  if (!S || !n_results || max_results < 0 || (max_results > 0 && !results)) return SICP_ERR_INVALID_ARGUMENT;
+  *n_results = 0;
+  std::unique_lock<std::mutex> lock(S->m);
+  const long long want = S->submitted;
+  if (wait == 1)
+    S->cv_done.wait(lock, [&] { return S->stop || S->error != SICP_OK || !S->done.empty() || S->completed >= S->submitted; });
+  else if (wait >= 2)
+    S->cv_done.wait(lock, [&] { return S->stop || S->error != SICP_OK || S->completed >= want; });
+  int k = 0;
+  while (k < max_results && !S->done.empty()) {
+    results[k++] = S->done.front();
+    S->done.pop_front();
+  }
+  *n_results = k;
+  return S->error;
+}
+
+int sicp_stream_counters(sicp_stream S, int64_t* submitted, int64_t* completed, int64_t* busy_evals, int64_t* slot_evals) {
+  if (!S) return SICP_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lock(S->m);
+  if (submitted) *submitted = S->submitted;
+  if (completed) *completed = S->completed;
+  if (busy_evals) *busy_evals = S->busy_evals;
+  if (slot_evals) *slot_evals = S->slot_evals;
   return SICP_OK;
 }
 

@@ -204,16 +204,20 @@ def lidar_sequence(seed: int = 5, n_scans: int = 7, n_points: int | None = 20000
 
 
 def lidar_sequence_scan(seed: int, i: int, n_points: int | None = 100_000, C: int = 11, n_az: int = 2250, max_range: float = 40.0,
-                        sigma: float = 0.01, label_noise: float = 0.10, step=(1.0, 2.0), wobble: float = 0.15):
+                        sigma: float = 0.01, label_noise: float = 0.10, step=(1.0, 2.0), wobble: float = 0.15, period: int | None = None):
     """Scan `i` of a long KITTI-odometry-like sequence, generated independently of the others (so a
     sequence can be produced by a process pool): the street of `seed`, the sensor of config 2 after
     `i` steps of `step[0]` m forward and `step[1]` deg yaw, modulated per scan by +-`wobble` so that
     consecutive registrations differ in difficulty.  The heading swings between -8 and +8 degrees with a
-    period of 16 scans, which keeps the vehicle inside the 120 m street.  Returns (xyz, labels, world pose 4x4)."""
+    period of 16 scans, which keeps the vehicle inside the 120 m street.  With `period` the vehicle drives
+    `period` steps up the street, the same steps back (in reverse gear), and so on -- a sequence of any
+    length stays inside the street; scans at the same position differ in their noise.
+    Returns (xyz, labels, world pose 4x4)."""
     boxes, poles = _street(np.random.default_rng(seed))
     cm = confusion_matrix(C)
     pose = np.eye(4); pose[:3, 3] = (-40.0, 0.3, 1.73)
-    for j in range(i):
+    n_steps = i if period is None else period - abs(i % (2 * period) - period)
+    for j in range(n_steps):
         r = np.random.default_rng([seed, 7919, j])
         f = 1.0 + wobble * r.uniform(-1, 1)
         yaw = step[1] * (1.0 if (j % 16) < 4 or (j % 16) >= 12 else -1.0)
