@@ -46,7 +46,6 @@ import os
 import socket
 import subprocess
 import sys
-import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -77,7 +76,9 @@ def parse_args():
                     help="independent, distinct scan pairs registered together on each GPU (one handle each; round 1 used 32)")
     ap.add_argument("--same-pair", action="store_true", help="r01 behaviour: every handle of a GPU gets the rank's first pair")
     ap.add_argument("--profile", type=int, default=0, help="SICP_PROFILE_* mask applied inside the timed region")
-    ap.add_argument("--sequence-pairs", type=int, default=128, help="registrations of the end-to-end sequence leg (0 = skip)")
+    ap.add_argument("--sequence-pairs", type=int, default=1024, help="registrations of the open-stream leg (0 = skip)")
+    ap.add_argument("--stream-in-flight", type=int, default=256, help="registrations that share the GPU in the open-stream leg")
+    ap.add_argument("--stream-lm-batch", type=int, default=4, help="LM evaluations per tick in the open-stream leg")
     ap.add_argument("--timed-only", action="store_true", help="skip the other workloads / roofline / CPU legs (for tracing the timed region)")
     ap.add_argument("--dry-run", action="store_true", help="exercise the multi-process plumbing without a GPU")
     ap.add_argument("--oversubscribe", action="store_true",
@@ -170,7 +171,7 @@ def gen_scan(job):
     import synth
 
     seed, i, n = job
-    p, l, pose = synth.lidar_sequence_scan(seed, i, n_points=n)
+    p, l, pose = synth.lidar_sequence_scan(seed, i, n_points=n, period=128)   # 128 steps up the street, 128 back, ...
     return p, l
 
 
@@ -194,7 +195,7 @@ def pool_map(fn, jobs, world):
     import concurrent.futures as cf
     import multiprocessing as mp
 
-    workers = max(1, min(len(jobs), (os.cpu_count() or 1) // max(1, world), 32))
+    workers = max(1, min(len(jobs), (os.cpu_count() or 1) // max(1, world), 64))
     if workers == 1:
         return [fn(j) for j in jobs]
     with cf.ProcessPoolExecutor(workers, mp_context=mp.get_context("fork")) as ex:
@@ -259,86 +260,72 @@ def run_batch_steps(sicp, engines, steps, warmup, sync):
     return time.perf_counter() - t0, agg, per_pair_outer, per_pair_evals, qts
 
 
-def sequence_leg(sicp, device, params, cm, scans, batch, n_points):
-    """Config-5 stand-in: `n_pairs` consecutive registrations of a scan sequence (scan p+1 onto scan p,
-    the loop of exec/kitti_eval.cc:124-249), END TO END: every scan is uploaded once (sicp_set_cloud:
-    H2D + search-tree build), shared as the source of one registration and the target of the next
-    (what setSourceCloud(cloud, kdtree, covs) is for, gicp.h:48-56), its normals / histograms are
-    computed once, and batches of `batch` registrations advance in lock step while a second host
-    thread uploads the next batch's scans."""
+def stream_leg(sicp, device, params, cm, scans, in_flight, lm_batch):
+    """Config-5 stand-in on one GPU: an OPEN stream of len(scans) - 1 consecutive registrations (scan p+1 onto
+    scan p, the loop of exec/kitti_eval.cc:124-249) through sicp_stream_*: every scan is uploaded once by
+    this thread (sicp_stream_add_cloud: copy into pinned memory, H2D and search-tree build queued on the
+    stream's own HIP stream), shared as the source of one registration and the target of the next
+    (setSourceCloud(cloud, kdtree, covs), gicp.h:48-56), its normals / histograms are computed once, and
+    up to `in_flight` registrations share the GPU while the library's worker thread runs the ticks.
+    Timed twice: END TO END (uploads inside the timed region, clouds released as soon as both their
+    registrations are submitted) and ALIGN ONLY (every cloud resident and indexed before the clock starts)."""
     import numpy as np
 
     n_pairs = len(scans) - 1
     p = sicp.SicpParams.from_buffer_copy(params)
-    p.reuse_features = 1
-    n_batches = (n_pairs + batch - 1) // batch
-    sets = [[sicp.Engine(device, p) for _ in range(batch)] for _ in range(2)]
-    for S in sets:
-        for e in S:
-            e.set_confusion(cm)
+    p.lm_batch = lm_batch
+    ident = np.array([0, 0, 0, 1, 0, 0, 0.0])
 
-    def upload(b):
-        E = sets[b % 2]
-        cnt = min(batch, n_pairs - b * batch)
-        for j in range(cnt):
-            k = b * batch + j
-            E[j].set_source(scans[k + 1][0], scans[k + 1][1])
-            if j > 0:
-                E[j].share_cloud(sicp.TARGET, E[j - 1], sicp.SOURCE)
-            elif b == 0:
-                E[0].set_target(scans[0][0], scans[0][1])
+    def run(resident):
+        with sicp.Stream(device, p, max_in_flight=in_flight, confusion=cm) as S:
+            res = []
+            if resident:
+                ids = [S.add_cloud(*sc) for sc in scans]
+                # (a registration of the first and the last scan: when it is back every upload before it has landed)
+                S.submit(ids[-1], ids[0], ident)
+                S.drain()
+                t0 = time.perf_counter()
+                for k in range(n_pairs):
+                    S.submit(ids[k + 1], ids[k], ident)
+                    if k % 64 == 0:
+                        res += S.poll(wait=0)
             else:
-                E[0].share_cloud(sicp.TARGET, sets[(b - 1) % 2][batch - 1], sicp.SOURCE)
-        return E[:cnt]
+                t0 = time.perf_counter()
+                ids = [S.add_cloud(*scans[0])]
+                for k in range(n_pairs):
+                    ids.append(S.add_cloud(*scans[k + 1]))
+                    S.submit(ids[k + 1], ids[k], ident)
+                    if k >= 1:
+                        S.release_cloud(ids[k - 1])
+                    if k % 64 == 0:
+                        res += S.poll(wait=0)
+            res += S.drain()
+            dt = time.perf_counter() - t0
+            c = S.counters()
+        assert len(res) == n_pairs and all(st == 0 for _, st, _, _ in res)
+        res.sort(key=lambda r: r[0])
+        return dt, res, c
 
-    def run(overlap):
-        t_align = 0.0
-        out = []
-        t0 = time.perf_counter()
-        cur = upload(0)
-        t_first_upload = time.perf_counter() - t0
-        for b in range(n_batches):
-            nxt = [None]
-            th = None
-            if b + 1 < n_batches:
-                if overlap:
-                    th = threading.Thread(target=lambda: nxt.__setitem__(0, upload(b + 1)))
-                    th.start()
-            ta = time.perf_counter()
-            res = sicp.align_batch(cur)
-            t_align += time.perf_counter() - ta
-            out += res
-            if b + 1 < n_batches:
-                if th:
-                    th.join()
-                else:
-                    nxt[0] = upload(b + 1)
-                cur = nxt[0]
-        return time.perf_counter() - t0, t_align, t_first_upload, out
-
-    run(True)                                   # warm-up: allocations, graphs, pools
-    t_e2e, _, t_up0, res = run(True)            # pipelined: uploads of batch b+1 beside the aligns of batch b
-    t_serial, t_align_only, _, res2 = run(False)  # uploads and aligns one after the other: align_batch time alone
-    for (qa, _), (qb, _) in zip(res, res2):
-        assert np.array_equal(qa, qb)
-    corr = sum(st["total_corr"] for _, st in res)
-    for S in sets:
-        for e in S:
-            e.close()
+    run(False)                               # warm-up: pools, graphs, allocations
+    t_e2e, res, c_e2e = run(False)
+    t_align, res2, c_al = run(True)
+    for (_, _, qa, _), (_, _, qb, _) in zip(res, res2):
+        assert np.array_equal(qa, qb)       # the same poses whatever a pair shared the GPU with
+    corr = sum(st["total_corr"] for _, _, _, st in res)
     return {
-        "workload": f"scan sequence end to end: {n_pairs} consecutive registrations (scan p+1 onto scan p) of {n_points}-point scans, "
-                    f"EM-ICP K={K_CORR} C={N_CLASSES}; every scan uploaded and indexed once (sicp_set_cloud), shared between its two "
-                    f"registrations, features computed once; lock-step batches of {batch} with the next batch's uploads on a second host thread",
-        "pairs_per_s_end_to_end": n_pairs / t_e2e,
-        "pairs_per_s_align_only": n_pairs / t_align_only,
-        "pairs_per_s_no_overlap": n_pairs / t_serial,
-        "end_to_end_over_align_only": t_e2e / t_align_only,
+        "workload": f"open stream (sicp_stream_*): {n_pairs} consecutive registrations (scan p+1 onto scan p) of {len(scans[0][0])}-point scans, "
+                    f"EM-ICP K={K_CORR} C={N_CLASSES}, {in_flight} in flight, ticks of {lm_batch} LM evaluations; every scan uploaded and indexed once "
+                    "(inside the timed region for the end-to-end figure), shared between its two registrations, features computed once",
+        "pairs": n_pairs,
         "value": corr / t_e2e, "unit": "correspondences/s",
+        "pairs_per_s_end_to_end": n_pairs / t_e2e,
+        "pairs_per_s_align_only": n_pairs / t_align,
+        "end_to_end_over_align_only": t_e2e / t_align,
+        "busy_fraction": c_e2e["busy_fraction"],
+        "busy_fraction_align_only": c_al["busy_fraction"],
         "ms_per_pair_end_to_end": 1e3 * t_e2e / n_pairs,
-        "ms_per_pair_align_only": 1e3 * t_align_only / n_pairs,
-        "ms_per_scan_upload_and_index": 1e3 * (t_serial - t_align_only) / (n_pairs + 1),
-        "first_batch_upload_ms": 1e3 * t_up0,
-        "outer_iters_per_pair": sum(st["outer_iters"] for _, st in res) / n_pairs,
+        "ms_per_pair_align_only": 1e3 * t_align / n_pairs,
+        "outer_iters_per_pair": sum(st["outer_iters"] for _, _, _, st in res) / n_pairs,
     }
 
 
@@ -564,7 +551,7 @@ def main():
                                         "config 3: EM-ICP K=4 C=13 eps=1e-6 (exec/scenenet_eval.cc:174) on the same RGB-D frame pairs"))
         # --- end-to-end sequence (cloud upload + tree build inside the timed region) ------------------
         if scans:
-            others.append(sequence_leg(sicp, device, engine.get_params(), cm, scans, 32, n))
+            others.append(stream_leg(sicp, device, engine.get_params(), cm, scans, args.stream_in_flight, args.stream_lm_batch))
         out["other_workloads"] = others
 
         # --- rooflines (SURVEY.md 8d per-unit bytes x units per launch / HIP-event duration) ----------
