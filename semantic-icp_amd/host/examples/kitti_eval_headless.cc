@@ -11,6 +11,11 @@
 // -r: every scan is read, uploaded and indexed ONCE: the source of pair (n, n+3) stays on the GPU and is
 // the target of pair (n+3, n+6) (setTargetCloudSharedWithSourceOf), and its normals / histograms are
 // kept (keepFeatures) instead of being recomputed by both registrations.  Same rows again.
+// -S <in flight>: the whole sequence as an OPEN STREAM (sicp_stream_*, include/sicp.h): one stream per method,
+// every scan read, uploaded and indexed once, its two registrations submitted as soon as it is there, up to
+// <in flight> registrations sharing the GPU while this thread reads the next files -- no closed batches, no
+// pair waiting for the slowest pair of its batch.  Same rows again (the time column is the run's wall time
+// per pair).
 #include <chrono>
 #include <cstdio>
 #include <fstream>
@@ -18,6 +23,7 @@
 #include <cstdlib>
 #include <iostream>
 #include <memory>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -25,6 +31,56 @@
 #include <gicp.h>
 
 #include "eval_support.h"
+
+namespace {
+
+// one registration method of the experiment as a stream: scans are added once (ids[scan index]), pair
+// (target n, source n + 3) is submitted when both are there, a scan is released after its second submit
+struct MethodStream {
+  sicp_stream s = nullptr;
+  std::vector<int64_t> cloud_of_scan;   // cloud id per file index, 0 = not uploaded
+  std::vector<int64_t> ticket_of_pair;
+  std::vector<sicp_stream_result> result_of_pair;
+  ~MethodStream() { if (s) sicp_stream_destroy(s); }
+  void check(int rc, const char* where) {
+    if (rc != SICP_OK) throw std::runtime_error(std::string(where) + ": " + sicp_strerror(rc) + " " + (s ? sicp_stream_last_error(s) : ""));
+  }
+  void open(int mode, int classes, const double* cm, int in_flight, size_t n_files, size_t n_pairs) {
+    sicp_params p;
+    check(sicp_default_params(mode, &p), "sicp_default_params");
+    p.num_classes = classes;
+    const char* dev = std::getenv("SICP_DEVICE");
+    check(sicp_stream_create(dev ? std::atoi(dev) : 0, &p, in_flight, &s), "sicp_stream_create");
+    if (cm) check(sicp_stream_set_confusion(s, classes, cm), "sicp_stream_set_confusion");
+    cloud_of_scan.assign(n_files, 0);
+    ticket_of_pair.assign(n_pairs, 0);
+    result_of_pair.resize(n_pairs);
+  }
+  template <typename PointT>
+  void add(size_t scan, const pcl::PointCloud<PointT>& c, bool with_labels) {
+    semanticicp::detail::FlatCloud f = semanticicp::detail::flatten(c);
+    check(sicp_stream_add_cloud(s, f.size(), f.x.data(), f.y.data(), f.z.data(), with_labels ? f.label.data() : nullptr, &cloud_of_scan[scan]),
+          "sicp_stream_add_cloud");
+  }
+  void submit(size_t pair, size_t target, size_t source) {
+    const double ident[7] = {0, 0, 0, 1, 0, 0, 0};   // exec/kitti_eval.cc:172-176
+    check(sicp_stream_submit(s, cloud_of_scan[source], cloud_of_scan[target], ident, &ticket_of_pair[pair]), "sicp_stream_submit");
+  }
+  void collect(int wait) {
+    sicp_stream_result r[64];
+    for (;;) {
+      int32_t n = 0;
+      check(sicp_stream_poll(s, wait, 64, r, &n), "sicp_stream_poll");
+      for (int32_t k = 0; k < n; ++k)
+        for (size_t q = 0; q < ticket_of_pair.size(); ++q)
+          if (ticket_of_pair[q] == r[k].ticket) { result_of_pair[q] = r[k]; break; }
+      if (n < 64) break;
+      wait = 0;
+    }
+  }
+};
+
+}  // namespace
 
 int main(int argc, char** argv) {
   using namespace evalsupport;
@@ -44,6 +100,60 @@ int main(int argc, char** argv) {
   KittiMetrics semanticICPMetrics(gtFile, &foutSICP), se3GICPMetrics(gtFile, &foutse3GICP);
   typedef semanticicp::EmIterativeClosestPoint<11> Em;
   typedef semanticicp::GICP<pcl::PointXYZ> Gicp;
+  const char* sarg = arg(argc, argv, "-S");
+  if (sarg) {
+    try {
+      const int in_flight = std::max(1, std::atoi(sarg));
+      std::vector<size_t> starts;
+      for (size_t n = 0; n + 3 < pcd_fns.size(); n += 3) starts.push_back(n);  // exec/kitti_eval.cc:124-129
+      double cmv[121];
+      for (int r = 0; r < 11; ++r)
+        for (int c = 0; c < 11; ++c) cmv[11 * r + c] = cm(r, c);
+      MethodStream em, gi;
+      em.open(SICP_MODE_EM, 11, cmv, in_flight, pcd_fns.size(), starts.size());
+      gi.open(SICP_MODE_GICP, 0, nullptr, in_flight, pcd_fns.size(), starts.size());
+      auto upload = [&](size_t scan) {
+        if (em.cloud_of_scan[scan]) return true;
+        pcl::PointCloud<pcl::PointXYZL>::Ptr cl(new pcl::PointCloud<pcl::PointXYZL>);
+        if (pcl::io::loadPCDFile<pcl::PointXYZL>(pcd_fns[scan], *cl) == -1) return false;
+        filterRange(cl, 40.0);  // :138, :159
+        em.add(scan, *cl, true);
+        // the reference re-loads the files as PointXYZ (:201-204): same points, no labels, no range filter
+        pcl::PointCloud<pcl::PointXYZ>::Ptr raw(new pcl::PointCloud<pcl::PointXYZ>);
+        pcl::io::loadPCDFile<pcl::PointXYZ>(pcd_fns[scan], *raw);
+        gi.add(scan, *raw, false);
+        return true;
+      };
+      const auto begin = std::chrono::steady_clock::now();
+      for (size_t q = 0; q < starts.size(); ++q) {
+        const size_t t = starts[q], sidx = t + 3;
+        if (!upload(t) || !upload(sidx)) { std::cerr << "Couldn't read scan file\n"; return -1; }
+        em.submit(q, t, sidx);
+        gi.submit(q, t, sidx);
+        // scan t has now been the source of pair q - 1 and the target of pair q: the caller is done with it
+        sicp_stream_release_cloud(em.s, em.cloud_of_scan[t]);
+        sicp_stream_release_cloud(gi.s, gi.cloud_of_scan[t]);
+        if (q % 16 == 15) { em.collect(0); gi.collect(0); }
+      }
+      em.collect(2);
+      gi.collect(2);
+      const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - begin).count() / double(std::max<size_t>(1, starts.size()));
+      for (size_t q = 0; q < starts.size(); ++q) {
+        const size_t t = starts[q], sidx = t + 3;
+        if (em.result_of_pair[q].status != SICP_OK || gi.result_of_pair[q].status != SICP_OK)
+          throw std::runtime_error(std::string("registration failed: ") + sicp_strerror(em.result_of_pair[q].status ? em.result_of_pair[q].status : gi.result_of_pair[q].status));
+        const double e1 = semanticICPMetrics.evaluate(semanticicp::detail::to_se3(em.result_of_pair[q].qt), t, sidx, secs, em.result_of_pair[q].outer_iters);
+        const double e2 = se3GICPMetrics.evaluate(semanticicp::detail::to_se3(gi.result_of_pair[q].qt), t, sidx, secs, gi.result_of_pair[q].outer_iters);
+        std::printf("pair %zu<-%zu  SICP MSE %.3e  se3GICP MSE %.3e\n", t, sidx, e1, e2);
+      }
+    } catch (const std::exception& e) {
+      std::cerr << "error: " << e.what() << "\n";
+      return 2;
+    }
+    std::printf("SICP FINAL MSE %.6e rot %.6e trans %.6e\n", semanticICPMetrics.getTransformMSE(), semanticICPMetrics.getRotMSE(), semanticICPMetrics.getTransMSE());
+    std::printf("se3GICP FINAL MSE %.6e rot %.6e trans %.6e\n", se3GICPMetrics.getTransformMSE(), se3GICPMetrics.getRotMSE(), se3GICPMetrics.getTransMSE());
+    return 0;
+  }
   try {
     // one engine per method and batch slot for the whole run: device buffers and the captured solver
     // graphs are reused

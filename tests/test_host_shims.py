@@ -190,6 +190,18 @@ def test_kitti_eval_headless_rows_match_oracle(tmp_path):
                 assert ra[:5] == rb[:5] and ra[6:] == rb[6:]
 
 
+    # -S 4: the whole sequence as an open stream (sicp_stream_*), at most 4 registrations in flight
+    prefix4 = str(tmp_path / "stream_")
+    r4 = subprocess.run([exe, "-s", d, "-t", gt, "-m", cmf, "-o", prefix4, "-S", "4"], capture_output=True, text=True, timeout=900)
+    assert r4.returncode == 0, r4.stderr
+    for fname in ("EMICPkitti.csv", "se3GICPkitti.csv"):
+        one = [line.split(",") for line in open(prefix + fname) if line.strip()]
+        four = [line.split(",") for line in open(prefix4 + fname) if line.strip()]
+        assert len(one) == len(four) == 3
+        for ra, rb in zip(one, four):
+            assert ra[:5] == rb[:5] and ra[6:] == rb[6:]
+
+
 # ------------------------------------------------------------------------------------------------
 # f2: headless scenenet_eval (exec/scenenet_eval.cc:110-250 + exec/scenenet_metrics.h)
 # ------------------------------------------------------------------------------------------------
