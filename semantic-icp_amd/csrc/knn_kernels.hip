@@ -718,10 +718,19 @@ __device__ __forceinline__ void knn_packet_body(const KnnArgs& a, int wg, int n_
     if (a.self) {
       seed_leaf = bid;  // the 16 queries ARE leaf `bid`
     } else {
-      const u64 qc_lane = curve_code_coarse<10>(px, py, pz, a.tree.lo[0], a.tree.lo[1], a.tree.lo[2], a.tree.scale);
-      const u64 qc = ((u64)(unsigned)__builtin_amdgcn_readlane((int)(qc_lane >> 32), 32) << 32) |
-                     (unsigned)__builtin_amdgcn_readlane((int)qc_lane, 32);
-      seed_leaf = locate_leaf(a.tree.leaf_code + a.tree.code_begin, top, qc, lane);
+      // the previous search of these queries, when there is one (outer iterations move the pose little): the
+      // leaf of the middle query's previous nearest neighbour -- one load instead of the curve transform and
+      // the search.  Any leaf is a legal seed; a stale one only costs visits.
+      int prev = -1;
+      if (a.seed_hint) prev = __builtin_amdgcn_readlane(a.seed_hint[(size_t)(a.q_begin + q) * a.hint_K], 32);
+      if (prev >= a.t_begin && prev < a.t_begin + a.tree.n) {
+        seed_leaf = (prev - a.t_begin) / kLeaf;
+      } else {
+        const u64 qc_lane = curve_code_coarse<10>(px, py, pz, a.tree.lo[0], a.tree.lo[1], a.tree.lo[2], a.tree.scale);
+        const u64 qc = ((u64)(unsigned)__builtin_amdgcn_readlane((int)(qc_lane >> 32), 32) << 32) |
+                       (unsigned)__builtin_amdgcn_readlane((int)qc_lane, 32);
+        seed_leaf = locate_leaf(a.tree.leaf_code + a.tree.code_begin, top, qc, lane);
+      }
     }
     seed_leaf = __builtin_amdgcn_readfirstlane(seed_leaf);
     u64 masks = 0;  // 4 sibling bits per level
