@@ -139,7 +139,9 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a) {
   const uint8_t* h = a.hist + (size_t)i * a.C;
   double temp = 0.0;
   for (int r = 0; r < a.C; ++r) temp += a.hval[h[r]] * a.cm[r * a.C + s];
-  a.proj[e] = temp;
+  const int PS = proj_stride(a.C);
+  a.proj[(size_t)i * PS + s] = temp;
+  if (s == 0 && PS != a.C) a.proj[(size_t)i * PS + a.C] = 0.0;  // the padding entry
 }
 
 // The same projection, one LANE PER POINT (C <= PROJ_CMAX): the point's C counts are read once and turned
@@ -152,7 +154,7 @@ __device__ __forceinline__ void proj_rows_body(const ProjArgs& a) {
   __shared__ double s_cm[PROJ_CMAX * PROJ_CMAX];
   __shared__ double s_hval[64];
   __shared__ double s_out[256 * PROJ_CMAX];
-  const int C = a.C;
+  const int C = a.C, PS = proj_stride(C);
   for (int k = threadIdx.x; k < C * C; k += 256) s_cm[k] = a.cm[k];
   for (int k = threadIdx.x; k <= 32; k += 256) s_hval[k] = a.hval[k];  // counts are at most k_cov <= 32 (the buffer carries slack: DevBuf)
   __syncthreads();
@@ -168,12 +170,13 @@ __device__ __forceinline__ void proj_rows_body(const ProjArgs& a) {
 #pragma unroll
       for (int r = 0; r < PROJ_CMAX; ++r)
         if (r < C) temp += hv[r] * s_cm[r * C + s];
-      s_out[threadIdx.x * C + s] = temp;
+      s_out[threadIdx.x * PS + s] = temp;
     }
+    if (PS != C) s_out[threadIdx.x * PS + C] = 0.0;  // the padding entry
   }
   __syncthreads();
-  const int valid = min(256, a.n - i0) * C;
-  double* out = a.proj + (size_t)i0 * C;
+  const int valid = min(256, a.n - i0) * PS;
+  double* out = a.proj + (size_t)i0 * PS;
   for (int k = threadIdx.x; k < valid; k += 256) out[k] = s_out[k];
 }
 
@@ -185,37 +188,99 @@ __global__ __launch_bounds__(256) void proj_jobs_kernel(ProjJobs jobs) { proj_bo
 __global__ __launch_bounds__(256) void proj_rows_kernel(ProjArgs a) { proj_rows_body(a); }
 __global__ __launch_bounds__(256) void proj_rows_jobs_kernel(ProjJobs jobs) { proj_rows_body(jobs.job[blockIdx.y]); }
 
+// GICPCostFunction::Probability as the reference uses it (gicp_cost_function.h:75-87 through em_icp.hpp:108):
+// the density det(2 pi A)^-1/2 exp(-r/2), converted to bool (quirk Q1: 1 unless the product underflows to
+// exactly 0; NaN -> 1).  pow() and exp() cost ~300 instructions to answer a question that is decided long
+// before the last digit: with a sane determinant the product cannot be 0 for r < 1300 (exp(-650) = 5e-283,
+// the power is far above 1e-20) and is exactly 0 for r > 1600 (exp(-800) is below the smallest denormal,
+// the power is finite).  Only the band between them -- and every odd value (NaN, Inf, det <= 0) -- takes
+// the literal formula, so the decision is the reference's for every input.
+__device__ __forceinline__ double geometric_gate(const Corr& c, int bool_probability) {
+  const double two_pi = 6.283185307179586;
+  if (bool_probability) {
+    const bool sane = c.detA > 1e-100 && c.detA < 1e100;
+    if (sane && c.r < 1300.0) return 1.0;
+    if (sane && c.r > 1600.0) return 0.0;
+    const double probability = pow(two_pi * two_pi * two_pi * c.detA, -0.5) * exp(-0.5 * c.r);
+    return (probability != 0.0) ? 1.0 : 0.0;  // quirk Q1: double -> bool (NaN -> true)
+  }
+  return pow(two_pi * two_pi * two_pi * c.detA, -0.5) * exp(-0.5 * c.r);
+}
+
+// one 16-byte piece of a projection row (rows are padded to an even number of doubles: proj_stride)
+typedef double v2d_t __attribute__((ext_vector_type(2)));
+
+// One lane per SOURCE point, its K slots one after the other: the source's record and projection row are
+// read once (they used to be read by each of the K lanes of a lane-per-slot kernel), rows move as 16-byte
+// pieces (half the load instructions of 8-byte ones), the K weights leave as one contiguous run.
+// em_icp.hpp:84-89 with the two dot products of each term taken from the per-point projections:
+// prob = sum_s (t_dist . CM[:, s]) * (s_dist . CM[:, s]), accumulated in ascending s, every product rounded
+// on its own -- the same operations in the same order as before, hence the same bits.
+constexpr int WEIGHT_CMAX = 16;  // classes the register-resident row holds; beyond, the generic kernel below
+template <int K>
+__device__ __forceinline__ void em_weight_rows_body(const WeightArgs& a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n_s) return;
+  const int C = a.C, PS = proj_stride(C), NP = PS / 2;
+  int j[K];
+#pragma unroll
+  for (int c = 0; c < K; ++c) j[c] = a.idx[(size_t)i * K + c];
+  v2d_t ps[WEIGHT_CMAX / 2];
+  const v2d_t* __restrict__ psrc = reinterpret_cast<const v2d_t*>(a.s_proj + (size_t)i * PS);
+#pragma unroll
+  for (int k = 0; k < WEIGHT_CMAX / 2; ++k) ps[k] = k < NP ? psrc[k] : v2d_t{0.0, 0.0};
+  const PointRec sr = a.srec[i];
+  double w[K];
+#pragma unroll
+  for (int c = 0; c < K; ++c) {
+    w[c] = 0.0;
+    if (j[c] >= 0) {
+      const v2d_t* __restrict__ pt = reinterpret_cast<const v2d_t*>(a.t_proj + (size_t)j[c] * PS);
+      v2d_t t[WEIGHT_CMAX / 2];
+#pragma unroll
+      for (int k = 0; k < WEIGHT_CMAX / 2; ++k) t[k] = k < NP ? pt[k] : v2d_t{0.0, 0.0};
+      const PointRec tr = a.trec[j[c]];
+      double prob = 0.0;
+#pragma unroll
+      for (int k = 0; k < WEIGHT_CMAX / 2; ++k) {
+        if (2 * k < C) { double temp = t[k].x; temp *= ps[k].x; prob += temp; }
+        if (2 * k + 1 < C) { double temp = t[k].y; temp *= ps[k].y; prob += temp; }
+      }
+      Corr cr;
+      corr_eval<false>(a.pose, a.one_m_eps, sr.x, sr.y, sr.z, sr.nx, sr.ny, sr.nz, tr.x, tr.y, tr.z, tr.nx, tr.ny, tr.nz, cr);
+      w[c] = prob * geometric_gate(cr, a.bool_probability);  // em_icp.hpp:108
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < K; ++c) a.w[(size_t)i * K + c] = w[c];
+}
+
+// any K and C: one lane per slot
 __device__ __forceinline__ void em_weight_body(const WeightArgs& a) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= a.n_s * a.K) return;
   const int i = e / a.K;
   const int j = a.idx[e];
   if (j < 0) { a.w[e] = 0.0; return; }
-  // em_icp.hpp:84-89 with the two dot products of each term taken from the per-point projections
-  const double* __restrict__ ps = a.s_proj + (size_t)i * a.C;
-  const double* __restrict__ pt = a.t_proj + (size_t)j * a.C;
+  const int PS = proj_stride(a.C);
+  const double* __restrict__ ps = a.s_proj + (size_t)i * PS;
+  const double* __restrict__ pt = a.t_proj + (size_t)j * PS;
   double prob = 0.0;
   for (int s = 0; s < a.C; ++s) {
     double temp = pt[s];
     temp *= ps[s];
     prob += temp;
   }
-  // em_icp.hpp:108 -> gicp_cost_function.h:75-87
   Corr c;
   const PointRec sr = a.srec[i], tr = a.trec[j];
   corr_eval<false>(a.pose, a.one_m_eps, sr.x, sr.y, sr.z, sr.nx, sr.ny, sr.nz, tr.x, tr.y, tr.z, tr.nx, tr.ny, tr.nz, c);
-  const double two_pi = 6.283185307179586;
-  const double probability = pow(two_pi * two_pi * two_pi * c.detA, -0.5) * exp(-0.5 * c.r);
-  if (a.bool_probability) {
-    prob *= (probability != 0.0) ? 1.0 : 0.0;  // quirk Q1: double -> bool (NaN -> true)
-  } else {
-    prob *= probability;
-  }
-  a.w[e] = prob;
+  a.w[e] = prob * geometric_gate(c, a.bool_probability);
 }
 
 __global__ __launch_bounds__(256) void em_weight_kernel(WeightArgs a) { em_weight_body(a); }
 __global__ __launch_bounds__(256) void em_weight_jobs_kernel(WeightJobs jobs) { em_weight_body(jobs.job[blockIdx.y]); }
+__global__ __launch_bounds__(256) void em_weight_rows4_kernel(WeightArgs a) { em_weight_rows_body<4>(a); }
+__global__ __launch_bounds__(256) void em_weight_rows4_jobs_kernel(WeightJobs jobs) { em_weight_rows_body<4>(jobs.job[blockIdx.y]); }
 
 __global__ void transform_float_kernel(int n, const float* x, const float* y, const float* z, Mat4f M,
                                        float* ox, float* oy, float* oz) {
@@ -245,12 +310,11 @@ __global__ __launch_bounds__(256) void fused_label_kernel(WeightArgs a, uint32_t
       Corr cr;
       const PointRec tr = a.trec[j];
       corr_eval<false>(a.pose, a.one_m_eps, sr.x, sr.y, sr.z, sr.nx, sr.ny, sr.nz, tr.x, tr.y, tr.z, tr.nx, tr.ny, tr.nz, cr);
-      const double two_pi = 6.283185307179586;
-      const double probability = pow(two_pi * two_pi * two_pi * cr.detA, -0.5) * exp(-0.5 * cr.r);
-      gprob[c] = a.bool_probability ? ((probability != 0.0) ? 1.0 : 0.0) : probability;
+      gprob[c] = geometric_gate(cr, a.bool_probability);
     }
   }
-  const double* __restrict__ ps = a.s_proj + (size_t)i * a.C;
+  const int PS = proj_stride(a.C);
+  const double* __restrict__ ps = a.s_proj + (size_t)i * PS;
   double max_prob = 0.0;
   int max_s = 0;
   for (int s = 0; s < a.C; ++s) {
@@ -258,7 +322,7 @@ __global__ __launch_bounds__(256) void fused_label_kernel(WeightArgs a, uint32_t
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       if (jj[c] < 0) continue;
-      double temp = a.t_proj[(size_t)jj[c] * a.C + s];
+      double temp = a.t_proj[(size_t)jj[c] * PS + s];
       temp *= ps[s];
       sprob += temp * gprob[c];  // em_icp.hpp:249-253
     }
@@ -297,7 +361,8 @@ hipError_t launch_proj(const ProjArgs& a, hipStream_t st) {
 hipError_t launch_em_weight(const WeightArgs& a, hipStream_t st) {
   const int total = a.n_s * a.K;
   if (total <= 0) return hipSuccess;
-  hipLaunchKernelGGL(em_weight_kernel, dim3((total + 255) / 256), dim3(256), 0, st, a);
+  if (a.K == 4 && a.C <= WEIGHT_CMAX) hipLaunchKernelGGL(em_weight_rows4_kernel, dim3((a.n_s + 255) / 256), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(em_weight_kernel, dim3((total + 255) / 256), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 
@@ -335,10 +400,17 @@ hipError_t launch_em_weight_jobs(const WeightArgs* jobs, int n, hipStream_t st) 
   for (int b = 0; b < n; b += kMaxKnnJobs) {
     const int cnt = n - b < kMaxKnnJobs ? n - b : kMaxKnnJobs;
     WeightJobs J;
-    int mx = 0;
-    for (int i = 0; i < cnt; ++i) { J.job[i] = jobs[b + i]; const int t = jobs[b + i].n_s * jobs[b + i].K; mx = t > mx ? t : mx; }
+    int mx = 0, mx_n = 0;
+    bool rows = true;
+    for (int i = 0; i < cnt; ++i) {
+      J.job[i] = jobs[b + i];
+      const int t = jobs[b + i].n_s * jobs[b + i].K;
+      mx = t > mx ? t : mx; mx_n = jobs[b + i].n_s > mx_n ? jobs[b + i].n_s : mx_n;
+      rows = rows && jobs[b + i].K == 4 && jobs[b + i].C <= WEIGHT_CMAX;
+    }
     if (mx <= 0) continue;
-    hipLaunchKernelGGL(em_weight_jobs_kernel, dim3((mx + 255) / 256, cnt), dim3(256), 0, st, J);
+    if (rows) hipLaunchKernelGGL(em_weight_rows4_jobs_kernel, dim3((mx_n + 255) / 256, cnt), dim3(256), 0, st, J);
+    else hipLaunchKernelGGL(em_weight_jobs_kernel, dim3((mx + 255) / 256, cnt), dim3(256), 0, st, J);
   }
   return hipGetLastError();
 }

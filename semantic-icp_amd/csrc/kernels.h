@@ -143,19 +143,23 @@ struct CovArgs {
   uint8_t* hist;          // [n][C] or nullptr
 };
 
+// rows of the projection arrays are padded to an even number of doubles: 16-byte aligned, read with
+// dwordx4 loads by the weight kernels
+SICP_HD inline int proj_stride(int C) { return (C + 1) & ~1; }
+
 struct ProjArgs {
   int n, C;
   const uint8_t* hist;  // [n][C] neighbour counts
   const double* cm;     // C*C row-major
   const double* hval;   // hval[c] = c additions of 1/k (em_icp.hpp:279,301)
-  double* proj;         // [n][C]
+  double* proj;         // [n][proj_stride(C)]
 };
 
 struct WeightArgs {
   int n_s, K, C;
   const int* idx;
   const PointRec *srec, *trec;
-  const double *s_proj, *t_proj;  // [n][C] label distributions projected through CM (proj_kernel)
+  const double *s_proj, *t_proj;  // [n][proj_stride(C)] label distributions projected through CM (proj_kernel)
   Pose pose;
   double one_m_eps;
   int bool_probability;

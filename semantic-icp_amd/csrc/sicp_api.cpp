@@ -132,7 +132,7 @@ struct Cloud {
   DevBuf<unsigned char> sort_temp;
   DevBuf<sicp::PointRec> rec;  // position + normal of every point (what the weight / accumulate kernels gather)
   DevBuf<uint8_t> hist;
-  DevBuf<double> proj;  // [n][C] label distribution x confusion matrix
+  DevBuf<double> proj;  // [n][proj_stride(C)] label distribution x confusion matrix
   bool proj_valid = false;
   DevBuf<int> nn;
   int nn_stride = 0;  // 0: [n][k]; > 0: [k][nn_stride]
@@ -681,7 +681,7 @@ int ensure_proj(sicp_context* h, Cloud& c) {
   const unsigned long long want_id = h->cm_id * 1099511628211ull + (unsigned long long)P.k_cov;
   if (c.proj_valid && c.proj_cm_id == want_id) return SICP_OK;
   SICPCHECK(ensure_hval(h, P.k_cov));
-  HIPCHECK(c.proj.reserve((size_t)(c.n > 0 ? c.n : 1) * P.num_classes));
+  HIPCHECK(c.proj.reserve((size_t)(c.n > 0 ? c.n : 1) * sicp::proj_stride(P.num_classes)));
   sicp::ProjArgs a;
   a.n = c.n; a.C = P.num_classes;
   a.hist = c.hist.p; a.cm = h->d_cm.p; a.hval = h->d_hval.p; a.proj = c.proj.p;
