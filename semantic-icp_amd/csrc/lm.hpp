@@ -56,15 +56,15 @@ enum { LM_RUNNING = -1, LM_CONVERGED = 0, LM_ITERATION_CAP = 1, LM_INVALID_STEPS
 // the part of the state that changes (what the GPU step keeps in registers) ...
 struct LmCore {
   double pose[7];  // the point whose evaluation lm_feed expects next
+  int status;      // LM_* (next to the pose: the accumulate kernel reads both, one cache line)
+  int pad_;
   double x[7];     // last accepted iterate (the answer when status != LM_RUNNING)
   double H[36], g[6], cost, x_norm;
   double scale[6], diag[6];
   double radius, decrease_factor, model_change;
   int reuse_diagonal, invalid, iterations, evaluations;
   int phase;   // 0: pose == x (first evaluation), 1: pose is a candidate step
-  int status;  // LM_*
   int pending; // chained device solve: an evaluation at `pose` has been accumulated but not fed yet
-  int pad_;
 };
 
 // ... and the whole state: the options stay in memory (uniform: scalar loads on the GPU)

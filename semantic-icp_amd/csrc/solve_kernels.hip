@@ -707,12 +707,17 @@ __global__ __launch_bounds__(REDUCE_THREADS) void lm_step_batch_kernel(const Bat
   if ((int)blockIdx.x >= hdr->n_pairs) return;
   const BatchArgs& B = batch[blockIdx.x];
   LmState* lm = B.a.lm_step;
-  if (lm->status != LM_RUNNING) return;
+  // One pair alone is a chain of ~120 (accumulate, LM step) launches, so every dependent memory round trip
+  // in here is paid ~120 times: the state (thread 0) and the status are requested BEFORE the reduction's own
+  // loads and arrive while it runs, instead of status -> partial columns -> state one after the other.
+  LmCore st;
+  if (threadIdx.x == 0) st = *lm;  // the options stay in memory: uniform, read with scalar loads
+  const int status = lm->status;
   __shared__ double s_part[4][28];
   double o[28];
   reduce_partials_block(B.a.partials, B.nb, s_part, o);
+  if (status != LM_RUNNING) return;  // (uniform; a finished pair's partial columns are read for nothing: 44 KB)
   if (threadIdx.x == 0) {
-    LmCore st = *lm;  // the options stay in memory: uniform, read with scalar loads
     lm_feed(st, lm->opt, o);
     *static_cast<LmCore*>(lm) = st;
   }
