@@ -242,6 +242,11 @@ int accumulate_blocks(int total, int K);  // chunks of a pair with `total` slots
 // every pair of the batch in one launch: hdr / batch in HBM, capacity = slots of the batch buffers
 hipError_t launch_accumulate_batch(int K, int use_sqloss, const BatchHeader* hdr, const BatchArgs* batch, int capacity, hipStream_t st);
 hipError_t launch_lm_step_batch(const BatchHeader* hdr, const BatchArgs* batch, int capacity, hipStream_t st);
+// one pair alone: the whole inner solve of batch[0] in one persistent launch (one workgroup per chunk); its partials
+// buffer holds TWO sets of columns, sync = max_evals + 1 words (word 0 is raised when a device-wide wait timed out)
+bool solve_one_fits(int total_slots, int K);
+hipError_t launch_solve_one(int K, int use_sqloss, const BatchArgs* batch, int n_chunks, unsigned* sync, int max_evals, hipStream_t st);
+constexpr int kSoloMaxEvals = 1024;
 hipError_t launch_finalize_batch(const BatchArgs* batch, int n, double* out28, hipStream_t st);
 // pairs that start an inner solve with the next tick: their LM states are initialised ON the device from
 // one small upload (states[j.pair] = lm_init(j.opt, j.start)) instead of one 800-byte copy per pair

@@ -280,6 +280,8 @@ struct sicp_context {
   // state per pair, pinned mirrors, and the captured [accumulate_batch, lm_step_batch] x lm_batch graph
   TickSet ts[2];  // two sets: the halves of a batch alternate, one's tick runs while the host turns the other around
   DevBuf<sicp::LmState> d_bstates;
+  DevBuf<unsigned> d_solo_sync;       // one pair alone: arrival counters of the persistent solve (solve_one_kernel)
+  unsigned* h_solo_abort = nullptr;   // pinned: its abort word, read back with the state
   DevBuf<double> d_bout28;
   sicp::LmState* h_bstates = nullptr;
   double* h_bout28 = nullptr;
@@ -843,7 +845,7 @@ void fill_acc(sicp_context* h, sicp::AccArgs& a) {
 const int kMaxActivePairs = [] { const char* e = std::getenv("SICP_MAX_ACTIVE"); const int v = e ? std::atoi(e) : 256; return std::min(std::max(v, 1), 512); }();
 int batch_reserve(sicp_context* h, int n);
 int run_tick(sicp_context* h, hipStream_t M, sicp_handle* hs, int n, const std::vector<int>& act, const std::vector<int>& joining,
-             const double (*start)[7], int len);
+             const double (*start)[7], int len, bool solo);
 
 // One evaluation sweep at pose qt: the batched kernel on a batch of one (every path -- a pair alone, a
 // lock-step batch, the host-loop solve, this hook -- runs the SAME accumulate kernel, so they agree bit
@@ -923,10 +925,11 @@ int run_solve(sicp_context* h, const double* init_qt, double* out_qt, SolveResul
   double start[1][7];
   std::memcpy(start[0], init_qt, sizeof start[0]);
   std::vector<int> act(1, 0), joining(1, 0);
+  const bool solo = P.lm_on_device == 1 && sicp::solve_one_fits(h->corr_n * h->corr_K, h->corr_K);
   for (;;) {
-    SICPCHECK(run_tick(h, h->stream, &self, 1, act, joining, start, len));
+    SICPCHECK(run_tick(h, h->stream, &self, 1, act, joining, start, len, solo));
     joining.clear();
-    h->st.acc_launches += len;
+    h->st.acc_launches += solo ? 1 : len;
     if (h->h_bstates[0].status != sicp::LM_RUNNING) break;
   }
   const sicp::LmState& s = h->h_bstates[0];
@@ -1135,7 +1138,7 @@ struct BatchGuard {
 // and uploaded first).  tick_launch only queues work on stream M (ending with the read-back of the
 // states of pairs [lo, hi) into h_bstates); the caller synchronises M when it wants the result.
 int tick_launch(sicp_context* h, TickSet& S, hipStream_t M, sicp_handle* hs, int lo, int hi, const std::vector<int>& act,
-                const std::vector<int>& joining, const double (*start)[7], int len) {
+                const std::vector<int>& joining, const double (*start)[7], int len, bool solo = false) {
   if (!joining.empty()) {  // their LM states are initialised on the device: one upload + one tiny kernel
     int k = 0;
     for (int p : joining) {
@@ -1156,7 +1159,7 @@ int tick_launch(sicp_context* h, TickSet& S, hipStream_t M, sicp_handle* hs, int
     sicp::BatchArgs& B = S.h_batch[k++];
     std::memset(&B, 0, sizeof B);
     const int nb = sicp::accumulate_blocks(g->corr_n * g->corr_K, g->corr_K);
-    if (g->partials.reserve((size_t)nb * 28) != hipSuccess) return SICP_ERR_OUT_OF_MEMORY;
+    if (g->partials.reserve((size_t)nb * 28 * (solo ? 2 : 1)) != hipSuccess) return SICP_ERR_OUT_OF_MEMORY;  // (solo: two sets of columns)
     fill_acc(g, B.a);
     B.a.lm = B.a.lm_step = h->d_bstates.p + p;
     B.nb = nb;
@@ -1167,6 +1170,18 @@ int tick_launch(sicp_context* h, TickSet& S, hipStream_t M, sicp_handle* hs, int
     HIPCHECK(hipMemcpyAsync(S.d_batch.p, S.h_batch, sizeof(sicp::BatchArgs) * act.size(), hipMemcpyHostToDevice, M));
     S.tick_act = act;
     S.tick_valid = true;
+  }
+  if (solo) {
+    // ONE pair alone: its whole inner solve as one persistent launch (solve_kernels.hip: solve_one_kernel) -- one
+    // device-wide wait per evaluation instead of two kernel boundaries, one host look per solve instead of per tick
+    sicp_context* g = hs[act[0]];
+    HIPCHECK(h->d_solo_sync.reserve((size_t)sicp::kSoloMaxEvals + 1));
+    if (!h->h_solo_abort) HIPCHECK(hipHostMalloc((void**)&h->h_solo_abort, sizeof(unsigned), hipHostMallocDefault));
+    HIPCHECK(sicp::launch_solve_one(g->corr_K, h->params.use_sqloss, S.d_batch.p, sicp::accumulate_blocks(g->corr_n * g->corr_K, g->corr_K),
+                                    h->d_solo_sync.p, sicp::kSoloMaxEvals, M));
+    HIPCHECK(hipMemcpyAsync(h->h_solo_abort, h->d_solo_sync.p, sizeof(unsigned), hipMemcpyDeviceToHost, M));
+    HIPCHECK(hipMemcpyAsync(h->h_bstates + lo, h->d_bstates.p + lo, sizeof(sicp::LmState) * (hi - lo), hipMemcpyDeviceToHost, M));
+    return SICP_OK;
   }
   // [accumulate, lm_step_batch] x len as an explicit graph with fixed grids: the kernels read the
   // number of pairs from the header and their status from the LM states, so the graph is instantiated once per tick set
@@ -1189,10 +1204,19 @@ int tick_wait(sicp_context* h, hipStream_t M) {
   return SICP_OK;
 }
 
+int solo_check(sicp_context* h) {
+  if (h->h_solo_abort && *h->h_solo_abort != 0u) {
+    h->last_error = "solve_one_kernel: a device-wide wait timed out (the grid was not resident)";
+    return SICP_ERR_HIP;
+  }
+  return SICP_OK;
+}
+
 int run_tick(sicp_context* h, hipStream_t M, sicp_handle* hs, int n, const std::vector<int>& act, const std::vector<int>& joining,
-             const double (*start)[7], int len) {
-  SICPCHECK(tick_launch(h, h->ts[0], M, hs, 0, n, act, joining, start, len));
+             const double (*start)[7], int len, bool solo) {
+  SICPCHECK(tick_launch(h, h->ts[0], M, hs, 0, n, act, joining, start, len, solo));
   SICPCHECK(tick_wait(h, M));
+  if (solo) SICPCHECK(solo_check(h));
   return SICP_OK;
 }
 
@@ -1234,11 +1258,14 @@ struct BatchRun {
   sicp_params P;                // what every pair of the run agrees on (same_solver)
   int len = 8;                  // LM evaluations per tick
   bool one_launch = true, want_stats = false;
+  bool solo = false;            // a run of ONE pair: an inner solve is one persistent launch (when its chunks fit the chip)
   hipStream_t side = nullptr;   // searches / features of the pairs between two inner solves
   struct Start { double q[7]; };
   std::vector<OuterState> o;
   std::vector<int> phase, search_round;
   std::vector<Start> starts;
+  bool solo_now = false;  // the tick in flight is a persistent solve
+  int solo_seen = 0;      // evaluations of the running solve already counted
   void resize(int slots) {
     n = slots;
     o.assign(slots, OuterState());
@@ -1269,11 +1296,14 @@ int BatchRun::turn(TickGroup& G, JobCollector& jc) {
     SICPCHECK(tick_wait(h, G.M));
     G.pending = false;
     G.finished.clear();
+    if (solo_now) SICPCHECK(solo_check(h));
     for (int p : G.act) {
       sicp_context* g = hs[p];
-      g->st.lockstep_slots += len;
-      g->st.acc_launches += len;
       const sicp::LmState& st = h->h_bstates[p];
+      // evaluation launches the pair sat through: the tick's, or -- one persistent launch -- its own evaluations
+      g->st.lockstep_slots += solo_now ? st.evaluations - solo_seen : len;
+      g->st.acc_launches += solo_now ? 1 : len;
+      if (solo_now) solo_seen = st.status == sicp::LM_RUNNING ? st.evaluations : 0;
       if (st.status == sicp::LM_RUNNING) continue;
       std::memcpy(o[p].est, st.x, sizeof st.x);
       g->st.total_lm_iters += st.iterations;
@@ -1336,7 +1366,8 @@ int BatchRun::turn(TickGroup& G, JobCollector& jc) {
   // the tick reads its pairs' arguments in ascending slot order (the order of the argument array)
   std::sort(G.act.begin(), G.act.end());
   for (int p : G.joining) { phase[p] = PAIR_SOLVING; std::memcpy(starts[p].q, o[p].est, sizeof starts[p].q); }
-  int rc = tick_launch(h, *G.S, G.M, hs, G.lo, G.hi, G.act, G.joining, reinterpret_cast<const double(*)[7]>(starts.data()), len);
+  solo_now = solo && G.act.size() == 1 && sicp::solve_one_fits(hs[G.act[0]]->corr_n * hs[G.act[0]]->corr_K, hs[G.act[0]]->corr_K);
+  int rc = tick_launch(h, *G.S, G.M, hs, G.lo, G.hi, G.act, G.joining, reinterpret_cast<const double(*)[7]>(starts.data()), len, solo_now);
   if (rc != SICP_OK) return rc;
   G.pending = true;
   return SICP_OK;
@@ -1461,6 +1492,7 @@ int sicp_destroy(sicp_handle h) {
   }
   if (h->h_bstates) (void)hipHostFree(h->h_bstates);
   if (h->h_bout28) (void)hipHostFree(h->h_bout28);
+  if (h->h_solo_abort) (void)hipHostFree(h->h_solo_abort);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
@@ -1699,6 +1731,7 @@ int sicp_align_batch(sicp_handle* hs, int32_t n, const double* init_qt, double* 
   }
   BatchRun run;
   run.L = L; run.hs = hs; run.P = P; run.one_launch = one_launch; run.want_stats = stats != nullptr;
+  run.solo = n == 1 && one_launch && P.lm_on_device == 1;
   run.resize(n);
   for (int p = 0; p < n; ++p) run.start_pair(p, init_qt + 7 * p);
   // Tick length: lm_batch evaluations; twice that for up to 4 pairs, where the host's turn-around between

@@ -27,11 +27,17 @@
 #include "fast_log.hpp"
 
 namespace sicp {
+// The float64 arithmetic of an evaluation is written with EXPLICIT fused multiply-adds (the file is compiled
+// with -ffp-contract=off): the same source then is the same instruction sequence in every kernel that inlines
+// it -- the batched kernel and the persistent one-pair solve agree bit for bit by construction.  (With
+// `#pragma clang fp contract(fast)` each instantiation picks its own FMA pairs: round 2 saw a second kernel
+// over the same chunks differ in the last bits.)
+#define FMA(a, b, c) __builtin_fma((a), (b), (c))
+
 __device__ __forceinline__ double rcp_newton(double d) {
-#pragma clang fp contract(fast)
   double r = __builtin_amdgcn_rcp(d);
-  r = r + r * (1.0 - d * r);
-  r = r + r * (1.0 - d * r);
+  r = FMA(r, FMA(-d, r, 1.0), r);
+  r = FMA(r, FMA(-d, r, 1.0), r);
   return r;
 }
 
@@ -43,14 +49,13 @@ struct SrcTerms {
 };
 
 __device__ __forceinline__ void src_terms(const Pose& P, double psx, double psy, double psz, double nsx, double nsy, double nsz, SrcTerms& s) {
-#pragma clang fp contract(fast)
   const double* R = P.R;
-  s.qx = R[0] * psx + R[1] * psy + R[2] * psz + P.t[0];
-  s.qy = R[3] * psx + R[4] * psy + R[5] * psz + P.t[1];
-  s.qz = R[6] * psx + R[7] * psy + R[8] * psz + P.t[2];
-  s.mx = R[0] * nsx + R[1] * nsy + R[2] * nsz;
-  s.my = R[3] * nsx + R[4] * nsy + R[5] * nsz;
-  s.mz = R[6] * nsx + R[7] * nsy + R[8] * nsz;
+  s.qx = FMA(R[2], psz, FMA(R[1], psy, FMA(R[0], psx, P.t[0])));
+  s.qy = FMA(R[5], psz, FMA(R[4], psy, FMA(R[3], psx, P.t[1])));
+  s.qz = FMA(R[8], psz, FMA(R[7], psy, FMA(R[6], psx, P.t[2])));
+  s.mx = FMA(R[2], nsz, FMA(R[1], nsy, R[0] * nsx));
+  s.my = FMA(R[5], nsz, FMA(R[4], nsy, R[3] * nsx));
+  s.mz = FMA(R[8], nsz, FMA(R[7], nsy, R[6] * nsx));
 }
 
 // residual r = res^T A^-1 res and its local Jacobian for one correspondence (gicp_cost_function.h:27-73
@@ -69,39 +74,37 @@ __device__ __forceinline__ void src_terms(const Pose& P, double psx, double psy,
 __device__ __forceinline__ void corr_eval_src(const Pose& P, double one_m_eps, double gw, const SrcTerms& s, double psx, double psy,
                                               double psz, double nsx, double nsy, double nsz, double ptx, double pty,
                                               double ptz, double ntx, double nty, double ntz, Corr& o) {
-#pragma clang fp contract(fast)
   const double* R = P.R;
   const double rx = ptx - s.qx, ry = pty - s.qy, rz = ptz - s.qz;
-  const double al = ntx * rx + nty * ry + ntz * rz;
-  const double be = s.mx * rx + s.my * ry + s.mz * rz;
-  const double d = ntx * s.mx + nty * s.my + ntz * s.mz;
+  const double al = FMA(ntz, rz, FMA(nty, ry, ntx * rx));
+  const double be = FMA(s.mz, rz, FMA(s.my, ry, s.mx * rx));
+  const double d = FMA(ntz, s.mz, FMA(nty, s.my, ntx * s.mx));
   // Everything from here to the Jacobian is carried at TWICE its value (a2 = 2 a, b2 = 2 b: the factors 1/2 of
   // A^-1 are never applied), and powers of two are exact: J = 2 [-b; b x c] = [-b2; b2 x c] comes out
   // unscaled, r = res . a = 1/2 res . a2 costs one multiplication by 1/2.
   const double h = rcp_newton((gw - d) * (gw + d));  // (gw - d)(gw + d) in [~4 eps, ~(2/k)^2]
-  const double ga = h * (gw * al + d * be), de = h * (d * al + gw * be);
-  const double ax = rx + ga * ntx + de * s.mx;
-  const double ay = ry + ga * nty + de * s.my;
-  const double az = rz + ga * ntz + de * s.mz;
-  o.r = 0.5 * (rx * ax + ry * ay + rz * az);
-  const double bx = R[0] * ax + R[3] * ay + R[6] * az;  // b2 = R^T a2
-  const double by = R[1] * ax + R[4] * ay + R[7] * az;
-  const double bz = R[2] * ax + R[5] * ay + R[8] * az;
+  const double ga = h * FMA(d, be, gw * al), de = h * FMA(gw, be, d * al);
+  const double ax = FMA(de, s.mx, FMA(ga, ntx, rx));
+  const double ay = FMA(de, s.my, FMA(ga, nty, ry));
+  const double az = FMA(de, s.mz, FMA(ga, ntz, rz));
+  o.r = 0.5 * FMA(rz, az, FMA(ry, ay, rx * ax));
+  const double bx = FMA(R[6], az, FMA(R[3], ay, R[0] * ax));  // b2 = R^T a2
+  const double by = FMA(R[7], az, FMA(R[4], ay, R[1] * ax));
+  const double bz = FMA(R[8], az, FMA(R[5], ay, R[2] * ax));
   // b x c with c = p_s + C_s b = p_s + b - (1-eps)(n_s . b) n_s: b x b = 0, so c may leave out its b
-  const double nb = (0.5 * one_m_eps) * (nsx * bx + nsy * by + nsz * bz);
-  const double cx = psx - nb * nsx;
-  const double cy = psy - nb * nsy;
-  const double cz = psz - nb * nsz;
+  const double nb = (0.5 * one_m_eps) * FMA(nsz, bz, FMA(nsy, by, nsx * bx));
+  const double cx = FMA(-nb, nsx, psx);
+  const double cy = FMA(-nb, nsy, psy);
+  const double cz = FMA(-nb, nsz, psz);
   o.J[0] = -bx; o.J[1] = -by; o.J[2] = -bz;
-  o.J[3] = by * cz - bz * cy;
-  o.J[4] = bz * cx - bx * cz;
-  o.J[5] = bx * cy - by * cx;
+  o.J[3] = FMA(by, cz, -(bz * cy));
+  o.J[4] = FMA(bz, cx, -(bx * cz));
+  o.J[5] = FMA(bx, cy, -(by * cx));
 }
 
 // g = sqrt(v) and h = 1 / (2 sqrt(v)) together, for v > 0: v_rsq_f64 and two Goldschmidt steps (9
 // instructions; a library rsqrt plus the two products is 12 and needs the special-case compares)
 __device__ __forceinline__ void sqrt_and_half_rsqrt(double v, double& g, double& h) {
-#pragma clang fp contract(fast)
   const double y = __builtin_amdgcn_rsq(v);
   g = v * y;
   h = 0.5 * y;
@@ -120,15 +123,14 @@ __device__ __forceinline__ void sqrt_and_half_rsqrt(double v, double& g, double&
 // which the caller evaluates for all slots of a group together (log_group below).
 template <bool SQLOSS>
 __device__ __forceinline__ void loss_rho1(double c, double s, double w, double& sum, double& rho1) {
-#pragma clang fp contract(fast)
   if (SQLOSS) {
     const double v = s + 2.220446049250313e-16;  // std::numeric_limits<double>::epsilon()
     double g0, g1;
     sqrt_and_half_rsqrt(v, g0, g1);
-    sum = 1.0 + g0 * c;
+    sum = FMA(g0, c, 1.0);
     rho1 = (w * fmax(2.2250738585072014e-308, rcp_newton(sum))) * g1;
   } else {
-    sum = 1.0 + s * c;
+    sum = FMA(s, c, 1.0);
     rho1 = fmax(2.2250738585072014e-308, rcp_newton(sum));
   }
 }
@@ -294,7 +296,6 @@ __device__ __forceinline__ void compute_group(const MathCtx& M, const Group<K>& 
   for (int c = 0; c < SG; ++c) w[c] = G.j[c] < 0 ? 0.0 : G.w[c];
 #pragma unroll
   for (int c = 0; c < SG; ++c) {
-#pragma clang fp contract(fast)
     const int s = NS == 1 ? 0 : c / (SG / NS);
     if (c % (SG / NS) == 0) src_terms(M.P, G.sx[s], G.sy[s], G.sz[s], G.snx[s], G.sny[s], G.snz[s], st);
     Corr cr;
@@ -308,18 +309,15 @@ __device__ __forceinline__ void compute_group(const MathCtx& M, const Group<K>& 
     for (int p = 0; p < 6; ++p) {
       const double jp = rho1 * cr.J[p];
 #pragma unroll
-      for (int q = p; q < 6; ++q) acc[o++] += jp * cr.J[q];
-      acc[21 + p] += jp * cr.r;
+      for (int q = p; q < 6; ++q, ++o) acc[o] = FMA(jp, cr.J[q], acc[o]);
+      acc[21 + p] = FMA(jp, cr.r, acc[21 + p]);
     }
   }
   // cost = 1/2 sum rho0, rho0 = w b log(sum) (w = 1 without SQLoss: semantic_icp.hpp:96 has no ScaledLoss)
   double lg[SG];
   log_group<SG>(M.log_table, sum, lg);
 #pragma unroll
-  for (int c = 0; c < SG; ++c) {
-#pragma clang fp contract(fast)
-    acc[27] += (0.5 * w[c]) * (M.loss_b * lg[c]);
-  }
+  for (int c = 0; c < SG; ++c) acc[27] = FMA(0.5 * w[c], M.loss_b * lg[c], acc[27]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -448,6 +446,127 @@ __device__ __forceinline__ void wave_reduce(const double (&acc)[28], SICP_LDS do
   }
 }
 
+// One SEGMENT: chunks [chunk_lo, chunk_lo + n_here) of one pair, evaluated by the calling workgroup at the pose
+// in M; their 28 sums go to columns chunk_lo ... of partials[28][n_chunks].  The one routine both the batched
+// kernel and the persistent one-pair solve run, so a chunk's sums are the same bits in either.
+template <int K, bool SQLOSS, int BS>
+__device__ __forceinline__ void accumulate_segment(const LoadCtx& L, const MathCtx& M, int chunk_lo, int n_here, int n_chunks, int steps, int chunk_groups,
+                                                   SICP_GLOBAL double* partials, SICP_LDS char* stage, SICP_LDS double* tile,
+                                                   double (&comb)[COMB_CHUNKS][BS / 64][28], int lane, int wave) {
+  constexpr int SG = GroupShape<K>::SG, NS = GroupShape<K>::NS;
+  const int nsteps = n_here * steps;
+  const int last = ((L.total - 1) / SG) * SG;
+  double acc[28];
+#pragma unroll
+  for (int k = 0; k < 28; ++k) acc[k] = 0.0;
+  // Two sets of the register-borne part alternate as "current" and "next" (the step below is
+  // instantiated twice with the roles swapped): a copy `current = next` would be scheduled into the
+  // arithmetic and wait there for the very loads it is meant to overlap.
+  GroupRegs<K> R0, R1;
+  int g = chunk_lo * chunk_groups + (int)threadIdx.x;  // this lane's group; + BS per step
+  int t = 0, in_chunk = 0, chunk = chunk_lo, parked = 0;  // parked: chunks whose wave sums sit in comb[]
+  // join the four waves' sums of the parked chunks [chunk - parked, chunk) -> their columns.  Raw barriers:
+  // a __syncthreads would also wait for the LDS-DMA / loads in flight.
+  auto flush_parked = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int e = threadIdx.x; e < parked * 28; e += BS) {
+      const int c = e / 28, k = e - 28 * c;
+      partials[(size_t)k * n_chunks + (chunk - parked + c)] = (comb[c][0][k] + comb[c][1][k]) + (comb[c][2][k] + comb[c][3][k]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    parked = 0;
+  };
+  auto issue_targets = [&](const int (&j)[SG]) {
+#pragma unroll
+#if defined(SICP_DEBUG_NOGATHER)  // developer aid: every gather reads target 0 (results are wrong)
+    for (int c = 0; c < SG; ++c) lds_dma_rec(L.trec + (max(j[c], 0) & 0), stage + c * STAGE_SLOT_BYTES);
+#else
+    for (int c = 0; c < SG; ++c) lds_dma_rec(L.trec + max(j[c], 0), stage + c * STAGE_SLOT_BYTES);
+#endif
+  };
+  // fill: indices of the first two groups, then targets / weights / source of the first
+  load_idx_raw<K>(L, g, R0.j);
+  load_idx_raw<K>(L, g + BS, R1.j);
+  fix_idx<K>(L.total, g, R0.j);
+  issue_targets(R0.j);
+  load_regs<K>(L, last, g, R0);
+
+  auto step = [&](GroupRegs<K>& cur, GroupRegs<K>& nxt) -> bool {
+    // (A) everything issued a step ago has landed.  The empty asm statements "use" every register a
+    // load of the previous step wrote: hipcc places its own (conservative, vmcnt(0)) wait for them
+    // here, where nothing is in flight, instead of at their first arithmetic use below -- where it
+    // would drain the loads issued in (B).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int c = 0; c < SG; ++c) { asm volatile("" : "+v"(cur.w[c]), "+v"(nxt.j[c])); }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      asm volatile("" : "+v"(cur.sx[s]), "+v"(cur.sy[s]), "+v"(cur.sz[s]), "+v"(cur.snx[s]), "+v"(cur.sny[s]), "+v"(cur.snz[s]));
+    }
+    Group<K> Gc;
+#pragma unroll
+    for (int c = 0; c < SG; ++c) {
+      Gc.j[c] = cur.j[c]; Gc.w[c] = cur.w[c];
+      lds_read_rec(stage + c * STAGE_SLOT_BYTES, lane, Gc.tx[c], Gc.ty[c], Gc.tz[c], Gc.tnx[c], Gc.tny[c], Gc.tnz[c]);
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { Gc.sx[s] = cur.sx[s]; Gc.sy[s] = cur.sy[s]; Gc.sz[s] = cur.sz[s]; Gc.snx[s] = cur.snx[s]; Gc.sny[s] = cur.sny[s]; Gc.snz[s] = cur.snz[s]; }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the staging area may be overwritten
+    // (B) the next group's traffic, and the indices of the group after it.  Unconditional: a load
+    // under a branch merges with the "not taken" value in a register copy, which is a use of the load
+    // -- the compiler would wait for it right here.  Past the end of the segment the fetch is target
+    // 0 of dead slots, and is never computed.
+    const bool more = t + 1 < nsteps;
+    fix_idx<K>(more ? L.total : 0, g + BS, nxt.j);
+    issue_targets(nxt.j);
+    load_regs<K>(L, last, g + BS, nxt);
+    load_idx_raw<K>(L, g + 2 * BS, cur.j);
+    // nothing of (B) may sink into the arithmetic: left alone, the scheduler issues the source-record
+    // and index loads half way through / near the end of the step (shorter live ranges), which leaves
+    // them a fraction of a step to land before (A) of the next step waits for them
+    __builtin_amdgcn_sched_barrier(0);
+    // (C) the arithmetic of the current group
+#if defined(SICP_DEBUG_NOCOMPUTE)  // developer aid: the memory pipeline alone (every loaded value is consumed once)
+#pragma unroll
+    for (int c = 0; c < SG; ++c) acc[c] += (double)(Gc.tx[c] + Gc.ty[c] + Gc.tz[c]) + Gc.tnx[c] + Gc.tny[c] + Gc.tnz[c] + Gc.w[c] + (double)Gc.j[c];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) acc[8 + s] += (double)(Gc.sx[s] + Gc.sy[s] + Gc.sz[s]) + Gc.snx[s] + Gc.sny[s] + Gc.snz[s];
+#else
+    compute_group<K, SQLOSS>(M, Gc, acc);
+#endif
+    if (++in_chunk == steps) {  // the chunk is complete
+#if defined(SICP_DEBUG_NOREDUCE)  // developer aid: no LDS transpose / DPP, all 28 sums stay live
+      {
+        double chk = 0.0;
+#pragma unroll
+        for (int k = 0; k < 28; ++k) chk += acc[k];
+        if (chk == 1.2345e300) partials[chunk] = chk;
+      }
+#else
+      wave_reduce(acc, tile, (SICP_LDS double*)&comb[parked][wave][0], lane);
+#endif
+#pragma unroll
+      for (int k = 0; k < 28; ++k) acc[k] = 0.0;
+      in_chunk = 0;
+      ++chunk;
+#if !defined(SICP_DEBUG_NOREDUCE)
+      if (++parked == COMB_CHUNKS || t + 1 == nsteps) flush_parked();
+#endif
+    }
+#if !defined(SICP_DEBUG_NOSTREAM)  // developer aid: with it, every step re-reads the segment's first groups (cache hits)
+    g += BS;
+#endif
+    ++t;
+    return more;
+  };
+  for (;;) {
+    if (!step(R0, R1)) break;
+    if (!step(R1, R0)) break;
+  }
+}
+
 template <int K, bool SQLOSS, int BS>
 __global__ __launch_bounds__(BS, SICP_ACC_OCC) void accumulate_staged_kernel(const BatchHeader* __restrict__ hdr, const BatchArgs* __restrict__ batch) {
   constexpr int SG = GroupShape<K>::SG, NS = GroupShape<K>::NS, NW = BS / 64;
@@ -500,14 +619,6 @@ __global__ __launch_bounds__(BS, SICP_ACC_OCC) void accumulate_staged_kernel(con
   SICP_LDS char* stage = (SICP_LDS char*)stage_all + wave * (SG * STAGE_SLOT_BYTES);
   SICP_LDS double* tile = (SICP_LDS double*)smem + wave * (RED_ROWS * RED_STRIDE);
 
-  double acc[28];
-#pragma unroll
-  for (int k = 0; k < 28; ++k) acc[k] = 0.0;
-  // Two sets of the register-borne part alternate as "current" and "next" (the step below is
-  // instantiated twice with the roles swapped): a copy `current = next` would be scheduled into the
-  // arithmetic and wait there for the very loads it is meant to overlap.
-  GroupRegs<K> R0, R1;
-
   while (item < item_end) {
     // the pair this item belongs to: the last one that begins at or before it (always a running one)
     int lo = 0, hi = n_pairs - 1;
@@ -529,8 +640,6 @@ __global__ __launch_bounds__(BS, SICP_ACC_OCC) void accumulate_staged_kernel(con
     const AccGeometry geo = acc_geometry(L.total, SG);
     const int n_chunks = uniform_i32(geo.n_chunks), steps = uniform_i32(geo.steps);
     const int n_here = min(n_chunks - chunk_lo, item_end - item);
-    const int nsteps = n_here * steps;
-    const int last = ((L.total - 1) / SG) * SG;
     SICP_GLOBAL double* partials = (SICP_GLOBAL double*)uniform_ptr(a.partials);
     MathCtx M;
     {
@@ -551,108 +660,7 @@ __global__ __launch_bounds__(BS, SICP_ACC_OCC) void accumulate_staged_kernel(con
       M.log_table = (unsigned)uniform_i32((int)(unsigned)(unsigned long)(SICP_LDS char*)log_tab);
     }
 
-    int g = chunk_lo * uniform_i32(geo.chunk_groups) + (int)threadIdx.x;  // this lane's group; + BS per step
-    int t = 0, in_chunk = 0, chunk = chunk_lo, parked = 0;  // parked: chunks whose wave sums sit in comb[]
-    // join the four waves' sums of the parked chunks [chunk - parked, chunk) -> their columns.  Raw barriers:
-    // a __syncthreads would also wait for the LDS-DMA / loads in flight.
-    auto flush_parked = [&]() {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      for (int e = threadIdx.x; e < parked * 28; e += BS) {
-        const int c = e / 28, k = e - 28 * c;
-        partials[(size_t)k * n_chunks + (chunk - parked + c)] = (comb[c][0][k] + comb[c][1][k]) + (comb[c][2][k] + comb[c][3][k]);
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      parked = 0;
-    };
-    auto issue_targets = [&](const int (&j)[SG]) {
-#pragma unroll
-#if defined(SICP_DEBUG_NOGATHER)  // developer aid: every gather reads target 0 (results are wrong)
-      for (int c = 0; c < SG; ++c) lds_dma_rec(L.trec + (max(j[c], 0) & 0), stage + c * STAGE_SLOT_BYTES);
-#else
-      for (int c = 0; c < SG; ++c) lds_dma_rec(L.trec + max(j[c], 0), stage + c * STAGE_SLOT_BYTES);
-#endif
-    };
-    // fill: indices of the first two groups, then targets / weights / source of the first
-    load_idx_raw<K>(L, g, R0.j);
-    load_idx_raw<K>(L, g + BS, R1.j);
-    fix_idx<K>(L.total, g, R0.j);
-    issue_targets(R0.j);
-    load_regs<K>(L, last, g, R0);
-
-    auto step = [&](GroupRegs<K>& cur, GroupRegs<K>& nxt) -> bool {
-      // (A) everything issued a step ago has landed.  The empty asm statements "use" every register a
-      // load of the previous step wrote: hipcc places its own (conservative, vmcnt(0)) wait for them
-      // here, where nothing is in flight, instead of at their first arithmetic use below -- where it
-      // would drain the loads issued in (B).
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int c = 0; c < SG; ++c) { asm volatile("" : "+v"(cur.w[c]), "+v"(nxt.j[c])); }
-#pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        asm volatile("" : "+v"(cur.sx[s]), "+v"(cur.sy[s]), "+v"(cur.sz[s]), "+v"(cur.snx[s]), "+v"(cur.sny[s]), "+v"(cur.snz[s]));
-      }
-      Group<K> Gc;
-#pragma unroll
-      for (int c = 0; c < SG; ++c) {
-        Gc.j[c] = cur.j[c]; Gc.w[c] = cur.w[c];
-        lds_read_rec(stage + c * STAGE_SLOT_BYTES, lane, Gc.tx[c], Gc.ty[c], Gc.tz[c], Gc.tnx[c], Gc.tny[c], Gc.tnz[c]);
-      }
-#pragma unroll
-      for (int s = 0; s < NS; ++s) { Gc.sx[s] = cur.sx[s]; Gc.sy[s] = cur.sy[s]; Gc.sz[s] = cur.sz[s]; Gc.snx[s] = cur.snx[s]; Gc.sny[s] = cur.sny[s]; Gc.snz[s] = cur.snz[s]; }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the staging area may be overwritten
-      // (B) the next group's traffic, and the indices of the group after it.  Unconditional: a load
-      // under a branch merges with the "not taken" value in a register copy, which is a use of the load
-      // -- the compiler would wait for it right here.  Past the end of the segment the fetch is target
-      // 0 of dead slots, and is never computed.
-      const bool more = t + 1 < nsteps;
-      fix_idx<K>(more ? L.total : 0, g + BS, nxt.j);
-      issue_targets(nxt.j);
-      load_regs<K>(L, last, g + BS, nxt);
-      load_idx_raw<K>(L, g + 2 * BS, cur.j);
-      // nothing of (B) may sink into the arithmetic: left alone, the scheduler issues the source-record
-      // and index loads half way through / near the end of the step (shorter live ranges), which leaves
-      // them a fraction of a step to land before (A) of the next step waits for them
-      __builtin_amdgcn_sched_barrier(0);
-      // (C) the arithmetic of the current group
-#if defined(SICP_DEBUG_NOCOMPUTE)  // developer aid: the memory pipeline alone (every loaded value is consumed once)
-#pragma unroll
-      for (int c = 0; c < SG; ++c) acc[c] += (double)(Gc.tx[c] + Gc.ty[c] + Gc.tz[c]) + Gc.tnx[c] + Gc.tny[c] + Gc.tnz[c] + Gc.w[c] + (double)Gc.j[c];
-#pragma unroll
-      for (int s = 0; s < NS; ++s) acc[8 + s] += (double)(Gc.sx[s] + Gc.sy[s] + Gc.sz[s]) + Gc.snx[s] + Gc.sny[s] + Gc.snz[s];
-#else
-      compute_group<K, SQLOSS>(M, Gc, acc);
-#endif
-      if (++in_chunk == steps) {  // the chunk is complete
-#if defined(SICP_DEBUG_NOREDUCE)  // developer aid: no LDS transpose / DPP, all 28 sums stay live
-        {
-          double chk = 0.0;
-#pragma unroll
-          for (int k = 0; k < 28; ++k) chk += acc[k];
-          if (chk == 1.2345e300) partials[chunk] = chk;
-        }
-#else
-        wave_reduce(acc, tile, (SICP_LDS double*)&comb[parked][wave][0], lane);
-#endif
-#pragma unroll
-        for (int k = 0; k < 28; ++k) acc[k] = 0.0;
-        in_chunk = 0;
-        ++chunk;
-#if !defined(SICP_DEBUG_NOREDUCE)
-        if (++parked == COMB_CHUNKS || t + 1 == nsteps) flush_parked();
-#endif
-      }
-#if !defined(SICP_DEBUG_NOSTREAM)  // developer aid: with it, every step re-reads the segment's first groups (cache hits)
-      g += BS;
-#endif
-      ++t;
-      return more;
-    };
-    for (;;) {
-      if (!step(R0, R1)) break;
-      if (!step(R1, R0)) break;
-    }
+    accumulate_segment<K, SQLOSS, BS>(L, M, chunk_lo, n_here, n_chunks, steps, uniform_i32(geo.chunk_groups), partials, stage, tile, comb, lane, wave);
     item += n_here;
   }
 }
@@ -731,6 +739,124 @@ __global__ __launch_bounds__(REDUCE_THREADS) void lm_step_batch_kernel(const Bat
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// One pair alone: the whole inner solve in ONE launch.
+//
+// A pair alone is a chain of ~120 evaluations, and as [accumulate launch, LM-step launch] each costs two launch
+// boundaries (a no-op launch of either kernel is 4-4.5 us) on top of its work.  Here workgroup b owns chunk b for
+// the whole solve (grid = the pair's chunks, all resident: one per CU) and an evaluation is
+//     accumulate chunk b at the current pose (accumulate_segment: the batched kernel's routine, same bits)
+//  -> column b of partials[e & 1]  -> arrive on counter e (agent-scope release)  -> wait for all (relaxed
+//     poll by one lane, one agent-scope acquire)
+//  -> EVERY workgroup sums the columns (reduce_partials_block: the LM-step kernel's routine) and advances ITS
+//     OWN copy of the trust-region state with lm_feed: same inputs, same code, same state everywhere -- no
+//     second hand-off for the new pose.  Workgroup 0 writes the state back at the end.
+// One device-wide wait per evaluation instead of two kernel boundaries, the state never leaves registers, and
+// the host looks once per inner solve.  Hand-off protocol: cdna_hip_programming.md guideline 16 (plain payload
+// stores -> every storing wave drains -> barrier -> one lane: release fence, drain, relaxed agent atomic;
+// consumer: relaxed poll, ONE acquire fence, barrier, plain loads); one counter per evaluation (zeroed by a
+// memset ahead of the launch), partial columns double-buffered by the evaluation's parity (a workgroup can be
+// at most one evaluation ahead of another).  Every spin is bounded: on a timeout the abort word is raised, every
+// workgroup leaves, and the host reports an error instead of waiting for a grid that is not resident.
+// ------------------------------------------------------------------------------------------
+constexpr int kSoloSpinLimit = 1 << 22;  // polls (with s_sleep) before a wait gives up: ~1 s
+
+template <int K, bool SQLOSS, int BS>
+__global__ __launch_bounds__(BS, 1) void solve_one_kernel(const BatchArgs* __restrict__ batch, unsigned* __restrict__ sync, int max_evals) {
+  constexpr int SG = GroupShape<K>::SG, NW = BS / 64;
+  extern __shared__ __attribute__((aligned(16))) double smem[];  // [reduction tiles | staging | logarithm table]
+  __shared__ double comb[COMB_CHUNKS][NW][28];
+  __shared__ double s_part[4][28];
+  __shared__ double s_pose[7];
+  __shared__ int s_status, s_abort;
+  char* stage_all = reinterpret_cast<char*>(smem + NW * RED_ROWS * RED_STRIDE);
+  char* log_tab = stage_all + NW * SG * STAGE_SLOT_BYTES;
+  for (int k = threadIdx.x; k < kLogTableEntries; k += BS) reinterpret_cast<v2d*>(log_tab)[k] = reinterpret_cast<const v2d*>(kLogTable)[k];
+  const int lane = threadIdx.x & 63, wave = uniform_i32((int)(threadIdx.x >> 6));
+  const AccArgs& a = batch[0].a;
+  LoadCtx L;
+  L.idx = (const SICP_GLOBAL int*)uniform_ptr(a.idx);
+  L.w = (const SICP_GLOBAL double*)uniform_ptr(a.w);
+  L.srec = (const SICP_GLOBAL PointRec*)uniform_ptr(a.srec);
+  L.trec = (const SICP_GLOBAL PointRec*)uniform_ptr(a.trec);
+  L.n_s = uniform_i32(a.n_s);
+  L.total = uniform_i32(a.n_s * a.K);
+  const AccGeometry geo = acc_geometry(L.total, SG);
+  const int n_chunks = uniform_i32(geo.n_chunks), steps = uniform_i32(geo.steps), chunk_groups = uniform_i32(geo.chunk_groups);
+  if (n_chunks != (int)gridDim.x) return;  // (the host launches one workgroup per chunk)
+  SICP_GLOBAL double* partials = (SICP_GLOBAL double*)uniform_ptr(a.partials);
+  LmState* lm = a.lm_step;
+  MathCtx M;
+  {
+    const double loss_b = a.loss.cauchy_a * a.loss.cauchy_a;
+    M.one_m_eps = uniform_f64(a.one_m_eps); M.loss_b = uniform_f64(loss_b); M.loss_c = uniform_f64(1.0 / loss_b);
+    M.gw = uniform_f64(2.0 / a.one_m_eps - 1.0);
+    M.log_table = (unsigned)uniform_i32((int)(unsigned)(unsigned long)(SICP_LDS char*)log_tab);
+  }
+  SICP_LDS char* stage = (SICP_LDS char*)stage_all + wave * (SG * STAGE_SLOT_BYTES);
+  SICP_LDS double* tile = (SICP_LDS double*)smem + wave * (RED_ROWS * RED_STRIDE);
+  // every workgroup keeps the trust-region state in the registers of its thread 0
+  LmCore st;
+  if (threadIdx.x == 0) {
+    st = *lm;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) s_pose[k] = st.pose[k];
+    s_status = st.status;
+    s_abort = 0;
+  }
+  __syncthreads();
+  unsigned* const abort_word = sync;       // sync[0]: raised when a wait timed out
+  unsigned* const arrivals = sync + 1;     // sync[1 + e]: workgroups that have written evaluation e's column
+  for (int e = 0; e < max_evals; ++e) {
+    if (s_status != LM_RUNNING) break;
+    {
+      double pose[7], R[9];
+#pragma unroll
+      for (int k = 0; k < 7; ++k) pose[k] = s_pose[k];
+      se3::rotation(pose, R);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) M.P.R[k] = uniform_f64(R[k]);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) M.P.t[k] = uniform_f64(pose[4 + k]);
+    }
+    SICP_GLOBAL double* col = partials + (size_t)(e & 1) * 28 * n_chunks;
+    accumulate_segment<K, SQLOSS, BS>(L, M, (int)blockIdx.x, 1, n_chunks, steps, chunk_groups, col, stage, tile, comb, lane, wave);
+    // ---- publish this workgroup's column, wait for everybody's
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its column stores
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_fetch_add(&arrivals[e], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int spins = 0;
+      bool bad = false;
+      while (__hip_atomic_load(&arrivals[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > kSoloSpinLimit || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+          __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          bad = true;
+          break;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      if (bad) s_abort = 1;
+    }
+    __syncthreads();
+    if (s_abort) return;
+    // ---- every workgroup: the 28 sums, and the step of its own copy of the state
+    double o[28];
+    reduce_partials_block((const double*)col, n_chunks, s_part, o);
+    if (threadIdx.x == 0) {
+      lm_feed(st, lm->opt, o);
+#pragma unroll
+      for (int k = 0; k < 7; ++k) s_pose[k] = st.pose[k];
+      s_status = st.status;
+    }
+    __syncthreads();
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) *static_cast<LmCore*>(lm) = st;
+}
+
 __global__ __launch_bounds__(REDUCE_THREADS) void finalize_batch_kernel(const BatchArgs* __restrict__ batch, double* out28) {
   const BatchArgs& B = batch[blockIdx.x];
   __shared__ double s_part[4][28];
@@ -802,6 +928,36 @@ hipError_t launch_accumulate_batch(int K, int use_sqloss, const BatchHeader* hdr
   if (!fn) return hipErrorInvalidValue;
   void* args[] = {(void*)&hdr, (void*)&batch};
   return hipLaunchKernel(fn, dim3(accumulate_grid()), dim3(256), args, stream_smem_bytes(capacity, K), st);
+}
+
+static size_t solo_smem_bytes(int K) {
+  const size_t staging = (size_t)4 * acc_slots_per_group(K) * STAGE_SLOT_BYTES;
+  return sizeof(double) * 4 * RED_ROWS * RED_STRIDE + staging + LOG_TABLE_BYTES;
+}
+
+// whether a pair of `total` slots can run as one persistent solve: one workgroup per chunk, all of them resident
+bool solve_one_fits(int total, int K) {
+  static const int cus = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+  }();
+  static const bool off = getenv("SICP_NO_SOLO") != nullptr;  // developer switch: always the [accumulate, LM step] graph
+  return !off && total > 0 && accumulate_blocks(total, K) <= cus;
+}
+
+hipError_t launch_solve_one(int K, int use_sqloss, const BatchArgs* batch, int n_chunks, unsigned* sync, int max_evals, hipStream_t st) {
+  void* fn = nullptr;
+  switch (K) {
+    case 1: fn = use_sqloss ? (void*)solve_one_kernel<1, true, 256> : (void*)solve_one_kernel<1, false, 256>; break;
+    case 4: fn = use_sqloss ? (void*)solve_one_kernel<4, true, 256> : (void*)solve_one_kernel<4, false, 256>; break;
+    case 20: fn = use_sqloss ? (void*)solve_one_kernel<20, true, 256> : (void*)solve_one_kernel<20, false, 256>; break;
+    default: return hipErrorInvalidValue;
+  }
+  hipError_t e = hipMemsetAsync(sync, 0, sizeof(unsigned) * (size_t)(max_evals + 1), st);
+  if (e != hipSuccess) return e;
+  void* args[] = {(void*)&batch, (void*)&sync, (void*)&max_evals};
+  return hipLaunchKernel(fn, dim3(n_chunks), dim3(256), args, solo_smem_bytes(K), st);
 }
 
 hipError_t launch_lm_step_batch(const BatchHeader* hdr, const BatchArgs* batch, int capacity, hipStream_t st) {

@@ -1,6 +1,8 @@
 #!/bin/bash
 # usage (GPU box): tools/profile_bench.sh <prefix>
-# rocprofv3 --kernel-trace --stats of the DEFAULT bench command (CPU leg off), the per-kernel statistics csv,
+# rocprofv3 --kernel-trace --stats of the default bench command with the CPU leg and the open-stream leg off (on the
+# full default command rocprofv3 itself died with a segmentation fault in round 3; the open-stream leg, which adds a
+# worker thread, is the new element -- not investigated further), the per-kernel statistics csv,
 # and a summary of the accumulate launches that separates the roofline legs of bench.py -- the LAST 60 launches
 # of accumulate_staged_kernel<4, true, 256> are its 256-pair leg (6 x 10 launches), the 300 before them its
 # 32-pair leg (6 x 50): the launches bench.py brackets with HIP events -- from the launches of the timed
@@ -9,7 +11,7 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 pre=$1
 rm -rf /tmp/pb_prof
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb_prof -- python3 bench.py --no-cpu-baseline \
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb_prof -- python3 bench.py --no-cpu-baseline --sequence-pairs 0 \
   > gpurun_out/${pre}_bench_under_rocprof.json 2> /tmp/pb_prof.err
 f=$(find /tmp/pb_prof -name '*kernel_stats.csv' | head -1)
 t=$(find /tmp/pb_prof -name '*kernel_trace.csv' | head -1)
