@@ -925,7 +925,7 @@ int run_solve(sicp_context* h, const double* init_qt, double* out_qt, SolveResul
   double start[1][7];
   std::memcpy(start[0], init_qt, sizeof start[0]);
   std::vector<int> act(1, 0), joining(1, 0);
-  const bool solo = P.lm_on_device == 1 && sicp::solve_one_fits(h->corr_n * h->corr_K, h->corr_K);
+  const bool solo = P.lm_on_device == 3 && sicp::solve_one_fits(h->corr_n * h->corr_K, h->corr_K);
   for (;;) {
     SICPCHECK(run_tick(h, h->stream, &self, 1, act, joining, start, len, solo));
     joining.clear();
@@ -1175,7 +1175,7 @@ int tick_launch(sicp_context* h, TickSet& S, hipStream_t M, sicp_handle* hs, int
     // ONE pair alone: its whole inner solve as one persistent launch (solve_kernels.hip: solve_one_kernel) -- one
     // device-wide wait per evaluation instead of two kernel boundaries, one host look per solve instead of per tick
     sicp_context* g = hs[act[0]];
-    HIPCHECK(h->d_solo_sync.reserve((size_t)sicp::kSoloMaxEvals + 1));
+    HIPCHECK(h->d_solo_sync.reserve((size_t)sicp::kSoloMaxEvals + 1 + 16));  // (+ the phase timers of a -DSICP_SOLO_TIMING build)
     if (!h->h_solo_abort) HIPCHECK(hipHostMalloc((void**)&h->h_solo_abort, sizeof(unsigned), hipHostMallocDefault));
     HIPCHECK(sicp::launch_solve_one(g->corr_K, h->params.use_sqloss, S.d_batch.p, sicp::accumulate_blocks(g->corr_n * g->corr_K, g->corr_K),
                                     h->d_solo_sync.p, sicp::kSoloMaxEvals, M));
@@ -1205,6 +1205,18 @@ int tick_wait(sicp_context* h, hipStream_t M) {
 }
 
 int solo_check(sicp_context* h) {
+#if defined(SICP_SOLO_TIMING)  // developer aid: cycles per phase of workgroup 0, per evaluation of the solve that just ended
+  {
+    unsigned w[10];
+    if (hipMemcpy(w, h->d_solo_sync.p + sicp::kSoloMaxEvals + 1, sizeof w, hipMemcpyDeviceToHost) == hipSuccess) {
+      const int ev = std::max(1, h->h_bstates[0].evaluations);
+      const char* nm[5] = {"accumulate", "publish", "wait", "reduce", "lm_feed"};
+      std::fprintf(stderr, "[solo timing] %d evaluations, cycles per evaluation:", ev);
+      for (int i = 0; i < 5; ++i) std::fprintf(stderr, " %s %.0f", nm[i], (double)(((unsigned long long)w[2 * i + 1] << 32) | w[2 * i]) / ev);
+      std::fprintf(stderr, "\n");
+    }
+  }
+#endif
   if (h->h_solo_abort && *h->h_solo_abort != 0u) {
     h->last_error = "solve_one_kernel: a device-wide wait timed out (the grid was not resident)";
     return SICP_ERR_HIP;
@@ -1731,7 +1743,7 @@ int sicp_align_batch(sicp_handle* hs, int32_t n, const double* init_qt, double* 
   }
   BatchRun run;
   run.L = L; run.hs = hs; run.P = P; run.one_launch = one_launch; run.want_stats = stats != nullptr;
-  run.solo = n == 1 && one_launch && P.lm_on_device == 1;
+  run.solo = n == 1 && one_launch && P.lm_on_device == 3;
   run.resize(n);
   for (int p = 0; p < n; ++p) run.start_pair(p, init_qt + 7 * p);
   // Tick length: lm_batch evaluations; twice that for up to 4 pairs, where the host's turn-around between

@@ -807,8 +807,17 @@ __global__ __launch_bounds__(BS, 1) void solve_one_kernel(const BatchArgs* __res
   __syncthreads();
   unsigned* const abort_word = sync;       // sync[0]: raised when a wait timed out
   unsigned* const arrivals = sync + 1;     // sync[1 + e]: workgroups that have written evaluation e's column
+#if defined(SICP_SOLO_TIMING)  // developer aid: cycles of workgroup 0 per phase, summed over the evaluations -> sync[max_evals + 1 ...]
+  unsigned long long tm[5] = {0, 0, 0, 0, 0}, tprev = 0;
+#define SOLO_MARK(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); tm[i] += now_ - tprev; tprev = now_; } while (0)
+#else
+#define SOLO_MARK(i) do { } while (0)
+#endif
   for (int e = 0; e < max_evals; ++e) {
     if (s_status != LM_RUNNING) break;
+#if defined(SICP_SOLO_TIMING)
+    tprev = __builtin_readcyclecounter();
+#endif
     {
       double pose[7], R[9];
 #pragma unroll
@@ -821,6 +830,7 @@ __global__ __launch_bounds__(BS, 1) void solve_one_kernel(const BatchArgs* __res
     }
     SICP_GLOBAL double* col = partials + (size_t)(e & 1) * 28 * n_chunks;
     accumulate_segment<K, SQLOSS, BS>(L, M, (int)blockIdx.x, 1, n_chunks, steps, chunk_groups, col, stage, tile, comb, lane, wave);
+    SOLO_MARK(0);
     // ---- publish this workgroup's column, wait for everybody's
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its column stores
     __syncthreads();
@@ -828,6 +838,7 @@ __global__ __launch_bounds__(BS, 1) void solve_one_kernel(const BatchArgs* __res
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __hip_atomic_fetch_add(&arrivals[e], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      SOLO_MARK(1);
       int spins = 0;
       bool bad = false;
       while (__hip_atomic_load(&arrivals[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
@@ -843,9 +854,11 @@ __global__ __launch_bounds__(BS, 1) void solve_one_kernel(const BatchArgs* __res
     }
     __syncthreads();
     if (s_abort) return;
+    SOLO_MARK(2);
     // ---- every workgroup: the 28 sums, and the step of its own copy of the state
     double o[28];
     reduce_partials_block((const double*)col, n_chunks, s_part, o);
+    SOLO_MARK(3);
     if (threadIdx.x == 0) {
       lm_feed(st, lm->opt, o);
 #pragma unroll
@@ -853,8 +866,13 @@ __global__ __launch_bounds__(BS, 1) void solve_one_kernel(const BatchArgs* __res
       s_status = st.status;
     }
     __syncthreads();
+    SOLO_MARK(4);
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) *static_cast<LmCore*>(lm) = st;
+#if defined(SICP_SOLO_TIMING)
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (int i = 0; i < 5; ++i) { sync[max_evals + 1 + 2 * i] = (unsigned)tm[i]; sync[max_evals + 2 + 2 * i] = (unsigned)(tm[i] >> 32); }
+#endif
 }
 
 __global__ __launch_bounds__(REDUCE_THREADS) void finalize_batch_kernel(const BatchArgs* __restrict__ batch, double* out28) {
