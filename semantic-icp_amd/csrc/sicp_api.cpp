@@ -288,6 +288,8 @@ struct sicp_context {
   int h_batch_cap = 0;  // capacity of the per-pair state mirrors (h_bstates, h_bout28)
   hipStream_t side_stream = nullptr;  // batch leader: searches of the pairs between two inner solves
   hipEvent_t side_done = nullptr, side_done2 = nullptr, main_done = nullptr;
+  hipStream_t feat_stream = nullptr;          // batch leader: the start-up pipelines (features + first search) of a large batch
+  std::vector<hipEvent_t> chunk_ev;           // one per start-up chunk
   hipStream_t part_stream[kParts] = {};
   hipEvent_t part_fork = nullptr, part_done[kParts] = {};
   // a slot of a registration stream: an upload that is still in flight (queued by the submitting thread on
@@ -1250,7 +1252,9 @@ int count_active(sicp_context* h) {
 // inside an inner solve, while the searches of the pairs that have just finished one run on a second
 // stream beside it; those pairs rejoin at the next tick.  No pair waits for another pair's solve or outer
 // loop -- only for the end of the current tick.
-enum { PAIR_FREE = -1, PAIR_NEED_SEARCH = 0, PAIR_JOINING, PAIR_SOLVING, PAIR_DONE };
+// PAIR_FIRST: the pair's start-up pipeline (features, first search, weights) is queued on the start-up stream; it joins
+// the ticks when the event of its chunk has completed
+enum { PAIR_FREE = -1, PAIR_NEED_SEARCH = 0, PAIR_JOINING, PAIR_SOLVING, PAIR_DONE, PAIR_FIRST };
 
 // pairs [lo, hi) that advance together: one tick stream, one argument set
 struct TickGroup {
@@ -1278,12 +1282,34 @@ struct BatchRun {
   std::vector<Start> starts;
   bool solo_now = false;  // the tick in flight is a persistent solve
   int solo_seen = 0;      // evaluations of the running solve already counted
+  std::vector<int> first_chunk;        // PAIR_FIRST: the start-up chunk the pair belongs to
+  std::vector<hipEvent_t> chunk_ev;    // recorded behind each chunk's start-up pipeline
+  // pairs whose start-up pipeline has completed join the ticks; with `block` the host waits for the first chunk
+  // that is still running (nothing else is left to do)
+  int promote_started(const TickGroup& G, bool block) {
+    int waiting = 0, promoted = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+      waiting = promoted = 0;
+      int first_unfinished = -1;
+      for (int p = G.lo; p < G.hi; ++p) {
+        if (phase[p] != PAIR_FIRST) continue;
+        const hipError_t q = hipEventQuery(chunk_ev[first_chunk[p]]);
+        if (q == hipSuccess) { phase[p] = PAIR_JOINING; search_round[p] = 0; ++promoted; }
+        else if (q == hipErrorNotReady) { ++waiting; if (first_unfinished < 0) first_unfinished = first_chunk[p]; }
+        else return -1;
+      }
+      if (promoted || !block || first_unfinished < 0) break;
+      if (hipEventSynchronize(chunk_ev[first_unfinished]) != hipSuccess) return -1;
+    }
+    return waiting;
+  }
   void resize(int slots) {
     n = slots;
     o.assign(slots, OuterState());
     phase.assign(slots, PAIR_FREE);
     search_round.assign(slots, 0);
     starts.assign(slots, Start());
+    first_chunk.assign(slots, 0);
   }
   // pair p starts its align() at init_qt (its handle's align_begin has run)
   void start_pair(int p, const double* init_qt) {
@@ -1294,7 +1320,7 @@ struct BatchRun {
   }
   int live(const TickGroup& G) const {
     int k = 0;
-    for (int p = G.lo; p < G.hi; ++p) k += phase[p] == PAIR_NEED_SEARCH || phase[p] == PAIR_JOINING || phase[p] == PAIR_SOLVING;
+    for (int p = G.lo; p < G.hi; ++p) k += phase[p] == PAIR_NEED_SEARCH || phase[p] == PAIR_JOINING || phase[p] == PAIR_SOLVING || phase[p] == PAIR_FIRST;
     return k;
   }
   int turn(TickGroup& G, JobCollector& jc);
@@ -1332,6 +1358,12 @@ int BatchRun::turn(TickGroup& G, JobCollector& jc) {
     if (want_stats && one_launch && !G.finished.empty()) SICPCHECK(flush_jobs(h, jc, side));  // counts: same stream, ahead of the searches
   }
   if (live(G) == 0) return SICP_OK;
+  if (!chunk_ev.empty()) {
+    // nothing in flight and nobody ready: wait for the next start-up chunk instead of spinning
+    bool idle = !G.pending;
+    for (int p = G.lo; p < G.hi && idle; ++p) idle = phase[p] != PAIR_NEED_SEARCH && phase[p] != PAIR_JOINING && phase[p] != PAIR_SOLVING;
+    if (promote_started(G, idle) < 0) { h->last_error = "start-up pipeline: event query failed"; return SICP_ERR_HIP; }
+  }
   ++G.round;
   // (1) searches of the pairs between two inner solves -> side stream
   bool any_search = false;
@@ -1512,6 +1544,8 @@ int sicp_destroy(sicp_handle h) {
   if (h->side_done2) (void)hipEventDestroy(h->side_done2);
   if (h->main_done) (void)hipEventDestroy(h->main_done);
   if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
+  if (h->feat_stream) (void)hipStreamDestroy(h->feat_stream);
+  for (hipEvent_t e : h->chunk_ev) (void)hipEventDestroy(e);
   if (h->part_fork) (void)hipEventDestroy(h->part_fork);
   for (int s = 1; s < kParts; ++s) {
     if (h->part_done[s]) (void)hipEventDestroy(h->part_done[s]);
@@ -1710,19 +1744,28 @@ int sicp_align_batch(sicp_handle* hs, int32_t n, const double* init_qt, double* 
   JobCollector jc;
   BatchGuard guard(hs, n, one_launch ? &jc : nullptr, L->stream);
   const unsigned long long epoch = next_epoch();
-  for (int p = 0; p < n; ++p) {
-    hs[p]->epoch = epoch;
-    jc.slice = batch_slice(p, n, P.knn);
-    SICPCHECK(align_begin(hs[p], stats != nullptr));
-  }
-  if (one_launch) {
-    SICPCHECK(flush_jobs(L, jc));
-  } else {
-    // per-pair launches on the pairs' own streams: a cloud shared by two pairs has just been given
-    // its features on ONE of them
+  // A large batch starts PIPELINED: the per-align features (self-searches, covariances, projections) and the first
+  // search + weights of the pairs are queued chunk by chunk on a stream of their own, and a chunk's pairs join the
+  // ticks as soon as its event has completed -- the solves of the first pairs run beside the features of the later
+  // ones instead of ~50 ms of features for all 512 clouds before the first tick.  The GPU is work-bound, so this only
+  // fills the ramp: 2.09 -> 2.12 G corr/s at 256 pairs (chunks of 8 ... 32 alike, 64 and more lose it again).
+  const bool staged = one_launch && n > 48;
+  static const int kStartChunk = [] { const char* e = std::getenv("SICP_START_CHUNK"); const int v = e ? std::atoi(e) : 32; return v > 0 ? v : 32; }();  // tuning aid
+  if (!staged) {  // (a staged batch queues its start-up pipelines below, once the run exists)
     for (int p = 0; p < n; ++p) {
-      sicp_context* h = hs[p];
-      HIPCHECK(hipStreamSynchronize(h->stream));
+      hs[p]->epoch = epoch;
+      jc.slice = batch_slice(p, n, P.knn);
+      SICPCHECK(align_begin(hs[p], stats != nullptr));
+    }
+    if (one_launch) {
+      SICPCHECK(flush_jobs(L, jc));
+    } else {
+      // per-pair launches on the pairs' own streams: a cloud shared by two pairs has just been given
+      // its features on ONE of them
+      for (int p = 0; p < n; ++p) {
+        sicp_context* h = hs[p];
+        HIPCHECK(hipStreamSynchronize(h->stream));
+      }
     }
   }
   // ---- the outer loops of all pairs, CONTINUOUSLY batched.  Every pair runs its own sequence
@@ -1746,6 +1789,38 @@ int sicp_align_batch(sicp_handle* hs, int32_t n, const double* init_qt, double* 
   run.solo = n == 1 && one_launch && P.lm_on_device == 3;
   run.resize(n);
   for (int p = 0; p < n; ++p) run.start_pair(p, init_qt + 7 * p);
+  if (staged) {
+    sicp_context* h = L;
+    if (!h->feat_stream) HIPCHECK(hipStreamCreateWithFlags(&h->feat_stream, hipStreamNonBlocking));
+    const int n_chunks = (n + kStartChunk - 1) / kStartChunk;
+    while ((int)h->chunk_ev.size() < n_chunks) {
+      hipEvent_t e = nullptr;
+      HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      h->chunk_ev.push_back(e);
+    }
+    run.chunk_ev.assign(h->chunk_ev.begin(), h->chunk_ev.begin() + n_chunks);
+    guard.retarget(h->feat_stream);
+    for (int c = 0; c < n_chunks; ++c) {
+      const int p0 = c * kStartChunk, p1 = std::min(n, p0 + kStartChunk);
+      for (int p = p0; p < p1; ++p) {
+        hs[p]->epoch = epoch;
+        jc.slice = batch_slice(p - p0, p1 - p0, P.knn);
+        SICPCHECK(align_begin(hs[p], stats != nullptr));
+      }
+      SICPCHECK(flush_jobs(h, jc, h->feat_stream));
+      for (int p = p0; p < p1; ++p) {  // the first search of the pair (what BatchRun::turn does for a pair between two solves)
+        OuterState& o = run.o[p];
+        std::memcpy(o.est, o.cur, sizeof o.est);
+        if (P.mode == SICP_MODE_SEMANTIC) o.count++;
+        jc.slice = batch_slice(p - p0, p1 - p0, P.knn);
+        SICPCHECK(run_correspondences(hs[p], o.cur, P.knn, true));
+        run.phase[p] = PAIR_FIRST;
+        run.first_chunk[p] = c;
+      }
+      SICPCHECK(flush_jobs(h, jc, h->feat_stream));
+      HIPCHECK(hipEventRecord(run.chunk_ev[c], h->feat_stream));
+    }
+  }
   // Tick length: lm_batch evaluations; twice that for up to 4 pairs, where the host's turn-around between
   // ticks (not the idle tail of a tick: a launch over finished pairs costs ~7 us) is what hurts.
   run.len = std::min((P.lm_batch > 0 ? P.lm_batch : 12) * (n <= 4 ? 2 : 1), sicp::kMaxBatchLen);
