@@ -110,14 +110,17 @@ typedef struct sicp_params {
   int32_t profile;                /* SICP_PROFILE_* bit mask: bracket those kernels with
                                      HIP events on the handle's stream (sicp_stats)     */
   int32_t lm_on_device;           /* 0 = host loop (one synchronisation per evaluation);
-                                     1 (default; 2 is an alias) = trust-region state lives on
+                                     1 (default; 3 is an alias) = trust-region state lives on
                                      the GPU: ticks of [accumulate kernel, LM-step kernel] x
                                      lm_batch as one graph launch, the host polls once per tick;
-                                     3 = as 1, but ONE pair alone (sicp_align) runs each inner
-                                     solve as one persistent launch (one workgroup per chunk, one
-                                     device-wide wait per evaluation) when its chunks fit the chip
-                                     -- measured slower than the ticks, kept as an
-                                     option.  Same machine (csrc/lm.hpp), same iterates, same bits. */
+                                     the ONLY pair still iterating -- sicp_align, or the tail of
+                                     a batch / stream -- continues its solve as persistent
+                                     launches (its chunks stay in registers, one workgroup per
+                                     chunk + one that steps the solver) when they
+                                     fit the chip, falling back to the ticks if that grid cannot
+                                     become resident;
+                                     2 = as 1 without the persistent launches.
+                                     Same machine (csrc/lm.hpp), same iterates, same bits.  */
   int32_t lm_batch;               /* evaluations queued per host poll (lm_on_device)    */
   int32_t reuse_features;         /* 0 (default) = recompute normals / histograms on every
                                      align() like em_icp.hpp:28-29 and gicp.hpp:33-34 do;

@@ -245,8 +245,9 @@ hipError_t launch_lm_step_batch(const BatchHeader* hdr, const BatchArgs* batch, 
 // one pair alone: the whole inner solve of batch[0] in one persistent launch (one workgroup per chunk); its partials
 // buffer holds TWO sets of columns, sync = max_evals + 1 words (word 0 is raised when a device-wide wait timed out)
 bool solve_one_fits(int total_slots, int K);
-hipError_t launch_solve_one(int K, int use_sqloss, const BatchArgs* batch, int n_chunks, unsigned* sync, int max_evals, hipStream_t st);
-constexpr int kSoloMaxEvals = 1024;
+constexpr int kSoloMaxEvals = 1024;   // evaluations one persistent launch may run (a solve that needs more is relaunched)
+constexpr int kSoloSyncWords = 288;   // its hand-off words (zeroed once, when allocated); 16 words of developer timers follow
+
 hipError_t launch_finalize_batch(const BatchArgs* batch, int n, double* out28, hipStream_t st);
 // pairs that start an inner solve with the next tick: their LM states are initialised ON the device from
 // one small upload (states[j.pair] = lm_init(j.opt, j.start)) instead of one 800-byte copy per pair
@@ -256,6 +257,22 @@ struct LmJoin {
   LmOptions opt;
 };
 hipError_t launch_lm_init(const LmJoin* joins, int n, LmState* states, hipStream_t st);
+// One persistent launch of the last pair still iterating (solve_kernels.hip: solve_one_kernel); everything it
+// needs travels in the kernel arguments: no upload, no state initialisation kernel, no memset ahead of it.
+struct SoloArgs {
+  AccArgs a;           // the pair; a.lm_step = its trust-region state in HBM
+  unsigned* sync;      // kSoloSyncWords hand-off words (+ 16 developer timers)
+  int max_evals;       // evaluations this launch may run
+  int spin_limit;      // polls before a wait gives up
+  unsigned tag_base;   // the launch's hand-off tags are tag_base + 1 ... tag_base + max_evals: older words never match
+  int init;            // 1: the inner solve starts with this launch (state := lm_init(opt, start)), 0: it continues
+  int seq;             // written to the state's pad_ word at a regular end: the host's proof the launch ran to it
+  int pad_;
+  double start[7];
+  LmOptions opt;
+};
+hipError_t launch_solve_one(int K, int use_sqloss, const SoloArgs& args, int n_chunks, hipStream_t st);
+int solo_spin_limit();
 hipError_t launch_count_active(const int* idx, int n, unsigned long long* out, hipStream_t st);
 // test hook: csrc/se3.hpp on the device, one lane per item (op = SICP_SE3_*; in/out strides per op)
 hipError_t launch_se3_ops(int op, int n, const double* in, double* out, hipStream_t st);

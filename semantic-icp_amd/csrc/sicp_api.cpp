@@ -280,8 +280,12 @@ struct sicp_context {
   // state per pair, pinned mirrors, and the captured [accumulate_batch, lm_step_batch] x lm_batch graph
   TickSet ts[2];  // two sets: the halves of a batch alternate, one's tick runs while the host turns the other around
   DevBuf<sicp::LmState> d_bstates;
-  DevBuf<unsigned> d_solo_sync;       // one pair alone: arrival counters of the persistent solve (solve_one_kernel)
-  unsigned* h_solo_abort = nullptr;   // pinned: its abort word, read back with the state
+  DevBuf<unsigned> d_solo_sync;       // the last pair still iterating: hand-off words of the persistent solve (solve_one_kernel)
+  unsigned solo_tag = 0;              // its tags so far (a launch uses solo_tag + 1 ...: the words are never zeroed in between)
+  int solo_seq = 0, solo_pair = 0;    // launch counter (the state's pad_ word echoes it at a regular end) and the pair's state slot
+  bool solo_was_init = false, solo_failed = false;  // the launch in flight starts a solve / the last one did not run to its end
+  bool solo_off = false;              // a persistent solve timed out once: this handle stays with the tick graph
+  bool count_stats = false;           // the align() in progress reports statistics: every search also counts its live slots
   DevBuf<double> d_bout28;
   sicp::LmState* h_bstates = nullptr;
   double* h_bout28 = nullptr;
@@ -770,6 +774,8 @@ int segment_of(const Cloud& c, uint32_t label) {
 }
 
 // transform + kNN + gate (+ EM weight) at pose qt: the loop em_icp.hpp:46-108
+int count_active(sicp_context* h);
+
 int run_correspondences(sicp_context* h, const double* qt, int K, bool weights) {
   const sicp_params& P = h->params;
   Cloud &S = h->cloud(0), &T = h->cloud(1);
@@ -825,6 +831,9 @@ int run_correspondences(sicp_context* h, const double* qt, int K, bool weights) 
   h->corr_K = K;
   h->corr_valid = true;
   h->hint_ok = true;
+  // statistics: the live slots of this search, counted right behind it (same stream / same job flush: no extra
+  // host turn between two solves)
+  if (h->count_stats) SICPCHECK(count_active(h));
   return SICP_OK;
 }
 
@@ -847,7 +856,7 @@ void fill_acc(sicp_context* h, sicp::AccArgs& a) {
 const int kMaxActivePairs = [] { const char* e = std::getenv("SICP_MAX_ACTIVE"); const int v = e ? std::atoi(e) : 256; return std::min(std::max(v, 1), 512); }();
 int batch_reserve(sicp_context* h, int n);
 int run_tick(sicp_context* h, hipStream_t M, sicp_handle* hs, int n, const std::vector<int>& act, const std::vector<int>& joining,
-             const double (*start)[7], int len, bool solo);
+             const double (*start)[7], int len, int solo_evals);
 
 // One evaluation sweep at pose qt: the batched kernel on a batch of one (every path -- a pair alone, a
 // lock-step batch, the host-loop solve, this hook -- runs the SAME accumulate kernel, so they agree bit
@@ -927,9 +936,10 @@ int run_solve(sicp_context* h, const double* init_qt, double* out_qt, SolveResul
   double start[1][7];
   std::memcpy(start[0], init_qt, sizeof start[0]);
   std::vector<int> act(1, 0), joining(1, 0);
-  const bool solo = P.lm_on_device == 3 && sicp::solve_one_fits(h->corr_n * h->corr_K, h->corr_K);
   for (;;) {
-    SICPCHECK(run_tick(h, h->stream, &self, 1, act, joining, start, len, solo));
+    const bool solo = P.lm_on_device != 2 && !h->solo_off && sicp::solve_one_fits(h->corr_n * h->corr_K, h->corr_K);
+    SICPCHECK(run_tick(h, h->stream, &self, 1, act, joining, start, len, solo ? sicp::kSoloMaxEvals : 0));
+    if (solo && h->solo_failed) continue;  // nothing has happened: the same step again as a tick
     joining.clear();
     h->st.acc_launches += solo ? 1 : len;
     if (h->h_bstates[0].status != sicp::LM_RUNNING) break;
@@ -957,6 +967,7 @@ int align_begin(sicp_context* h, bool want_stats) {
   Cloud &S = h->cloud(0), &T = h->cloud(1);
   HIPCHECK(h->d_count.reserve(1));
   if (want_stats) HIPCHECK(hipMemsetAsync(h->d_count.p, 0, sizeof(long long), h->stream));
+  h->count_stats = want_stats;
   SICPCHECK(prepare_cloud(h, S));
   SICPCHECK(prepare_cloud(h, T));
   // em_icp.hpp:28-29 / gicp.hpp:33-34 recompute the covariances on every align(); for
@@ -1009,6 +1020,7 @@ void outer_finish(const sicp_params& P, OuterState& o) {
 }
 
 int align_end(sicp_context* h, const OuterState& o, double t_begin, int32_t* outer_iters, sicp_stats* stats) {
+  h->count_stats = false;
   if (stats) {
     HIPCHECK(hipMemcpyAsync(h->h_count, h->d_count.p, sizeof(long long), hipMemcpyDeviceToHost, h->stream));
     HIPCHECK(hipStreamSynchronize(h->stream));
@@ -1140,8 +1152,8 @@ struct BatchGuard {
 // and uploaded first).  tick_launch only queues work on stream M (ending with the read-back of the
 // states of pairs [lo, hi) into h_bstates); the caller synchronises M when it wants the result.
 int tick_launch(sicp_context* h, TickSet& S, hipStream_t M, sicp_handle* hs, int lo, int hi, const std::vector<int>& act,
-                const std::vector<int>& joining, const double (*start)[7], int len, bool solo = false) {
-  if (!joining.empty()) {  // their LM states are initialised on the device: one upload + one tiny kernel
+                const std::vector<int>& joining, const double (*start)[7], int len, int solo_evals = 0) {
+  if (!joining.empty() && solo_evals <= 0) {  // their LM states are initialised on the device: one upload + one tiny kernel
     int k = 0;
     for (int p : joining) {
       sicp::LmJoin& J = S.h_join[k++];
@@ -1152,6 +1164,42 @@ int tick_launch(sicp_context* h, TickSet& S, hipStream_t M, sicp_handle* hs, int
     HIPCHECK(hipMemcpyAsync(S.d_join.p, S.h_join, sizeof(sicp::LmJoin) * joining.size(), hipMemcpyHostToDevice, M));
     HIPCHECK(sicp::launch_lm_init(S.d_join.p, (int)joining.size(), h->d_bstates.p, M));
   }
+  if (solo_evals > 0) {
+    // The ONLY pair still iterating: (up to solo_evals evaluations of) its inner solve as one persistent launch
+    // (solve_kernels.hip: solve_one_kernel) -- the chunk data stays in registers, two fence-free hand-offs per
+    // evaluation instead of two kernel boundaries, one host look per launch instead of per tick.  Everything travels
+    // in the kernel arguments: no argument upload, no state-initialisation kernel, no memset.
+    const int p = act[0];
+    sicp_context* g = hs[p];
+    const int nb = sicp::accumulate_blocks(g->corr_n * g->corr_K, g->corr_K);
+    if (g->partials.reserve((size_t)nb * 28) != hipSuccess) return SICP_ERR_OUT_OF_MEMORY;
+    const int evals = std::min(solo_evals, sicp::kSoloMaxEvals);
+    if (!h->d_solo_sync.p || h->solo_tag > 0xF0000000u) {
+      HIPCHECK(h->d_solo_sync.reserve((size_t)sicp::kSoloSyncWords + 16));  // (+ the phase timers of a -DSICP_SOLO_TIMING build)
+      HIPCHECK(hipMemsetAsync(h->d_solo_sync.p, 0, sizeof(unsigned) * (sicp::kSoloSyncWords + 16), M));
+      h->solo_tag = 0;
+    }
+    sicp::SoloArgs A;
+    std::memset(&A, 0, sizeof A);
+    fill_acc(g, A.a);
+    A.a.lm = A.a.lm_step = h->d_bstates.p + p;
+    A.sync = h->d_solo_sync.p;
+    A.max_evals = evals;
+    A.spin_limit = sicp::solo_spin_limit();
+    A.tag_base = h->solo_tag;
+    h->solo_tag += (unsigned)evals + 1u;
+    A.init = joining.empty() ? 0 : 1;
+    static std::atomic<int> launches{0};  // process-wide: a recycled state buffer cannot hold the number by accident
+    A.seq = h->solo_seq = ++launches;
+    if (A.init) std::memcpy(A.start, start[p], sizeof A.start);
+    A.opt = lm_options(g->params);
+    h->solo_pair = p;
+    h->solo_was_init = A.init != 0;
+    S.tick_valid = false;  // (the argument array in HBM was not refreshed)
+    HIPCHECK(sicp::launch_solve_one(g->corr_K, h->params.use_sqloss, A, nb, M));
+    HIPCHECK(hipMemcpyAsync(h->h_bstates + p, h->d_bstates.p + p, sizeof(sicp::LmState), hipMemcpyDeviceToHost, M));
+    return SICP_OK;
+  }
   // the argument array in HBM only changes when the set of pairs inside a solve does
   const bool same_set = S.tick_valid && joining.empty() && S.tick_act == act;
   int k = 0;
@@ -1161,7 +1209,7 @@ int tick_launch(sicp_context* h, TickSet& S, hipStream_t M, sicp_handle* hs, int
     sicp::BatchArgs& B = S.h_batch[k++];
     std::memset(&B, 0, sizeof B);
     const int nb = sicp::accumulate_blocks(g->corr_n * g->corr_K, g->corr_K);
-    if (g->partials.reserve((size_t)nb * 28 * (solo ? 2 : 1)) != hipSuccess) return SICP_ERR_OUT_OF_MEMORY;  // (solo: two sets of columns)
+    if (g->partials.reserve((size_t)nb * 28) != hipSuccess) return SICP_ERR_OUT_OF_MEMORY;
     fill_acc(g, B.a);
     B.a.lm = B.a.lm_step = h->d_bstates.p + p;
     B.nb = nb;
@@ -1172,18 +1220,6 @@ int tick_launch(sicp_context* h, TickSet& S, hipStream_t M, sicp_handle* hs, int
     HIPCHECK(hipMemcpyAsync(S.d_batch.p, S.h_batch, sizeof(sicp::BatchArgs) * act.size(), hipMemcpyHostToDevice, M));
     S.tick_act = act;
     S.tick_valid = true;
-  }
-  if (solo) {
-    // ONE pair alone: its whole inner solve as one persistent launch (solve_kernels.hip: solve_one_kernel) -- one
-    // device-wide wait per evaluation instead of two kernel boundaries, one host look per solve instead of per tick
-    sicp_context* g = hs[act[0]];
-    HIPCHECK(h->d_solo_sync.reserve((size_t)sicp::kSoloMaxEvals + 1 + 16));  // (+ the phase timers of a -DSICP_SOLO_TIMING build)
-    if (!h->h_solo_abort) HIPCHECK(hipHostMalloc((void**)&h->h_solo_abort, sizeof(unsigned), hipHostMallocDefault));
-    HIPCHECK(sicp::launch_solve_one(g->corr_K, h->params.use_sqloss, S.d_batch.p, sicp::accumulate_blocks(g->corr_n * g->corr_K, g->corr_K),
-                                    h->d_solo_sync.p, sicp::kSoloMaxEvals, M));
-    HIPCHECK(hipMemcpyAsync(h->h_solo_abort, h->d_solo_sync.p, sizeof(unsigned), hipMemcpyDeviceToHost, M));
-    HIPCHECK(hipMemcpyAsync(h->h_bstates + lo, h->d_bstates.p + lo, sizeof(sicp::LmState) * (hi - lo), hipMemcpyDeviceToHost, M));
-    return SICP_OK;
   }
   // [accumulate, lm_step_batch] x len as an explicit graph with fixed grids: the kernels read the
   // number of pairs from the header and their status from the LM states, so the graph is instantiated once per tick set
@@ -1206,35 +1242,43 @@ int tick_wait(sicp_context* h, hipStream_t M) {
   return SICP_OK;
 }
 
+// after a persistent launch has been waited for: did it run to its regular end?
 int solo_check(sicp_context* h) {
-#if defined(SICP_SOLO_TIMING)  // developer aid: cycles per phase of workgroup 0, per evaluation of the solve that just ended
+#if defined(SICP_SOLO_TIMING)  // developer aid: cycles per phase of the master and of worker 0, per evaluation of the launch that just ended
   {
-    unsigned w[10];
-    if (hipMemcpy(w, h->d_solo_sync.p + sicp::kSoloMaxEvals + 1, sizeof w, hipMemcpyDeviceToHost) == hipSuccess) {
-      const int ev = std::max(1, h->h_bstates[0].evaluations);
-      const char* nm[5] = {"accumulate", "publish", "wait", "reduce", "lm_feed"};
+    unsigned w[14];
+    if (hipMemcpy(w, h->d_solo_sync.p + sicp::kSoloSyncWords, sizeof w, hipMemcpyDeviceToHost) == hipSuccess) {
+      const int ev = std::max(1, h->h_bstates[h->solo_pair].evaluations);
+      const char* nm[7] = {"master: wait", "reduce", "lm_feed", "publish", "| worker 0: compute", "publish", "wait"};
       std::fprintf(stderr, "[solo timing] %d evaluations, cycles per evaluation:", ev);
-      for (int i = 0; i < 5; ++i) std::fprintf(stderr, " %s %.0f", nm[i], (double)(((unsigned long long)w[2 * i + 1] << 32) | w[2 * i]) / ev);
+      for (int i = 0; i < 7; ++i) std::fprintf(stderr, " %s %.0f", nm[i], (double)(((unsigned long long)w[2 * i + 1] << 32) | w[2 * i]) / ev);
       std::fprintf(stderr, "\n");
     }
   }
 #endif
-  if (h->h_solo_abort && *h->h_solo_abort != 0u) {
-    h->last_error = "solve_one_kernel: a device-wide wait timed out (the grid was not resident)";
-    return SICP_ERR_HIP;
+  // The master echoes the launch's sequence number in the state's pad_ word when it writes the state back.  Anything
+  // else means a wait timed out -- the grid was not resident as a whole: something else holds CUs for longer than
+  // the limit -- and the launch has left the state in HBM as it was: the solve continues (or starts) as
+  // [accumulate, LM step] ticks, and this handle stays with them.
+  h->solo_failed = h->h_bstates[h->solo_pair].pad_ != h->solo_seq;
+  if (h->solo_failed) {
+    h->solo_off = true;
+    HIPCHECK(hipMemsetAsync(h->d_solo_sync.p, 0, sizeof(unsigned) * sicp::kSoloSyncWords, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    h->solo_tag = 0;
   }
   return SICP_OK;
 }
 
 int run_tick(sicp_context* h, hipStream_t M, sicp_handle* hs, int n, const std::vector<int>& act, const std::vector<int>& joining,
-             const double (*start)[7], int len, bool solo) {
-  SICPCHECK(tick_launch(h, h->ts[0], M, hs, 0, n, act, joining, start, len, solo));
+             const double (*start)[7], int len, int solo_evals) {
+  SICPCHECK(tick_launch(h, h->ts[0], M, hs, 0, n, act, joining, start, len, solo_evals));
   SICPCHECK(tick_wait(h, M));
-  if (solo) SICPCHECK(solo_check(h));
+  if (solo_evals > 0) SICPCHECK(solo_check(h));
   return SICP_OK;
 }
 
-// statistics only: add the number of live slots of the current search to the device counter
+// statistics only: add the number of live slots of the current search to the device counter (run_correspondences)
 int count_active(sicp_context* h) {
   if (h->collect) {
     h->collect->count[h->collect->slice].push_back(sicp::CountJob{h->idx.p, h->corr_n * h->corr_K, (unsigned long long*)h->d_count.p});
@@ -1274,14 +1318,14 @@ struct BatchRun {
   sicp_params P;                // what every pair of the run agrees on (same_solver)
   int len = 8;                  // LM evaluations per tick
   bool one_launch = true, want_stats = false;
-  bool solo = false;            // a run of ONE pair: an inner solve is one persistent launch (when its chunks fit the chip)
+  bool solo = false;            // the last pair still iterating may run its solve as persistent launches (lm_on_device != 2)
   hipStream_t side = nullptr;   // searches / features of the pairs between two inner solves
   struct Start { double q[7]; };
   std::vector<OuterState> o;
   std::vector<int> phase, search_round;
   std::vector<Start> starts;
-  bool solo_now = false;  // the tick in flight is a persistent solve
-  int solo_seen = 0;      // evaluations of the running solve already counted
+  bool solo_now = false;        // the tick in flight is a persistent solve
+  std::vector<int> evals_seen;  // evaluations of the pair's running solve already counted in the statistics
   std::vector<int> first_chunk;        // PAIR_FIRST: the start-up chunk the pair belongs to
   std::vector<hipEvent_t> chunk_ev;    // recorded behind each chunk's start-up pipeline
   // pairs whose start-up pipeline has completed join the ticks; with `block` the host waits for the first chunk
@@ -1310,6 +1354,7 @@ struct BatchRun {
     search_round.assign(slots, 0);
     starts.assign(slots, Start());
     first_chunk.assign(slots, 0);
+    evals_seen.assign(slots, 0);
   }
   // pair p starts its align() at init_qt (its handle's align_begin has run)
   void start_pair(int p, const double* init_qt) {
@@ -1334,14 +1379,21 @@ int BatchRun::turn(TickGroup& G, JobCollector& jc) {
     SICPCHECK(tick_wait(h, G.M));
     G.pending = false;
     G.finished.clear();
-    if (solo_now) SICPCHECK(solo_check(h));
+    if (solo_now) {
+      SICPCHECK(solo_check(h));
+      if (h->solo_failed) {  // nothing has happened: the pair takes the same step again with the ticks
+        const int p = G.act[0];
+        if (h->solo_was_init) { phase[p] = PAIR_JOINING; search_round[p] = 0; }
+        G.act.clear();
+      }
+    }
     for (int p : G.act) {
       sicp_context* g = hs[p];
       const sicp::LmState& st = h->h_bstates[p];
       // evaluation launches the pair sat through: the tick's, or -- one persistent launch -- its own evaluations
-      g->st.lockstep_slots += solo_now ? st.evaluations - solo_seen : len;
+      g->st.lockstep_slots += solo_now ? st.evaluations - evals_seen[p] : len;
       g->st.acc_launches += solo_now ? 1 : len;
-      if (solo_now) solo_seen = st.status == sicp::LM_RUNNING ? st.evaluations : 0;
+      evals_seen[p] = st.status == sicp::LM_RUNNING ? st.evaluations : 0;
       if (st.status == sicp::LM_RUNNING) continue;
       std::memcpy(o[p].est, st.x, sizeof st.x);
       g->st.total_lm_iters += st.iterations;
@@ -1351,11 +1403,9 @@ int BatchRun::turn(TickGroup& G, JobCollector& jc) {
     }
     for (int p : G.finished) {
       jc.slice = 0;
-      if (want_stats) SICPCHECK(count_active(hs[p]));  // before the pair's next search overwrites idx
       outer_finish(P, o[p]);
       phase[p] = o[p].converged ? PAIR_DONE : PAIR_NEED_SEARCH;
     }
-    if (want_stats && one_launch && !G.finished.empty()) SICPCHECK(flush_jobs(h, jc, side));  // counts: same stream, ahead of the searches
   }
   if (live(G) == 0) return SICP_OK;
   if (!chunk_ev.empty()) {
@@ -1410,8 +1460,18 @@ int BatchRun::turn(TickGroup& G, JobCollector& jc) {
   // the tick reads its pairs' arguments in ascending slot order (the order of the argument array)
   std::sort(G.act.begin(), G.act.end());
   for (int p : G.joining) { phase[p] = PAIR_SOLVING; std::memcpy(starts[p].q, o[p].est, sizeof starts[p].q); }
-  solo_now = solo && G.act.size() == 1 && sicp::solve_one_fits(hs[G.act[0]]->corr_n * hs[G.act[0]]->corr_K, hs[G.act[0]]->corr_K);
-  int rc = tick_launch(h, *G.S, G.M, hs, G.lo, G.hi, G.act, G.joining, reinterpret_cast<const double(*)[7]>(starts.data()), len, solo_now);
+  // The only pair of the whole run that still iterates -- a run of one, or the tail of a batch -- has the chip to
+  // itself: its solve continues as persistent launches (of at most 64 evaluations when other slots may fill up
+  // meanwhile: a stream's new registrations are admitted between launches).
+  solo_now = false;
+  if (solo && !L->solo_off && G.act.size() == 1) {
+    int live_all = 0;
+    for (int p = 0; p < n; ++p) live_all += phase[p] != PAIR_FREE && phase[p] != PAIR_DONE;
+    const sicp_context* g = hs[G.act[0]];
+    solo_now = live_all == 1 && sicp::solve_one_fits(g->corr_n * g->corr_K, g->corr_K);
+  }
+  int rc = tick_launch(h, *G.S, G.M, hs, G.lo, G.hi, G.act, G.joining, reinterpret_cast<const double(*)[7]>(starts.data()), len,
+                       solo_now ? (n == 1 ? sicp::kSoloMaxEvals : 64) : 0);
   if (rc != SICP_OK) return rc;
   G.pending = true;
   return SICP_OK;
@@ -1536,7 +1596,6 @@ int sicp_destroy(sicp_handle h) {
   }
   if (h->h_bstates) (void)hipHostFree(h->h_bstates);
   if (h->h_bout28) (void)hipHostFree(h->h_bout28);
-  if (h->h_solo_abort) (void)hipHostFree(h->h_solo_abort);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
@@ -1702,7 +1761,6 @@ int sicp_align(sicp_handle h, const double init_qt[7], double out_qt[7], int32_t
       h->st.final_cost = r.cost;
       h->st.t_solve_ms += now_ms() - t0;
     }
-    if (stats) SICPCHECK(count_active(h));
     outer_finish(P, o);
   }
   std::memcpy(out_qt, o.cur, sizeof o.cur);
@@ -1786,7 +1844,7 @@ int sicp_align_batch(sicp_handle* hs, int32_t n, const double* init_qt, double* 
   }
   BatchRun run;
   run.L = L; run.hs = hs; run.P = P; run.one_launch = one_launch; run.want_stats = stats != nullptr;
-  run.solo = n == 1 && one_launch && P.lm_on_device == 3;
+  run.solo = one_launch && P.lm_on_device != 2;
   run.resize(n);
   for (int p = 0; p < n; ++p) run.start_pair(p, init_qt + 7 * p);
   if (staged) {
@@ -1846,7 +1904,8 @@ int sicp_align_batch(sicp_handle* hs, int32_t n, const double* init_qt, double* 
       grp[g].side_done = g == 0 ? h->side_done : h->side_done2;
     }
   }
-  const hipStream_t side = one_launch ? L->side_stream : grp[0].M;
+  // (one pair alone: its searches and its solves alternate anyway -- one stream, no cross-stream event per outer iteration)
+  const hipStream_t side = (one_launch && n > 1) ? L->side_stream : grp[0].M;
   run.side = side;
   {  // the tick streams and the side stream start after everything queued so far (features)
     sicp_context* h = L;
@@ -1942,6 +2001,7 @@ void stream_worker(sicp_stream_ctx* S) {
   sicp_context* L = S->slots[0];
   BatchRun run;
   run.L = L; run.hs = S->slots.data(); run.P = S->params; run.one_launch = true; run.want_stats = false;
+  run.solo = S->params.lm_on_device != 2;
   run.resize(S->cap);
   run.len = std::min(S->params.lm_batch > 0 ? S->params.lm_batch : 8, sicp::kMaxBatchLen);
   run.side = L->side_stream;

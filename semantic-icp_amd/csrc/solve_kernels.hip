@@ -665,6 +665,17 @@ __global__ __launch_bounds__(BS, SICP_ACC_OCC) void accumulate_staged_kernel(con
   }
 }
 
+// Hand-offs between workgroups of one launch (the persistent solve): write-through stores and agent-scope loads of
+// at most 8 bytes -- visible across CUs and XCDs without a release / acquire fence (cdna_hip_programming.md
+// guideline 16, recipe R1: payload sc1 -> the storing wave drains -> one lane stores the flag).
+typedef unsigned long long u64;
+__device__ __forceinline__ void coherent_store_f64(SICP_GLOBAL double* p, double v) {
+  __hip_atomic_store((SICP_GLOBAL u64*)p, (u64)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double coherent_load_f64(const SICP_GLOBAL double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load((const SICP_GLOBAL u64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
 // Fixed-order sum of the partial columns (layout [28][n]) by one workgroup of
 // REDUCE_THREADS / 64 waves: wave (cq = wave / 4, rg = wave % 4) sums the rows rg, rg + 4, ... (7 of
 // them) over the column part cq (all columns with 256 threads) -- lane l takes the columns l, l + 64,
@@ -678,6 +689,9 @@ __global__ __launch_bounds__(BS, SICP_ACC_OCC) void accumulate_staged_kernel(con
 #endif
 constexpr int REDUCE_THREADS = SICP_REDUCE_THREADS, REDUCE_PARTS = REDUCE_THREADS / 256;
 static_assert(REDUCE_PARTS == 1, "the column count need not divide");
+// COHERENT: the columns were written by other workgroups of the SAME launch with write-through (sc1) stores and are
+// read with agent-scope loads, which no cache of this CU / XCD can serve stale (the persistent solve's master).
+template <bool COHERENT = false>
 __device__ __forceinline__ void reduce_partials_block(const double* __restrict__ partials, int n, double (&s_part)[4][28], double (&o)[28]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, rg = wave & 3, cq = wave >> 2;
   const int nq = n / REDUCE_PARTS, c0 = cq * nq, c1 = c0 + nq;
@@ -692,7 +706,8 @@ __device__ __forceinline__ void reduce_partials_block(const double* __restrict__
     for (int t = 0; t < DEEP; ++t) {
       const int b = min(b0 + 64 * t, c1 - 1);  // clamped: loaded unconditionally, added only when in range
 #pragma unroll
-      for (int r = 0; r < 7; ++r) v[t][r] = __builtin_nontemporal_load(base + (size_t)(4 * r) * n + b);
+      for (int r = 0; r < 7; ++r)
+        v[t][r] = COHERENT ? coherent_load_f64((const SICP_GLOBAL double*)(base + (size_t)(4 * r) * n + b)) : __builtin_nontemporal_load(base + (size_t)(4 * r) * n + b);
     }
 #pragma unroll
     for (int t = 0; t < DEEP; ++t)
@@ -743,37 +758,46 @@ __global__ __launch_bounds__(REDUCE_THREADS) void lm_step_batch_kernel(const Bat
 // One pair alone: the whole inner solve in ONE launch.
 //
 // A pair alone is a chain of ~120 evaluations, and as [accumulate launch, LM-step launch] each costs two launch
-// boundaries (a no-op launch of either kernel is 4-4.5 us) on top of its work.  Here workgroup b owns chunk b for
-// the whole solve (grid = the pair's chunks, all resident: one per CU) and an evaluation is
-//     accumulate chunk b at the current pose (accumulate_segment: the batched kernel's routine, same bits)
-//  -> column b of partials[e & 1]  -> arrive on counter e (agent-scope release)  -> wait for all (relaxed
-//     poll by one lane, one agent-scope acquire)
-//  -> EVERY workgroup sums the columns (reduce_partials_block: the LM-step kernel's routine) and advances ITS
-//     OWN copy of the trust-region state with lm_feed: same inputs, same code, same state everywhere -- no
-//     second hand-off for the new pose.  Workgroup 0 writes the state back at the end.
-// One device-wide wait per evaluation instead of two kernel boundaries, the state never leaves registers, and
-// the host looks once per inner solve.  Hand-off protocol: cdna_hip_programming.md guideline 16 (plain payload
-// stores -> every storing wave drains -> barrier -> one lane: release fence, drain, relaxed agent atomic;
-// consumer: relaxed poll, ONE acquire fence, barrier, plain loads); one counter per evaluation (zeroed by a
-// memset ahead of the launch), partial columns double-buffered by the evaluation's parity (a workgroup can be
-// at most one evaluation ahead of another).  Every spin is bounded: on a timeout the abort word is raised, every
-// workgroup leaves, and the host reports an error instead of waiting for a grid that is not resident.
+// boundaries (a no-op launch of either kernel is 4-4.5 us) on top of its work, and every evaluation streams the
+// same 5.7 MB again.  Here the grid is one WORKER workgroup per chunk plus one MASTER, all resident (one per CU):
+//   * worker b loads chunk b ONCE -- indices, weights, source records, the gathered target records: 8 slots per
+//     lane, ~114 registers -- and keeps it in registers for the whole solve: the correspondences do not change
+//     inside an inner solve, only the pose does.  An evaluation is compute_group over the resident groups (the
+//     batched kernel's arithmetic, the same order: the same bits) -> wave_reduce -> column b -> flag b := e + 1;
+//   * the master polls the flags (one lane per worker: parallel loads, no contended atomic), sums the columns
+//     (reduce_partials_block: the LM-step kernel's routine), advances the trust-region state (lm_feed, state in
+//     the registers of its thread 0), publishes pose + status and raises the epoch;
+//   * the workers poll the epoch, read the pose, go again.
+// Two hand-offs per evaluation, without a fence (cdna_hip_programming.md guideline 16, recipe R1): the payload --
+// a column's 28 doubles, the pose -- is stored write-through (agent-scope 8-byte stores), the storing wave drains
+// (s_waitcnt vmcnt(0)), ONE lane stores the flag; the consumer polls the flag relaxed and reads the payload with
+// agent-scope loads, which neither its L1 nor its XCD's L2 can serve stale.  (With plain stores + a release fence
+// and an acquire fence + plain loads each hand-off cost ~4 us more: buffer_wbl2 / buffer_inv are ~1.7 us each.)
+// Columns, pose and flags need no double buffering: a worker writes column e + 1 only after epoch e + 1, which the master raises after it has summed the columns of e; the master writes
+// pose e + 2 only after every worker has flagged e + 1, i.e. has read pose e + 1.  Every spin is bounded: on a
+// timeout the abort word is raised, every workgroup leaves, and the host reports an error instead of waiting
+// for a grid that is not resident.
 // ------------------------------------------------------------------------------------------
-constexpr int kSoloSpinLimit = 1 << 22;  // polls (with s_sleep) before a wait gives up: ~1 s
+// sync[0]: abort word; sync[2 .. 31]: the published pose as 15 granules {tag = evaluations fed, 32 bits of payload}
+// (7 doubles in halves + the status: the data is its own flag -- recipe R2 -- so a worker learns the new pose in ONE
+// round trip); sync[kSoloFlags + b]: worker b's flag (= evaluations it has delivered).
+constexpr int kSoloFlags = 32, kSoloGranules = 15;
+static_assert(kSoloFlags + 256 <= kSoloSyncWords, "flags of up to 256 workers");
 
 template <int K, bool SQLOSS, int BS>
-__global__ __launch_bounds__(BS, 1) void solve_one_kernel(const BatchArgs* __restrict__ batch, unsigned* __restrict__ sync, int max_evals) {
-  constexpr int SG = GroupShape<K>::SG, NW = BS / 64;
-  extern __shared__ __attribute__((aligned(16))) double smem[];  // [reduction tiles | staging | logarithm table]
-  __shared__ double comb[COMB_CHUNKS][NW][28];
+__global__ __launch_bounds__(BS, 1) void solve_one_kernel(const SoloArgs A) {
+  constexpr int SG = GroupShape<K>::SG, NS = GroupShape<K>::NS, NW = BS / 64, STEPS = 8 / SG;
+  extern __shared__ __attribute__((aligned(16))) double smem[];  // [reduction tiles | logarithm table]
+  __shared__ double comb[NW][28];
   __shared__ double s_part[4][28];
-  __shared__ double s_pose[7];
+  __shared__ unsigned s_gran[kSoloGranules + 1];
   __shared__ int s_status, s_abort;
-  char* stage_all = reinterpret_cast<char*>(smem + NW * RED_ROWS * RED_STRIDE);
-  char* log_tab = stage_all + NW * SG * STAGE_SLOT_BYTES;
-  for (int k = threadIdx.x; k < kLogTableEntries; k += BS) reinterpret_cast<v2d*>(log_tab)[k] = reinterpret_cast<const v2d*>(kLogTable)[k];
+  char* log_tab = reinterpret_cast<char*>(smem + NW * RED_ROWS * RED_STRIDE);
   const int lane = threadIdx.x & 63, wave = uniform_i32((int)(threadIdx.x >> 6));
-  const AccArgs& a = batch[0].a;
+  const AccArgs& a = A.a;
+  const int max_evals = A.max_evals, spin_limit = A.spin_limit;
+  const unsigned tag_base = A.tag_base;
+  unsigned* const sync = A.sync;
   LoadCtx L;
   L.idx = (const SICP_GLOBAL int*)uniform_ptr(a.idx);
   L.w = (const SICP_GLOBAL double*)uniform_ptr(a.w);
@@ -782,10 +806,97 @@ __global__ __launch_bounds__(BS, 1) void solve_one_kernel(const BatchArgs* __res
   L.n_s = uniform_i32(a.n_s);
   L.total = uniform_i32(a.n_s * a.K);
   const AccGeometry geo = acc_geometry(L.total, SG);
-  const int n_chunks = uniform_i32(geo.n_chunks), steps = uniform_i32(geo.steps), chunk_groups = uniform_i32(geo.chunk_groups);
-  if (n_chunks != (int)gridDim.x) return;  // (the host launches one workgroup per chunk)
-  SICP_GLOBAL double* partials = (SICP_GLOBAL double*)uniform_ptr(a.partials);
+  const int n_chunks = uniform_i32(geo.n_chunks), chunk_groups = uniform_i32(geo.chunk_groups);
+  // (the host launches one workgroup per chunk + the master, and only for pairs whose chunks are 8 slots per lane)
+  if (n_chunks + 1 != (int)gridDim.x || geo.steps != STEPS || n_chunks > BS) return;
+  SICP_GLOBAL double* col = (SICP_GLOBAL double*)uniform_ptr(a.partials);
   LmState* lm = a.lm_step;
+  SICP_GLOBAL unsigned* const abort_word = (SICP_GLOBAL unsigned*)sync;
+  SICP_GLOBAL u64* const gran = (SICP_GLOBAL u64*)(abort_word + 2);
+  SICP_GLOBAL unsigned* const flags = abort_word + kSoloFlags;
+#if defined(SICP_SOLO_TIMING)  // developer aid: cycles per phase of the master and of worker 0, summed over the evaluations
+  unsigned long long tm[4] = {0, 0, 0, 0}, tprev = 0;
+#define SOLO_MARK(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); tm[i] += now_ - tprev; tprev = now_; } while (0)
+#else
+#define SOLO_MARK(i) do { } while (0)
+#endif
+  if (threadIdx.x == 0) s_abort = 0;
+
+  if (blockIdx.x == 0) {
+    // ------------------------------------------------------------------ the master
+    LmCore st;
+    if (threadIdx.x == 0) {
+      if (A.init) {
+        LmState fresh;
+        lm_init(fresh, A.opt, A.start);
+        st = fresh;
+      } else {
+        st = *lm;
+      }
+      s_status = st.status;
+    }
+    __syncthreads();
+    for (int e = 0; e < max_evals; ++e) {
+      if (s_status != LM_RUNNING) break;
+      const unsigned want = tag_base + (unsigned)(e + 1);
+#if defined(SICP_SOLO_TIMING)
+      tprev = __builtin_readcyclecounter();
+#endif
+      if ((int)threadIdx.x < n_chunks) {
+        int spins = 0;
+        while (__hip_atomic_load(&flags[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > spin_limit || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+            __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_abort = 1;
+            break;
+          }
+        }
+      }
+      __syncthreads();
+      if (s_abort) return;
+      SOLO_MARK(0);
+      double o[28];
+      reduce_partials_block<true>((const double*)col, n_chunks, s_part, o);
+      SOLO_MARK(1);
+      if (threadIdx.x < 64) {
+        // thread 0 steps the machine; the new pose leaves as ONE store instruction of 15 lanes (15 stores of one
+        // lane reach the other XCDs one after the other: ~1.5 us)
+        if (threadIdx.x == 0) {
+          lm_feed(st, A.opt, o);
+          SOLO_MARK(2);
+#pragma unroll
+          for (int k = 0; k < 7; ++k) {
+            const u64 bits = (u64)__double_as_longlong(st.pose[k]);
+            s_gran[2 * k] = (unsigned)bits;
+            s_gran[2 * k + 1] = (unsigned)(bits >> 32);
+          }
+          s_gran[14] = (unsigned)st.status;
+          s_status = st.status;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (lane < kSoloGranules)
+          __hip_atomic_store(gran + lane, ((u64)want << 32) | (u64)s_gran[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        SOLO_MARK(3);
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      st.pad_ = A.seq;  // the launch ran to its regular end (after a timed-out wait the state in HBM is left as it was)
+      *static_cast<LmCore*>(lm) = st;
+      if (A.init) lm->opt = A.opt;
+#if defined(SICP_SOLO_TIMING)
+      for (int i = 0; i < 4; ++i) { sync[kSoloSyncWords + 2 * i] = (unsigned)tm[i]; sync[kSoloSyncWords + 1 + 2 * i] = (unsigned)(tm[i] >> 32); }
+#endif
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------- a worker
+  const int b = (int)blockIdx.x - 1;
+  for (int k = threadIdx.x; k < kLogTableEntries; k += BS) reinterpret_cast<v2d*>(log_tab)[k] = reinterpret_cast<const v2d*>(kLogTable)[k];
   MathCtx M;
   {
     const double loss_b = a.loss.cauchy_a * a.loss.cauchy_a;
@@ -793,85 +904,92 @@ __global__ __launch_bounds__(BS, 1) void solve_one_kernel(const BatchArgs* __res
     M.gw = uniform_f64(2.0 / a.one_m_eps - 1.0);
     M.log_table = (unsigned)uniform_i32((int)(unsigned)(unsigned long)(SICP_LDS char*)log_tab);
   }
-  SICP_LDS char* stage = (SICP_LDS char*)stage_all + wave * (SG * STAGE_SLOT_BYTES);
   SICP_LDS double* tile = (SICP_LDS double*)smem + wave * (RED_ROWS * RED_STRIDE);
-  // every workgroup keeps the trust-region state in the registers of its thread 0
-  LmCore st;
-  if (threadIdx.x == 0) {
-    st = *lm;
+  // the chunk, once: what accumulate_segment loads step by step (same clamps, same dead-slot rule)
+  Group<K> G[STEPS];
+  {
+    const int last = ((L.total - 1) / SG) * SG;
 #pragma unroll
-    for (int k = 0; k < 7; ++k) s_pose[k] = st.pose[k];
-    s_status = st.status;
-    s_abort = 0;
+    for (int t = 0; t < STEPS; ++t) {
+      const int g = b * chunk_groups + (int)threadIdx.x + t * BS;
+      load_idx_raw<K>(L, g, G[t].j);
+      fix_idx<K>(L.total, g, G[t].j);
+      GroupRegs<K> R;
+      load_regs<K>(L, last, g, R);
+#pragma unroll
+      for (int c = 0; c < SG; ++c) {
+        G[t].w[c] = R.w[c];
+        load_rec(L.trec + max(G[t].j[c], 0), G[t].tx[c], G[t].ty[c], G[t].tz[c], G[t].tnx[c], G[t].tny[c], G[t].tnz[c]);
+      }
+#pragma unroll
+      for (int s = 0; s < NS; ++s) { G[t].sx[s] = R.sx[s]; G[t].sy[s] = R.sy[s]; G[t].sz[s] = R.sz[s]; G[t].snx[s] = R.snx[s]; G[t].sny[s] = R.sny[s]; G[t].snz[s] = R.snz[s]; }
+    }
   }
+  if (threadIdx.x < 7) {
+    const u64 bits = (u64)__double_as_longlong(A.init ? A.start[threadIdx.x] : lm->pose[threadIdx.x]);
+    s_gran[2 * threadIdx.x] = (unsigned)bits;
+    s_gran[2 * threadIdx.x + 1] = (unsigned)(bits >> 32);
+  }
+  if (threadIdx.x == 0) s_gran[14] = (unsigned)(A.init ? (int)LM_RUNNING : lm->status);
   __syncthreads();
-  unsigned* const abort_word = sync;       // sync[0]: raised when a wait timed out
-  unsigned* const arrivals = sync + 1;     // sync[1 + e]: workgroups that have written evaluation e's column
-#if defined(SICP_SOLO_TIMING)  // developer aid: cycles of workgroup 0 per phase, summed over the evaluations -> sync[max_evals + 1 ...]
-  unsigned long long tm[5] = {0, 0, 0, 0, 0}, tprev = 0;
-#define SOLO_MARK(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); tm[i] += now_ - tprev; tprev = now_; } while (0)
-#else
-#define SOLO_MARK(i) do { } while (0)
-#endif
   for (int e = 0; e < max_evals; ++e) {
-    if (s_status != LM_RUNNING) break;
+    if ((int)s_gran[14] != LM_RUNNING) break;
 #if defined(SICP_SOLO_TIMING)
     tprev = __builtin_readcyclecounter();
 #endif
     {
       double pose[7], R[9];
 #pragma unroll
-      for (int k = 0; k < 7; ++k) pose[k] = s_pose[k];
+      for (int k = 0; k < 7; ++k) pose[k] = __hiloint2double((int)s_gran[2 * k + 1], (int)s_gran[2 * k]);
       se3::rotation(pose, R);
 #pragma unroll
       for (int k = 0; k < 9; ++k) M.P.R[k] = uniform_f64(R[k]);
 #pragma unroll
       for (int k = 0; k < 3; ++k) M.P.t[k] = uniform_f64(pose[4 + k]);
     }
-    SICP_GLOBAL double* col = partials + (size_t)(e & 1) * 28 * n_chunks;
-    accumulate_segment<K, SQLOSS, BS>(L, M, (int)blockIdx.x, 1, n_chunks, steps, chunk_groups, col, stage, tile, comb, lane, wave);
-    SOLO_MARK(0);
-    // ---- publish this workgroup's column, wait for everybody's
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its column stores
+    double acc[28];
+#pragma unroll
+    for (int k = 0; k < 28; ++k) acc[k] = 0.0;
+#pragma unroll
+    for (int t = 0; t < STEPS; ++t) compute_group<K, SQLOSS>(M, G[t], acc);
+    wave_reduce(acc, tile, (SICP_LDS double*)&comb[wave][0], lane);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (threadIdx.x < 28)
+      coherent_store_f64(col + (size_t)threadIdx.x * n_chunks + b, (comb[0][threadIdx.x] + comb[1][threadIdx.x]) + (comb[2][threadIdx.x] + comb[3][threadIdx.x]));
+    SOLO_MARK(0);
+    // ---- publish the column (its 28 write-through stores are wave 0's: that wave drains, one lane raises the flag),
+    //      then wave 0 sweeps the pose granules until all 15 carry this evaluation's tag
+    // (every thread read this evaluation's pose out of s_gran before the barrier above)
+    if (threadIdx.x < 64) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_fetch_add(&arrivals[e], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned want = tag_base + (unsigned)(e + 1);
+      if (threadIdx.x == 0) __hip_atomic_store(&flags[b], want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       SOLO_MARK(1);
-      int spins = 0;
-      bool bad = false;
-      while (__hip_atomic_load(&arrivals[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
-        __builtin_amdgcn_s_sleep(2);
-        if (++spins > kSoloSpinLimit || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-          __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          bad = true;
+      const int gl = min(lane, kSoloGranules - 1);
+      for (int spins = 0;;) {
+        const u64 x = __hip_atomic_load(gran + gl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__all((unsigned)(x >> 32) == want)) {
+          if (lane < kSoloGranules) s_gran[lane] = (unsigned)x;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > spin_limit || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+          if (lane == 0) {
+            __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_abort = 1;
+          }
           break;
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      if (bad) s_abort = 1;
     }
     __syncthreads();
     if (s_abort) return;
     SOLO_MARK(2);
-    // ---- every workgroup: the 28 sums, and the step of its own copy of the state
-    double o[28];
-    reduce_partials_block((const double*)col, n_chunks, s_part, o);
-    SOLO_MARK(3);
-    if (threadIdx.x == 0) {
-      lm_feed(st, lm->opt, o);
-#pragma unroll
-      for (int k = 0; k < 7; ++k) s_pose[k] = st.pose[k];
-      s_status = st.status;
-    }
-    __syncthreads();
-    SOLO_MARK(4);
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) *static_cast<LmCore*>(lm) = st;
 #if defined(SICP_SOLO_TIMING)
-  if (blockIdx.x == 0 && threadIdx.x == 0)
-    for (int i = 0; i < 5; ++i) { sync[max_evals + 1 + 2 * i] = (unsigned)tm[i]; sync[max_evals + 2 + 2 * i] = (unsigned)(tm[i] >> 32); }
+  if (b == 0 && threadIdx.x == 0)
+    for (int i = 0; i < 3; ++i) { sync[kSoloSyncWords + 8 + 2 * i] = (unsigned)tm[i]; sync[kSoloSyncWords + 9 + 2 * i] = (unsigned)(tm[i] >> 32); }
 #endif
 }
 
@@ -948,12 +1066,10 @@ hipError_t launch_accumulate_batch(int K, int use_sqloss, const BatchHeader* hdr
   return hipLaunchKernel(fn, dim3(accumulate_grid()), dim3(256), args, stream_smem_bytes(capacity, K), st);
 }
 
-static size_t solo_smem_bytes(int K) {
-  const size_t staging = (size_t)4 * acc_slots_per_group(K) * STAGE_SLOT_BYTES;
-  return sizeof(double) * 4 * RED_ROWS * RED_STRIDE + staging + LOG_TABLE_BYTES;
-}
+static size_t solo_smem_bytes(int) { return sizeof(double) * 4 * RED_ROWS * RED_STRIDE + LOG_TABLE_BYTES; }
 
-// whether a pair of `total` slots can run as one persistent solve: one workgroup per chunk, all of them resident
+// whether a pair of `total` slots can run as one persistent solve: one workgroup per chunk and the master, all of
+// them resident (one per CU), a chunk being 8 slots per lane (m = 1 in acc_geometry: always, at this size)
 bool solve_one_fits(int total, int K) {
   static const int cus = [] {
     int dev = 0, n = 256;
@@ -961,10 +1077,17 @@ bool solve_one_fits(int total, int K) {
     return n > 0 ? n : 256;
   }();
   static const bool off = getenv("SICP_NO_SOLO") != nullptr;  // developer switch: always the [accumulate, LM step] graph
-  return !off && total > 0 && accumulate_blocks(total, K) <= cus;
+  return !off && total > 0 && accumulate_blocks(total, K) + 1 <= (cus < 257 ? cus : 257) && acc_geometry(total, acc_slots_per_group(K)).steps == 8 / acc_slots_per_group(K);
 }
 
-hipError_t launch_solve_one(int K, int use_sqloss, const BatchArgs* batch, int n_chunks, unsigned* sync, int max_evals, hipStream_t st) {
+// polls (a memory round trip + s_sleep each, ~1 us) before a wait of the persistent solve gives up: ~0.1 s.
+// SICP_SOLO_SPIN: test aid (0 = the first unsuccessful poll gives up, which exercises the host's fallback to the ticks)
+int solo_spin_limit() {
+  static const int v = [] { const char* e = getenv("SICP_SOLO_SPIN"); return e ? atoi(e) : 1 << 17; }();
+  return v;
+}
+
+hipError_t launch_solve_one(int K, int use_sqloss, const SoloArgs& args, int n_chunks, hipStream_t st) {
   void* fn = nullptr;
   switch (K) {
     case 1: fn = use_sqloss ? (void*)solve_one_kernel<1, true, 256> : (void*)solve_one_kernel<1, false, 256>; break;
@@ -972,10 +1095,8 @@ hipError_t launch_solve_one(int K, int use_sqloss, const BatchArgs* batch, int n
     case 20: fn = use_sqloss ? (void*)solve_one_kernel<20, true, 256> : (void*)solve_one_kernel<20, false, 256>; break;
     default: return hipErrorInvalidValue;
   }
-  hipError_t e = hipMemsetAsync(sync, 0, sizeof(unsigned) * (size_t)(max_evals + 1), st);
-  if (e != hipSuccess) return e;
-  void* args[] = {(void*)&batch, (void*)&sync, (void*)&max_evals};
-  return hipLaunchKernel(fn, dim3(n_chunks), dim3(256), args, solo_smem_bytes(K), st);
+  void* kargs[] = {(void*)&args};
+  return hipLaunchKernel(fn, dim3(n_chunks + 1), dim3(256), kargs, solo_smem_bytes(K), st);
 }
 
 hipError_t launch_lm_step_batch(const BatchHeader* hdr, const BatchArgs* batch, int capacity, hipStream_t st) {

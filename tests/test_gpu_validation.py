@@ -226,27 +226,59 @@ def test_inner_solve_through_runs_of_rejected_steps(mode):
 
 @pytest.mark.parametrize("mode", [sicp.MODE_EM, sicp.MODE_GICP, sicp.MODE_SEMANTIC])
 def test_one_pair_alone_persistent_solve_equals_the_tick_graph_and_the_host_loop(mode):
-    """lm_on_device = 3: sicp_align of ONE pair runs every inner solve as one persistent launch (solve_one_kernel:
-    one workgroup per chunk, one device-wide wait per evaluation, every workgroup advancing its own copy of the
-    trust-region state).  1 is the [accumulate, LM step] graph of ticks, 0 the host loop: the same kernels'
-    routines, the same machine -- the three must agree bit for bit, poses and every counter; sizes from one
-    chunk to the chip's 256 (beyond, 3 falls back to the ticks)."""
+    """lm_on_device = 1 (the default): the only pair still iterating -- here sicp_align of ONE pair -- runs its inner
+    solves as persistent launches (solve_one_kernel: one workgroup per chunk keeps the chunk in registers, a master
+    workgroup sums the columns and steps the trust-region machine, two fence-free hand-offs per evaluation).  2 is
+    the [accumulate, LM step] graph of ticks only, 0 the host loop: the same routines, the same machine -- the three
+    must agree bit for bit, poses and every counter; sizes from one chunk to beyond the chip's 255 workers (where 1
+    is the tick graph again)."""
     cm = synth.confusion_matrix(11)
     em = mode == sicp.MODE_EM
-    for n_src, n_tgt, seed in ((700, 900, 3), (20000, 20000, 2), (100000, 100000, 4), (131000, 90000, 5), (150000, 150000, 6)):
+    for n_src, n_tgt, seed in ((700, 900, 3), (20000, 20000, 2), (100000, 100000, 4), (130500, 90000, 5), (150000, 150000, 6)):
         src, sl, tgt, tl, T_gt, _ = synth.lidar_pair(seed=seed, n_points=max(n_src, n_tgt) if max(n_src, n_tgt) <= 141000 else None)
         src, sl, tgt, tl = src[:n_src], sl[:n_src], tgt[:n_tgt], tl[:n_tgt]
         got = {}
-        for lm in (3, 1, 0):
+        for lm in (1, 2, 0):
             with make_engine(mode, 11 if em else 0, cm if em else None, lm_on_device=lm) as e:
                 e.set_source(src, sl if mode != sicp.MODE_GICP else None)
                 e.set_target(tgt, tl if mode != sicp.MODE_GICP else None)
                 qt, st = e.align(IDENT)
-                qt2, st2 = e.align(IDENT)      # again on the same handle: the counters of the launch are fresh
+                qt2, st2 = e.align(IDENT)      # again on the same handle: the hand-off words of the launch are fresh
                 assert np.array_equal(qt, qt2) and st["total_evals"] == st2["total_evals"]
                 got[lm] = (qt, st)
-        for lm in (1, 0):
-            assert np.array_equal(got[3][0], got[lm][0]), (n_src, lm)
+        for lm in (2, 0):
+            assert np.array_equal(got[1][0], got[lm][0]), (n_src, lm)
             for key in ("outer_iters", "total_lm_iters", "total_evals", "total_corr", "total_active"):
-                assert got[3][1][key] == got[lm][1][key], (n_src, lm, key)
-            assert got[3][1]["final_cost"] == got[lm][1]["final_cost"]
+                assert got[1][1][key] == got[lm][1][key], (n_src, lm, key)
+            assert got[1][1]["final_cost"] == got[lm][1]["final_cost"]
+        if n_src * (4 if em else 1) <= 255 * 2048:   # the persistent path did run: one launch per (part of an) inner solve
+            assert got[1][1]["acc_launches"] < got[2][1]["acc_launches"], (n_src, got[1][1]["acc_launches"], got[2][1]["acc_launches"])
+
+
+def test_persistent_solve_falls_back_to_the_ticks_when_its_grid_is_not_resident():
+    """SICP_SOLO_SPIN=0 makes the first unsuccessful poll of a persistent launch give up -- what happens when other work
+    keeps its workgroups from becoming resident together.  The launch must leave the trust-region state untouched,
+    the host must carry on with [accumulate, LM step] ticks, and the result must be the very same bits."""
+    import os, subprocess, sys, json
+    code = r"""
+import json, sys, os
+sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import importlib, numpy as np, synth
+sicp = importlib.import_module("semantic-icp_amd")
+cm = synth.confusion_matrix(11)
+src, sl, tgt, tl, T, _ = synth.lidar_pair(seed=9, n_points=30000)
+out = {}
+for lm in (1, 2):
+    p = sicp.default_params(sicp.MODE_EM); p.lm_on_device = lm; p.num_classes = 11
+    with sicp.Engine(0, p) as e:
+        e.set_confusion(cm)
+        e.set_source(src, sl); e.set_target(tgt, tl)
+        qt, st = e.align(np.array([0, 0, 0, 1, 0, 0, 0], dtype=np.float64))
+        out[lm] = [qt.tobytes().hex(), st["total_evals"], st["outer_iters"]]
+print(json.dumps(out))
+"""
+    env = dict(os.environ, SICP_SOLO_SPIN="0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["1"] == out["2"], out
