@@ -263,7 +263,7 @@ struct SoloArgs {
   AccArgs a;           // the pair; a.lm_step = its trust-region state in HBM
   unsigned* sync;      // kSoloSyncWords hand-off words (+ 16 developer timers)
   int max_evals;       // evaluations this launch may run
-  int spin_limit;      // polls before a wait gives up
+  int wait_ticks;      // 100 MHz ticks before a wait gives up
   unsigned tag_base;   // the launch's hand-off tags are tag_base + 1 ... tag_base + max_evals: older words never match
   int init;            // 1: the inner solve starts with this launch (state := lm_init(opt, start)), 0: it continues
   int seq;             // written to the state's pad_ word at a regular end: the host's proof the launch ran to it
@@ -272,7 +272,7 @@ struct SoloArgs {
   LmOptions opt;
 };
 hipError_t launch_solve_one(int K, int use_sqloss, const SoloArgs& args, int n_chunks, hipStream_t st);
-int solo_spin_limit();
+int solo_wait_ticks();
 hipError_t launch_count_active(const int* idx, int n, unsigned long long* out, hipStream_t st);
 // test hook: csrc/se3.hpp on the device, one lane per item (op = SICP_SE3_*; in/out strides per op)
 hipError_t launch_se3_ops(int op, int n, const double* in, double* out, hipStream_t st);

@@ -284,7 +284,7 @@ struct sicp_context {
   unsigned solo_tag = 0;              // its tags so far (a launch uses solo_tag + 1 ...: the words are never zeroed in between)
   int solo_seq = 0, solo_pair = 0;    // launch counter (the state's pad_ word echoes it at a regular end) and the pair's state slot
   bool solo_was_init = false, solo_failed = false;  // the launch in flight starts a solve / the last one did not run to its end
-  bool solo_off = false;              // a persistent solve timed out once: this handle stays with the tick graph
+  int solo_skip = 0, solo_penalty = 0;  // after a persistent launch timed out: solves that stay with the tick graph before the next try (doubling)
   bool count_stats = false;           // the align() in progress reports statistics: every search also counts its live slots
   DevBuf<double> d_bout28;
   sicp::LmState* h_bstates = nullptr;
@@ -329,6 +329,7 @@ struct sicp_stream_ctx {
   std::unordered_map<long long, std::shared_ptr<Cloud>> clouds;
   long long next_cloud = 1, next_ticket = 1;
   long long submitted = 0, completed = 0, busy_evals = 0, slot_evals = 0;
+  int draining = 0;  // callers blocked in sicp_stream_poll(wait >= 2): nothing new will be submitted by them meanwhile
   int in_flight = 0;
   bool stop = false;
   int error = 0;
@@ -910,6 +911,12 @@ struct SolveResult {
   double cost = 0;
 };
 
+// may the next launch of this leader be a persistent one?  (after a timed-out launch a number of them are not)
+bool solo_allowed(sicp_context* h) {
+  if (h->solo_skip > 0) { --h->solo_skip; return false; }
+  return true;
+}
+
 // the inner ceres::Solve (em_icp.hpp:162-177) on the current correspondences
 int run_solve(sicp_context* h, const double* init_qt, double* out_qt, SolveResult* res) {
   const sicp_params& P = h->params;
@@ -937,7 +944,7 @@ int run_solve(sicp_context* h, const double* init_qt, double* out_qt, SolveResul
   std::memcpy(start[0], init_qt, sizeof start[0]);
   std::vector<int> act(1, 0), joining(1, 0);
   for (;;) {
-    const bool solo = P.lm_on_device != 2 && !h->solo_off && sicp::solve_one_fits(h->corr_n * h->corr_K, h->corr_K);
+    const bool solo = P.lm_on_device != 2 && solo_allowed(h) && sicp::solve_one_fits(h->corr_n * h->corr_K, h->corr_K);
     SICPCHECK(run_tick(h, h->stream, &self, 1, act, joining, start, len, solo ? sicp::kSoloMaxEvals : 0));
     if (solo && h->solo_failed) continue;  // nothing has happened: the same step again as a tick
     joining.clear();
@@ -1185,7 +1192,7 @@ int tick_launch(sicp_context* h, TickSet& S, hipStream_t M, sicp_handle* hs, int
     A.a.lm = A.a.lm_step = h->d_bstates.p + p;
     A.sync = h->d_solo_sync.p;
     A.max_evals = evals;
-    A.spin_limit = sicp::solo_spin_limit();
+    A.wait_ticks = sicp::solo_wait_ticks();
     A.tag_base = h->solo_tag;
     h->solo_tag += (unsigned)evals + 1u;
     A.init = joining.empty() ? 0 : 1;
@@ -1262,7 +1269,8 @@ int solo_check(sicp_context* h) {
   // [accumulate, LM step] ticks, and this handle stays with them.
   h->solo_failed = h->h_bstates[h->solo_pair].pad_ != h->solo_seq;
   if (h->solo_failed) {
-    h->solo_off = true;
+    h->solo_penalty = std::min(std::max(2 * h->solo_penalty, 8), 4096);
+    h->solo_skip = h->solo_penalty;
     HIPCHECK(hipMemsetAsync(h->d_solo_sync.p, 0, sizeof(unsigned) * sicp::kSoloSyncWords, h->stream));
     HIPCHECK(hipStreamSynchronize(h->stream));
     h->solo_tag = 0;
@@ -1464,11 +1472,11 @@ int BatchRun::turn(TickGroup& G, JobCollector& jc) {
   // itself: its solve continues as persistent launches (of at most 64 evaluations when other slots may fill up
   // meanwhile: a stream's new registrations are admitted between launches).
   solo_now = false;
-  if (solo && !L->solo_off && G.act.size() == 1) {
+  if (solo && G.act.size() == 1) {
     int live_all = 0;
     for (int p = 0; p < n; ++p) live_all += phase[p] != PAIR_FREE && phase[p] != PAIR_DONE;
     const sicp_context* g = hs[G.act[0]];
-    solo_now = live_all == 1 && sicp::solve_one_fits(g->corr_n * g->corr_K, g->corr_K);
+    solo_now = live_all == 1 && sicp::solve_one_fits(g->corr_n * g->corr_K, g->corr_K) && solo_allowed(L);
   }
   int rc = tick_launch(h, *G.S, G.M, hs, G.lo, G.hi, G.act, G.joining, reinterpret_cast<const double(*)[7]>(starts.data()), len,
                        solo_now ? (n == 1 ? sicp::kSoloMaxEvals : 64) : 0);
@@ -2001,7 +2009,6 @@ void stream_worker(sicp_stream_ctx* S) {
   sicp_context* L = S->slots[0];
   BatchRun run;
   run.L = L; run.hs = S->slots.data(); run.P = S->params; run.one_launch = true; run.want_stats = false;
-  run.solo = S->params.lm_on_device != 2;
   run.resize(S->cap);
   run.len = std::min(S->params.lm_batch > 0 ? S->params.lm_batch : 8, sicp::kMaxBatchLen);
   run.side = L->side_stream;
@@ -2029,6 +2036,10 @@ void stream_worker(sicp_stream_ctx* S) {
         ++S->in_flight;
       }
       if (!fresh.empty()) S->cv_space.notify_all();
+      // The last registration of a stream that is being drained may run its solves as persistent launches.  Not
+      // otherwise: a stream that has just begun is alone for a moment too, and the next registrations' feature
+      // kernels would then compete with the persistent grid for the CUs it needs all at once.
+      run.solo = S->params.lm_on_device != 2 && S->draining > 0 && S->queue.empty();
     }
     out.clear();
     for (size_t k = 0; k < fresh.size(); ++k) {
@@ -2255,8 +2266,11 @@ int sicp_stream_poll(sicp_stream S, int32_t wait, int32_t max_results, sicp_stre
   const long long want = S->submitted;
   if (wait == 1)
     S->cv_done.wait(lock, [&] { return S->stop || S->error != SICP_OK || !S->done.empty() || S->completed >= S->submitted; });
-  else if (wait >= 2)
+  else if (wait >= 2) {
+    ++S->draining;
     S->cv_done.wait(lock, [&] { return S->stop || S->error != SICP_OK || S->completed >= want; });
+    --S->draining;
+  }
   int k = 0;
   while (k < max_results && !S->done.empty()) {
     results[k++] = S->done.front();

@@ -795,7 +795,7 @@ __global__ __launch_bounds__(BS, 1) void solve_one_kernel(const SoloArgs A) {
   char* log_tab = reinterpret_cast<char*>(smem + NW * RED_ROWS * RED_STRIDE);
   const int lane = threadIdx.x & 63, wave = uniform_i32((int)(threadIdx.x >> 6));
   const AccArgs& a = A.a;
-  const int max_evals = A.max_evals, spin_limit = A.spin_limit;
+  const int max_evals = A.max_evals, wait_ticks = A.wait_ticks;
   const unsigned tag_base = A.tag_base;
   unsigned* const sync = A.sync;
   LoadCtx L;
@@ -843,10 +843,13 @@ __global__ __launch_bounds__(BS, 1) void solve_one_kernel(const SoloArgs A) {
       tprev = __builtin_readcyclecounter();
 #endif
       if ((int)threadIdx.x < n_chunks) {
-        int spins = 0;
-        while (__hip_atomic_load(&flags[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
+        unsigned long long t0 = 0;
+        for (int spins = 0; __hip_atomic_load(&flags[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want; ++spins) {
           __builtin_amdgcn_s_sleep(1);
-          if (++spins > spin_limit || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+          if ((spins & 15) != 15 && wait_ticks > 0) continue;  // the clock and the abort word every 16th poll
+          const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+          if (t0 == 0) t0 = now;
+          if (now - t0 >= (unsigned long long)wait_ticks || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
             __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_abort = 1;
             break;
@@ -967,14 +970,18 @@ __global__ __launch_bounds__(BS, 1) void solve_one_kernel(const SoloArgs A) {
       if (threadIdx.x == 0) __hip_atomic_store(&flags[b], want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       SOLO_MARK(1);
       const int gl = min(lane, kSoloGranules - 1);
-      for (int spins = 0;;) {
+      unsigned long long t0 = 0;
+      for (int spins = 0;; ++spins) {
         const u64 x = __hip_atomic_load(gran + gl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (__all((unsigned)(x >> 32) == want)) {
           if (lane < kSoloGranules) s_gran[lane] = (unsigned)x;
           break;
         }
         __builtin_amdgcn_s_sleep(1);
-        if (++spins > spin_limit || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+        if ((spins & 15) != 15 && wait_ticks > 0) continue;  // the clock and the abort word every 16th poll
+        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+        if (t0 == 0) t0 = now;
+        if (now - t0 >= (unsigned long long)wait_ticks || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
           if (lane == 0) {
             __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_abort = 1;
@@ -1080,10 +1087,12 @@ bool solve_one_fits(int total, int K) {
   return !off && total > 0 && accumulate_blocks(total, K) + 1 <= (cus < 257 ? cus : 257) && acc_geometry(total, acc_slots_per_group(K)).steps == 8 / acc_slots_per_group(K);
 }
 
-// polls (a memory round trip + s_sleep each, ~1 us) before a wait of the persistent solve gives up: ~0.1 s.
-// SICP_SOLO_SPIN: test aid (0 = the first unsuccessful poll gives up, which exercises the host's fallback to the ticks)
-int solo_spin_limit() {
-  static const int v = [] { const char* e = getenv("SICP_SOLO_SPIN"); return e ? atoi(e) : 1 << 17; }();
+// How long a wait of the persistent solve may last before it gives up, in ticks of the 100 MHz constant clock: 5 ms
+// (a hand-off normally takes microseconds; a grid that is not resident as a whole will not become so while its
+// resident part spins).  SICP_SOLO_WAIT_TICKS: test aid (0 = the first unsuccessful poll gives up, which exercises the
+// host's fallback to the ticks).
+int solo_wait_ticks() {
+  static const int v = [] { const char* e = getenv("SICP_SOLO_WAIT_TICKS"); return e ? atoi(e) : 500000; }();
   return v;
 }
 

@@ -256,7 +256,7 @@ def test_one_pair_alone_persistent_solve_equals_the_tick_graph_and_the_host_loop
 
 
 def test_persistent_solve_falls_back_to_the_ticks_when_its_grid_is_not_resident():
-    """SICP_SOLO_SPIN=0 makes the first unsuccessful poll of a persistent launch give up -- what happens when other work
+    """SICP_SOLO_WAIT_TICKS=0 makes the first unsuccessful poll of a persistent launch give up -- what happens when other work
     keeps its workgroups from becoming resident together.  The launch must leave the trust-region state untouched,
     the host must carry on with [accumulate, LM step] ticks, and the result must be the very same bits."""
     import os, subprocess, sys, json
@@ -274,10 +274,10 @@ for lm in (1, 2):
         e.set_confusion(cm)
         e.set_source(src, sl); e.set_target(tgt, tl)
         qt, st = e.align(np.array([0, 0, 0, 1, 0, 0, 0], dtype=np.float64))
-        out[lm] = [qt.tobytes().hex(), st["total_evals"], st["outer_iters"]]
+        out[lm] = [qt.tobytes().hex(), st["total_evals"], st["outer_iters"], st["acc_launches"]]   # (no persistent launch counted)
 print(json.dumps(out))
 """
-    env = dict(os.environ, SICP_SOLO_SPIN="0")
+    env = dict(os.environ, SICP_SOLO_WAIT_TICKS="0")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
