@@ -218,7 +218,7 @@ double now_ms() {
 constexpr int kParts = 4;  // slices of a batch whose stage sequences run on their own streams
 
 struct JobCollector {
-  int knn_K = 0;
+  int knn_K[kParts] = {};  // list length of a slice's searches (one launch per slice: one length)
   int slice = 0;  // slice of the batch the pair whose stage is running belongs to (set by the driver)
   std::vector<sicp::KnnArgs> knn[kParts];
   std::vector<sicp::CovArgs> cov[kParts];
@@ -595,8 +595,13 @@ int run_nn(sicp_context* h, int K, const Cloud& Qc, int q_begin, int q_count, co
     if (want_dbg) { HIPCHECK(dbg.reserve((size_t)2 * q_count)); a.dbg = dbg.p; }
     static const bool lane_per_query = std::getenv("SICP_KNN_LANE_PER_QUERY") != nullptr;  // A/B aid
     if (h->collect) {  // lock-step batch (packet search, no profiling: checked by the driver)
-      h->collect->knn_K = L;
-      h->collect->knn[h->collect->slice].push_back(a);
+      JobCollector& jc = *h->collect;
+      if (!jc.knn[jc.slice].empty() && jc.knn_K[jc.slice] != L) {
+        h->last_error = "internal: searches of two list lengths collected into one slice";
+        return SICP_ERR_INVALID_ARGUMENT;
+      }
+      jc.knn_K[jc.slice] = L;
+      jc.knn[jc.slice].push_back(a);
       return SICP_OK;
     }
     KernelTimer kt(h, stream == h->stream ? timer_bit : 0);
@@ -776,6 +781,7 @@ int segment_of(const Cloud& c, uint32_t label) {
 
 // transform + kNN + gate (+ EM weight) at pose qt: the loop em_icp.hpp:46-108
 int count_active(sicp_context* h);
+int run_weights(sicp_context* h, const double* qt);
 
 int run_correspondences(sicp_context* h, const double* qt, int K, bool weights) {
   const sicp_params& P = h->params;
@@ -807,7 +813,23 @@ int run_correspondences(sicp_context* h, const double* qt, int K, bool weights) 
     h->st.t_nn_ms += now_ms() - t0;
   }
   h->corr_weighted = false;
-  if (weights && P.mode == SICP_MODE_EM) {
+  h->corr_n = S.n;
+  h->corr_K = K;
+  h->corr_valid = true;
+  h->hint_ok = true;
+  // statistics: the live slots of this search, counted right behind it (same stream / same job flush: no extra
+  // host turn between two solves)
+  if (h->count_stats) SICPCHECK(count_active(h));
+  if (weights) SICPCHECK(run_weights(h, qt));
+  return SICP_OK;
+}
+
+// the EM weights of the current correspondences (em_icp.hpp:62-107): what run_correspondences(..., true) ends with
+int run_weights(sicp_context* h, const double* qt) {
+  const sicp_params& P = h->params;
+  Cloud &S = h->cloud(0), &T = h->cloud(1);
+  const int K = h->corr_K;
+  if (P.mode == SICP_MODE_EM) {
     KernelTimer kt(h, SICP_PROFILE_WEIGHT);
     const double t0 = now_ms();
     sicp::WeightArgs a;
@@ -828,13 +850,6 @@ int run_correspondences(sicp_context* h, const double* qt, int K, bool weights) 
     h->st.t_weight_ms += now_ms() - t0;
     h->corr_weighted = true;
   }
-  h->corr_n = S.n;
-  h->corr_K = K;
-  h->corr_valid = true;
-  h->hint_ok = true;
-  // statistics: the live slots of this search, counted right behind it (same stream / same job flush: no extra
-  // host turn between two solves)
-  if (h->count_stats) SICPCHECK(count_active(h));
   return SICP_OK;
 }
 
@@ -1119,7 +1134,7 @@ int flush_jobs(sicp_context* h, JobCollector& jc, hipStream_t base = nullptr) {
     if (!used[s]) continue;
     hipStream_t st = s ? h->part_stream[s] : base;
     if (s) HIPCHECK(hipStreamWaitEvent(st, h->part_fork, 0));
-    if (!jc.knn[s].empty()) HIPCHECK(sicp::launch_bvh_knn_packet_jobs(jc.knn_K, jc.knn[s].data(), (int)jc.knn[s].size(), st));
+    if (!jc.knn[s].empty()) HIPCHECK(sicp::launch_bvh_knn_packet_jobs(jc.knn_K[s], jc.knn[s].data(), (int)jc.knn[s].size(), st));
     if (!jc.cov[s].empty()) HIPCHECK(sicp::launch_cov_jobs(jc.cov[s].data(), (int)jc.cov[s].size(), st));
     if (!jc.proj[s].empty()) HIPCHECK(sicp::launch_proj_jobs(jc.proj[s].data(), (int)jc.proj[s].size(), st));
     if (!jc.weight[s].empty()) HIPCHECK(sicp::launch_em_weight_jobs(jc.weight[s].data(), (int)jc.weight[s].size(), st));
@@ -1816,6 +1831,7 @@ int sicp_align_batch(sicp_handle* hs, int32_t n, const double* init_qt, double* 
   // ones instead of ~50 ms of features for all 512 clouds before the first tick.  The GPU is work-bound, so this only
   // fills the ramp: 2.09 -> 2.12 G corr/s at 256 pairs (chunks of 8 ... 32 alike, 64 and more lose it again).
   const bool staged = one_launch && n > 48;
+  const bool early_first = one_launch && n <= 4;  // (never staged: that starts at 49 pairs)
   static const int kStartChunk = [] { const char* e = std::getenv("SICP_START_CHUNK"); const int v = e ? std::atoi(e) : 32; return v > 0 ? v : 32; }();  // tuning aid
   if (!staged) {  // (a staged batch queues its start-up pipelines below, once the run exists)
     for (int p = 0; p < n; ++p) {
@@ -1824,7 +1840,23 @@ int sicp_align_batch(sicp_handle* hs, int32_t n, const double* init_qt, double* 
       SICPCHECK(align_begin(hs[p], stats != nullptr));
     }
     if (one_launch) {
+      if (early_first) {
+        // A few pairs alone: the first search (pose = the initial guess) needs none of the features, only the weights
+        // behind it do -- it is collected into a slice of its own, i.e. runs on its own stream beside the
+        // self-searches / covariances / projections; the weights follow once both have been queued.
+        for (int p = 0; p < n; ++p) {
+          jc.slice = kParts - 1;
+          SICPCHECK(run_correspondences(hs[p], init_qt + 7 * p, P.knn, false));
+        }
+      }
       SICPCHECK(flush_jobs(L, jc));
+      if (early_first) {
+        for (int p = 0; p < n; ++p) {
+          jc.slice = 0;
+          SICPCHECK(run_weights(hs[p], init_qt + 7 * p));
+        }
+        SICPCHECK(flush_jobs(L, jc));
+      }
     } else {
       // per-pair launches on the pairs' own streams: a cloud shared by two pairs has just been given
       // its features on ONE of them
@@ -1855,6 +1887,14 @@ int sicp_align_batch(sicp_handle* hs, int32_t n, const double* init_qt, double* 
   run.solo = one_launch && P.lm_on_device != 2;
   run.resize(n);
   for (int p = 0; p < n; ++p) run.start_pair(p, init_qt + 7 * p);
+  if (early_first)  // (their first search is on its way: what BatchRun::turn does for a pair between two solves)
+    for (int p = 0; p < n; ++p) {
+      OuterState& o = run.o[p];
+      std::memcpy(o.est, o.cur, sizeof o.est);
+      if (P.mode == SICP_MODE_SEMANTIC) o.count++;
+      run.phase[p] = PAIR_JOINING;
+      run.search_round[p] = 0;
+    }
   if (staged) {
     sicp_context* h = L;
     if (!h->feat_stream) HIPCHECK(hipStreamCreateWithFlags(&h->feat_stream, hipStreamNonBlocking));
@@ -2324,7 +2364,7 @@ int sicp_search_batch(sicp_handle* hs, int32_t n, const double* qt, int32_t what
     }
   }
   if (repeat < 1) repeat = 1;
-  const int L = jc.knn_K;
+  const int L = jc.knn_K[0];
   HIPCHECK(hipEventRecord(h->ev0, h->stream));
   for (int r = 0; r < repeat; ++r)
     if (!jc.knn[0].empty()) HIPCHECK(sicp::launch_bvh_knn_packet_jobs(L, jc.knn[0].data(), (int)jc.knn[0].size(), h->stream));
