@@ -282,3 +282,47 @@ print(json.dumps(out))
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["1"] == out["2"], out
+
+
+def test_two_host_threads_aligning_their_own_pairs_concurrently():
+    """Two host threads, each with its own handle and pair, call sicp_align at the same time: two persistent grids
+    compete for the chip -- whichever way the dispatcher interleaves them (one waits for the other, or neither becomes
+    resident as a whole and both fall back to the ticks after their bounded wait) every result must be the bits of
+    the same align() made alone."""
+    import threading
+    cm = synth.confusion_matrix(11)
+    pairs = [synth.lidar_pair(seed=s, n_points=60000)[:4] for s in (21, 22)]
+    alone = []
+    for src, sl, tgt, tl in pairs:
+        with make_engine(sicp.MODE_EM, 11, cm) as e:
+            e.set_source(src, sl); e.set_target(tgt, tl)
+            alone.append(e.align(IDENT))
+    engines = []
+    for src, sl, tgt, tl in pairs:
+        e = make_engine(sicp.MODE_EM, 11, cm)
+        e.set_source(src, sl); e.set_target(tgt, tl)
+        engines.append(e)
+    got = [[None] * 6 for _ in engines]
+    errors = []
+
+    def work(k):
+        try:
+            for r in range(6):
+                got[k][r] = engines[k].align(IDENT)
+        except Exception as ex:  # noqa: BLE001
+            errors.append(ex)
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(len(engines))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for e in engines:
+        e.close()
+    assert not errors, errors
+    for k in range(len(engines)):
+        for r in range(6):
+            qt, st = got[k][r]
+            assert np.array_equal(qt, alone[k][0]), (k, r)
+            for key in ("outer_iters", "total_lm_iters", "total_evals"):
+                assert st[key] == alone[k][1][key], (k, r, key)
