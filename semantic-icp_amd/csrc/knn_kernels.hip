@@ -441,10 +441,7 @@ __device__ __forceinline__ float quad_bound(const u64 (&bk)[K]) {
 // chain each; some lane of the wave almost always inserts, so the wave almost always ran them all).
 // Candidates beyond the quad bound may now enter a lane's list; they are beyond the true K-th
 // distance, so the merged result -- the K smallest keys of everything seen -- is the same.
-__device__ __forceinline__ void scan_leaf_quad4(const float4* __restrict__ pts, float px, float py, float pz, u64 (&bk)[4], float& wd) {
-  float4 t[4];
-#pragma unroll
-  for (int p = 0; p < 4; ++p) t[p] = pts[4 * p];
+__device__ __forceinline__ void scan_points_quad4(const float4 (&t)[4], float px, float py, float pz, u64 (&bk)[4], float& wd) {
   u64 c[4];
 #pragma unroll
   for (int p = 0; p < 4; ++p) c[p] = make_key(l2_simple(px, py, pz, t[p].x, t[p].y, t[p].z), __float_as_uint(t[p].w));
@@ -461,12 +458,10 @@ __device__ __forceinline__ void scan_leaf_quad4(const float4* __restrict__ pts, 
   wd = quad_bound<4>(bk);
 }
 
+// t = the lane's four points of the leaf: lane s of the quad takes points s, s+4, s+8, s+12 (a mixed quarter)
 template <int K>
-__device__ __forceinline__ void scan_leaf_quad(const float4* __restrict__ pts, float px, float py, float pz, u64 (&bk)[K], float& wd) {
-  if constexpr (K == 4) { scan_leaf_quad4(pts, px, py, pz, bk, wd); return; }
-  float4 t[4];
-#pragma unroll
-  for (int p = 0; p < 4; ++p) t[p] = pts[4 * p];  // lane s of the quad takes points s, s+4, s+8, s+12: a mixed quarter
+__device__ __forceinline__ void scan_points_quad(const float4 (&t)[4], float px, float py, float pz, u64 (&bk)[K], float& wd) {
+  if constexpr (K == 4) { scan_points_quad4(t, px, py, pz, bk, wd); return; }
   if constexpr (K >= 8) {
     // Long lists: an insertion is 2 K instructions and the WAVE runs it whenever any of its 64 lanes
     // inserts.  The lane's 4 candidates are sorted first (10 instructions); a lane then inserts them in
@@ -496,6 +491,14 @@ __device__ __forceinline__ void scan_leaf_quad(const float4* __restrict__ pts, f
   wd = quad_bound<K>(bk);
 }
 
+template <int K>
+__device__ __forceinline__ void scan_leaf_quad(const float4* __restrict__ pts, float px, float py, float pz, u64 (&bk)[K], float& wd) {
+  float4 t[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) t[p] = pts[4 * p];
+  scan_points_quad<K>(t, px, py, pz, bk, wd);
+}
+
 __device__ __forceinline__ unsigned child_mask_quad(const float4* __restrict__ blo, const float4* __restrict__ bhi, int child_off,
                                                     int child_cnt, int parent, int sub, int lane, float px, float py, float pz,
                                                     float wd) {
@@ -520,7 +523,8 @@ __global__ __launch_bounds__(64) void bvh_knn_quad_kernel(KnnArgs a) {
   u64 bk[K];
   key_list_init<K>(bk);
   float wd = INFINITY;
-  const float4* __restrict__ pts = a.tree.pts4 + a.tree.pt_begin + sub;
+  const float4* __restrict__ pts_all = a.tree.pts4 + a.tree.pt_begin;
+  const float4* __restrict__ pts = pts_all + sub;
   const float4* __restrict__ blo = a.tree.box_lo + a.tree.node_begin;
   const float4* __restrict__ bhi = a.tree.box_hi + a.tree.node_begin;
   const int top = a.tree.lv.n_levels - 1;
@@ -665,6 +669,28 @@ __device__ __forceinline__ int locate_leaf(const u64* __restrict__ codes, int to
 
 constexpr int kWalkLevels = kMaxLevels - 1;  // levels that carry sibling bounds (every level but the root)
 
+// The four leaves below a level-1 node are 64 consecutive points = 1 KB: ONE LDS-DMA instruction (global_load_lds,
+// 16 bytes per lane, no destination registers) brings them into a wave-private buffer together with the load of
+// their four boxes, so the leaves that pass the box test are scanned from LDS without another round trip to memory.
+#ifndef SICP_KNN_DMA_MAXK
+#define SICP_KNN_DMA_MAXK 4  // list lengths whose walk buffers leaf groups in LDS (tuning aid; longer lists measured slower with it)
+#endif
+#define KNN_LDS __attribute__((address_space(3)))
+#define KNN_GLOBAL __attribute__((address_space(1)))
+typedef float knn_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void dma_leaf_group(const float4* __restrict__ pts_all, unsigned group, KNN_LDS knn_v4f* buf, int lane) {
+  const float4* p = pts_all + (size_t)group * (kFan * kLeaf) + lane;
+  __builtin_amdgcn_global_load_lds((const KNN_GLOBAL void*)p, (KNN_LDS void*)buf, 16, 0, 0);
+}
+// the calling lane's four points (sub, sub + 4, sub + 8, sub + 12) of leaf c of the buffered group
+__device__ __forceinline__ void lds_leaf_points(const KNN_LDS knn_v4f* buf, unsigned c, int sub, float4 (&t)[4]) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const knn_v4f v = buf[c * kLeaf + sub + 4 * p];
+    t[p] = make_float4(v.x, v.y, v.z, v.w);
+  }
+}
+
 // WPB waves (packets) per workgroup: one-wave workgroups are launched too slowly to fill the chip
 // (6250 of them at 100K queries: ~1.5 waves per SIMD resident on average)
 template <int K, int WPB>
@@ -676,6 +702,9 @@ __device__ __forceinline__ void knn_packet_body(const KnnArgs& a, int wg, int n_
   constexpr size_t kMergeBytes = sizeof(u64) * 16 * 4 * K, kLbBytes = sizeof(float) * kWalkLevels * 64;
   constexpr size_t kWaveBytes = kMergeBytes > kLbBytes ? kMergeBytes : kLbBytes;
   __shared__ __attribute__((aligned(16))) unsigned char s_wave_all[WPB][kWaveBytes];
+  constexpr bool kDma = K <= SICP_KNN_DMA_MAXK;
+  __shared__ __attribute__((aligned(16))) float4 s_pts_all[kDma ? WPB : 1][kDma ? kFan * kLeaf : 1];  // the leaf group the walk is in (dma_leaf_group)
+  KNN_LDS knn_v4f* const s_pts = (KNN_LDS knn_v4f*)s_pts_all[kDma ? (threadIdx.x >> 6) : 0];
   u64 (&s_merge)[16][4][K] = *reinterpret_cast<u64 (*)[16][4][K]>(s_wave_all[threadIdx.x >> 6]);
   float (&s_lb)[kWalkLevels][64] = *reinterpret_cast<float (*)[kWalkLevels][64]>(s_wave_all[threadIdx.x >> 6]);
   const int lane = threadIdx.x & 63, sub = lane & 3, slot = lane >> 2;
@@ -688,7 +717,8 @@ __device__ __forceinline__ void knn_packet_body(const KnnArgs& a, int wg, int n_
   u64 bk[K];
   key_list_init<K>(bk);
   float wd = INFINITY;
-  const float4* __restrict__ pts = a.tree.pts4 + a.tree.pt_begin + sub;
+  const float4* __restrict__ pts_all = a.tree.pts4 + a.tree.pt_begin;
+  const float4* __restrict__ pts = pts_all + sub;
   const float4* __restrict__ blo = a.tree.box_lo + a.tree.node_begin;
   const float4* __restrict__ bhi = a.tree.box_hi + a.tree.node_begin;
   const int top = a.tree.lv.n_levels - 1;
@@ -736,6 +766,7 @@ __device__ __forceinline__ void knn_packet_body(const KnnArgs& a, int wg, int n_
     u64 masks = 0;  // 4 sibling bits per level
     float cur_lb = 0.f;  // this lane's bound for child `sub` on the level the walk stands on
     constexpr int PB = 4;  // levels per round trip of the path phase
+    if constexpr (kDma) dma_leaf_group(pts_all, (unsigned)seed_leaf >> 2, s_pts, lane);  // the seed's leaf group travels with the path's boxes
     for (int L0 = 0; L0 < top; L0 += PB) {
       float4 lo[PB], hi[PB];
 #pragma unroll
@@ -765,22 +796,32 @@ __device__ __forceinline__ void knn_packet_body(const KnnArgs& a, int wg, int n_
       // the 16 seed candidates of a lane all enter its (empty) list.  Sixteen insertions are 16 x 39
       // instructions; writing them into the first 16 slots and sorting those with a 63-comparator network is
       // 126 (same list: the keys are unique up to identical padding keys).
-      const int l0 = seed_leaf & ~3;
+      if constexpr (kDma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the group has landed in LDS
 #pragma unroll
       for (int l = 0; l < kFan; ++l) {
-        const float4* __restrict__ lp = pts + (size_t)(l0 + l) * kLeaf;
+        float4 t[4];
+        if constexpr (kDma) {
+          lds_leaf_points(s_pts, (unsigned)l, sub, t);
+        } else {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-          const float4 t = lp[4 * p];
-          bk[4 * l + p] = make_key(l2_simple(px, py, pz, t.x, t.y, t.z), __float_as_uint(t.w));
+          for (int p = 0; p < 4; ++p) t[p] = pts[(size_t)((seed_leaf & ~3) + l) * kLeaf + 4 * p];
         }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) bk[4 * l + p] = make_key(l2_simple(px, py, pz, t[p].x, t[p].y, t[p].z), __float_as_uint(t[p].w));
       }
       key_sort16<K>(bk);
       wd = quad_bound<K>(bk);
       masks &= ~15ull;
       n_scan += 4;
     } else {
-      scan_leaf_quad<K>(pts + (size_t)seed_leaf * kLeaf, px, py, pz, bk, wd);
+      if constexpr (kDma) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the group has landed in LDS
+        float4 t[4];
+        lds_leaf_points(s_pts, (unsigned)seed_leaf & 3u, sub, t);
+        scan_points_quad<K>(t, px, py, pz, bk, wd);
+      } else {
+        scan_leaf_quad<K>(pts + (size_t)seed_leaf * kLeaf, px, py, pz, bk, wd);
+      }
       ++n_scan;
     }
     unsigned sh = 0u, ubase = (unsigned)seed_leaf & ~3u;
@@ -810,12 +851,21 @@ __device__ __forceinline__ void knn_packet_body(const KnnArgs& a, int wg, int n_
         ++n_box;
         sh -= 4u;
         ubase = node * kFan;
+        if constexpr (kDma)
+          if (sh == 0u) dma_leaf_group(pts_all, node, s_pts, lane);  // the children are leaves: their points travel with their boxes
         const unsigned cm = child_mask_packet(blo, bhi, (int)((t4 - (t4 >> (sh >> 1))) / 3u), (int)node, sub, px, py, pz, wd, cur_lb);
         masks |= (u64)cm << sh;  // (a level's sibling bits are zero when the walk descends into it)
         s_lb[sh >> 2][lane] = cur_lb;
       }
       if (leaf < 0) break;
-      scan_leaf_quad<K>(pts + (size_t)leaf * kLeaf, px, py, pz, bk, wd);
+      if constexpr (kDma) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the group's DMA was issued ahead of the box loads that put the walk here)
+        float4 t[4];
+        lds_leaf_points(s_pts, (unsigned)leaf & 3u, sub, t);
+        scan_points_quad<K>(t, px, py, pz, bk, wd);
+      } else {
+        scan_leaf_quad<K>(pts + (size_t)leaf * kLeaf, px, py, pz, bk, wd);
+      }
       ++n_scan;
     }
   }
