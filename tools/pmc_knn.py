@@ -80,8 +80,18 @@ for phase, kname in PHASES.items():
     insts = sum(c.get(k, 0.0) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"))
     if insts:
         ent["wave_instructions_per_dispatch"] = insts
-        ent["issue_frac"] = insts / (1024 * 2.4e9 * t)
-        ent["valu_issue_frac"] = c.get("SQ_INSTS_VALU", 0.0) / (1024 * 2.4e9 * t)
+        # A wave64 VALU instruction occupies its 16-lane SIMD for 4 cycles, and a SIMD issues to each pipe (vector,
+        # scalar, memory ...) at most once per 4-cycle round: the SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES / SQ_WAIT_* counters
+        # are in those 4-cycle units (SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU).  GRBM_GUI_ACTIVE is summed over the 8 XCDs.
+        rounds = c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0 / 4.0 if c.get("GRBM_GUI_ACTIVE") else 2.4e9 * t / 4.0
+        simds = 1024.0
+        ent["issue_rounds_per_simd"] = rounds
+        ent["valu_pipe_busy"] = c.get("SQ_ACTIVE_INST_VALU", c.get("SQ_INSTS_VALU", 0.0)) / (simds * rounds)
+        ent["scalar_pipe_busy"] = c.get("SQ_ACTIVE_INST_SCA", c.get("SQ_INSTS_SALU", 0.0)) / (simds * rounds)
+        if c.get("SQ_WAVE_CYCLES"):
+            ent["waves_per_simd_resident"] = c["SQ_WAVE_CYCLES"] / (simds * rounds)
+            ent["wave_time_waiting_frac"] = c.get("SQ_WAIT_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"]
+            ent["wave_time_issuing_frac"] = c.get("SQ_ACTIVE_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"]
         ent["bound"] = "issue"
         if "SQ_WAVES" in c and c["SQ_WAVES"]:
             ent["instructions_per_wave"] = insts / c["SQ_WAVES"]
