@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -34,16 +35,119 @@ namespace {
 
 using sicp::se3::matrix34;
 
+// ---- device memory arena -----------------------------------------------------------------------------
+// hipMalloc costs 0.1 ... several ms and hipFree synchronises the device; a stream of registrations creates
+// clouds and slot buffers all the time (a fresh cloud is ~26 buffers), on the very thread that feeds the GPU.
+// Device buffers therefore come from a process-wide arena per device: slabs (64 MB doubling to 1 GB, or the
+// request if larger) carved by a bump pointer into blocks of a few size classes (1/16 steps between powers of
+// two: at most ~12 % slack); a released block goes to its class's free list and is handed out again for the
+// same class.  Nothing is returned to the driver before sicp_release_pool, which frees the slabs of a device
+// that hold no live block.  (Measured before: the align-only leg of an open stream took 0.4 or 1.3 s for the same
+// 1024 registrations, depending on how the ~3000 hipMalloc calls inside it happened to go.)
+constexpr int kArenaDevices = 64;
+struct DevArena {
+  struct Slab { char* base = nullptr; size_t size = 0, used = 0; long long live = 0; };
+  struct Block { void* p; int slab; };
+  struct Dev {
+    std::vector<Slab> slabs;
+    std::unordered_map<size_t, std::vector<Block>> free_by_class;
+  };
+  std::mutex m;
+  Dev dev[kArenaDevices];
+  static size_t size_class(size_t bytes) {
+    if (bytes <= 256) return 256;
+    size_t p2 = 256;
+    while (p2 < bytes) p2 <<= 1;
+    const size_t step = std::max<size_t>(p2 >> 4, 256);
+    return (bytes + step - 1) / step * step;
+  }
+  hipError_t alloc(size_t bytes, void** out, int* device, int* slab, size_t* cls_out) {
+    int d = 0;
+    hipError_t e = hipGetDevice(&d);
+    if (e != hipSuccess) return e;
+    const size_t cls = size_class(bytes);
+    std::lock_guard<std::mutex> lock(m);
+    Dev& D = dev[d % kArenaDevices];
+    auto it = D.free_by_class.find(cls);
+    if (it != D.free_by_class.end() && !it->second.empty()) {
+      const Block b = it->second.back();
+      it->second.pop_back();
+      D.slabs[b.slab].live++;
+      *out = b.p; *device = d; *slab = b.slab; *cls_out = cls;
+      return hipSuccess;
+    }
+    int k = -1;
+    for (int i = (int)D.slabs.size() - 1; i >= 0 && i >= (int)D.slabs.size() - 4; --i)
+      if (D.slabs[i].base && D.slabs[i].size - D.slabs[i].used >= cls) { k = i; break; }
+    if (k < 0) {
+      size_t want = (size_t)64 << 20;
+      for (const Slab& sl : D.slabs) if (sl.base) want = std::min<size_t>(std::max(want, 2 * sl.size), (size_t)1 << 30);
+      want = std::max(want, cls);
+      Slab sl;
+      e = hipMalloc((void**)&sl.base, want);
+      if (e != hipSuccess && want > cls) { want = cls; e = hipMalloc((void**)&sl.base, want); }  // (memory is tight: the request alone)
+      if (e != hipSuccess) return e;
+      sl.size = want;
+      k = -1;
+      for (size_t i = 0; i < D.slabs.size(); ++i) if (!D.slabs[i].base) { k = (int)i; break; }  // (a slot freed by release)
+      if (k < 0) { D.slabs.push_back(sl); k = (int)D.slabs.size() - 1; } else D.slabs[k] = sl;
+    }
+    Slab& S = D.slabs[k];
+    *out = S.base + S.used;
+    S.used += cls;
+    S.live++;
+    *device = d; *slab = k; *cls_out = cls;
+    return hipSuccess;
+  }
+  // A block may be handed out again at once, to any thread and stream: like hipFree, giving one back first waits
+  // for the device (launches that still read or write it may be in flight on streams the caller knows nothing of).
+  // Releases are rare next to allocations: buffers that grow, handles and clouds (beyond the cloud pool) that go.
+  void free(void* p, int device, int slab, size_t cls) {
+    {
+      int cur = -1;
+      const bool ok = hipGetDevice(&cur) == hipSuccess;
+      const bool switched = ok && cur != device && hipSetDevice(device) == hipSuccess;
+      (void)hipDeviceSynchronize();
+      if (switched) (void)hipSetDevice(cur);
+    }
+    std::lock_guard<std::mutex> lock(m);
+    Dev& D = dev[device % kArenaDevices];
+    D.free_by_class[cls].push_back(Block{p, slab});
+    D.slabs[slab].live--;
+  }
+  // frees the slabs of `device` that hold no live block (the current device must be `device`)
+  void release(int device) {
+    std::lock_guard<std::mutex> lock(m);
+    Dev& D = dev[device % kArenaDevices];
+    for (size_t i = 0; i < D.slabs.size(); ++i) {
+      Slab& S = D.slabs[i];
+      if (!S.base || S.live != 0) continue;
+      for (auto& kv : D.free_by_class) {
+        std::vector<Block>& v = kv.second;
+        v.erase(std::remove_if(v.begin(), v.end(), [&](const Block& b) { return b.slab == (int)i; }), v.end());
+      }
+      (void)hipFree(S.base);
+      S = Slab();
+    }
+  }
+};
+DevArena& dev_arena() {
+  static DevArena* a = new DevArena;  // never destroyed: it may outlive the HIP runtime at process exit
+  return *a;
+}
+
 template <class T>
 struct DevBuf {
   T* p = nullptr;
   size_t cap = 0;
+  int dev_ = -1, slab_ = -1;
+  size_t cls_ = 0;
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
   ~DevBuf() { release(); }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p) dev_arena().free(p, dev_, slab_, cls_);
     p = nullptr;
     cap = 0;
   }
@@ -53,8 +157,10 @@ struct DevBuf {
     // 64 elements of slack beyond the capacity: kernels that read whole vectors may touch up to one
     // vector past the last element (the values are never used)
     size_t want = n + n / 8;
-    hipError_t e = hipMalloc((void**)&p, (want + 64) * sizeof(T));
+    void* q = nullptr;
+    hipError_t e = dev_arena().alloc((want + 64) * sizeof(T), &q, &dev_, &slab_, &cls_);
     if (e != hipSuccess) { p = nullptr; return e; }
+    p = static_cast<T*>(q);
     cap = want;
     return hipSuccess;
   }
@@ -1283,6 +1389,10 @@ int solo_check(sicp_context* h) {
   // the limit -- and the launch has left the state in HBM as it was: the solve continues (or starts) as
   // [accumulate, LM step] ticks, and this handle stays with them.
   h->solo_failed = h->h_bstates[h->solo_pair].pad_ != h->solo_seq;
+  static const bool log = std::getenv("SICP_SOLO_LOG") != nullptr;  // developer aid
+  if (log)
+    std::fprintf(stderr, "[solo] launch %d pair %d init %d -> %s, evaluations %d, status %d, t %.3f ms\n", h->solo_seq, h->solo_pair, (int)h->solo_was_init,
+                 h->solo_failed ? "TIMED OUT" : "ok", h->h_bstates[h->solo_pair].evaluations, h->h_bstates[h->solo_pair].status, now_ms());
   if (h->solo_failed) {
     h->solo_penalty = std::min(std::max(2 * h->solo_penalty, 8), 4096);
     h->solo_skip = h->solo_penalty;
@@ -1347,6 +1457,7 @@ struct BatchRun {
   std::vector<OuterState> o;
   std::vector<int> phase, search_round;
   std::vector<Start> starts;
+  double dbg_wait_ms = 0; long long dbg_ticks = 0, dbg_act = 0;  // developer aid (SICP_STREAM_LOG)
   bool solo_now = false;        // the tick in flight is a persistent solve
   std::vector<int> evals_seen;  // evaluations of the pair's running solve already counted in the statistics
   std::vector<int> first_chunk;        // PAIR_FIRST: the start-up chunk the pair belongs to
@@ -1399,7 +1510,9 @@ struct BatchRun {
 int BatchRun::turn(TickGroup& G, JobCollector& jc) {
   sicp_context* h = L;
   if (G.pending) {
+    const double tw0 = now_ms();
     SICPCHECK(tick_wait(h, G.M));
+    dbg_wait_ms += now_ms() - tw0; ++dbg_ticks; dbg_act += (long long)G.act.size();
     G.pending = false;
     G.finished.clear();
     if (solo_now) {
@@ -1649,8 +1762,10 @@ int sicp_release_pool(int device_id) {
     std::lock_guard<std::mutex> lock(pool.m);
     dead.swap(pool.free_list[device_id % kPoolDevices]);
   }
-  if (!dead.empty() && hipSetDevice(device_id) != hipSuccess) return SICP_ERR_NO_DEVICE;
+  if (hipSetDevice(device_id) != hipSuccess) return SICP_ERR_NO_DEVICE;
   for (Cloud* c : dead) delete c;
+  (void)hipDeviceSynchronize();   // nothing may still be running out of a block that goes back to the driver
+  dev_arena().release(device_id);  // the slabs no live buffer is carved from
   return SICP_OK;
 }
 
@@ -2061,13 +2176,19 @@ void stream_worker(sicp_stream_ctx* S) {
   std::vector<sicp_stream_ctx::Submission> fresh;
   std::vector<int> fresh_slot;
   std::vector<sicp_stream_result> out;
+  std::vector<std::array<double, 6>> dbg_log;
   for (;;) {
     // ---- admit
     fresh.clear(); fresh_slot.clear();
     {
       std::unique_lock<std::mutex> lock(S->m);
       S->cv_work.wait(lock, [&] { return S->stop || !S->queue.empty() || S->in_flight > 0; });
-      if (S->stop) return;
+      if (S->stop) {
+        for (size_t i = 0; i < dbg_log.size(); i += std::max<size_t>(1, dbg_log.size() / 40))
+          std::fprintf(stderr, "[stream] t %.1f ms completed %.0f ticks %.0f waited %.1f ms pairs-per-tick %.1f solo-allowed %.0f\n", dbg_log[i][0], dbg_log[i][1],
+                       dbg_log[i][2], dbg_log[i][3], dbg_log[i][4], dbg_log[i][5]);
+        return;
+      }
       while (!S->queue.empty() && !free_slots.empty()) {
         fresh.push_back(std::move(S->queue.front()));
         S->queue.pop_front();
@@ -2136,6 +2257,12 @@ void stream_worker(sicp_stream_ctx* S) {
       out.push_back(r);
       run.phase[p] = PAIR_FREE;
       free_slots.push_back(p);
+    }
+    {
+      static const bool slog = std::getenv("SICP_STREAM_LOG") != nullptr;  // developer aid: kept in memory, printed when the stream ends
+      if (slog && !out.empty())
+        dbg_log.push_back({now_ms(), (double)(S->completed + (long long)out.size()), (double)run.dbg_ticks, run.dbg_wait_ms,
+                           run.dbg_ticks ? (double)run.dbg_act / run.dbg_ticks : 0.0, (double)run.solo});
     }
     if (!out.empty()) {
       std::lock_guard<std::mutex> lock(S->m);
