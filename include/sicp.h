@@ -161,8 +161,10 @@ int sicp_device_count(int* count);
 int sicp_create(int device_id, sicp_handle* out);
 int sicp_destroy(sicp_handle h);
 /* Uploaded clouds (device buffers, search structures, pinned staging memory) are recycled through a
- * per-device pool when their last handle lets go of them; this frees what the pool of `device_id`
- * currently holds.  Never required. */
+ * per-device pool when their last handle lets go of them, and all device buffers are carved from a
+ * per-device arena that is not returned to the driver by itself; this frees what the pool of
+ * `device_id` currently holds and every arena slab no live buffer sits in (it waits for the device
+ * first).  Never required. */
 int sicp_release_pool(int device_id);
 const char* sicp_strerror(int status);
 const char* sicp_last_error(sicp_handle h); /* detail of the last SICP_ERR_HIP */

@@ -326,3 +326,30 @@ def test_two_host_threads_aligning_their_own_pairs_concurrently():
             assert np.array_equal(qt, alone[k][0]), (k, r)
             for key in ("outer_iters", "total_lm_iters", "total_evals"):
                 assert st[key] == alone[k][1][key], (k, r, key)
+
+
+def test_release_pool_gives_the_arena_back_and_the_engine_carries_on():
+    """Device buffers are carved from an arena that only sicp_release_pool returns to the driver (the slabs no live
+    buffer sits in).  Releasing it between aligns -- with one engine still alive, i.e. with live blocks in some slabs --
+    must leave that engine intact and later engines working: the same bits as before."""
+    cm = synth.confusion_matrix(11)
+    src, sl, tgt, tl, T, _ = synth.lidar_pair(seed=31, n_points=40000)
+
+    def one():
+        with make_engine(sicp.MODE_EM, 11, cm) as e:
+            e.set_source(src, sl); e.set_target(tgt, tl)
+            return e.align(IDENT)
+
+    ref = one()
+    keeper = make_engine(sicp.MODE_EM, 11, cm)
+    keeper.set_source(src, sl); keeper.set_target(tgt, tl)
+    k0 = keeper.align(IDENT)
+    for _ in range(3):
+        assert sicp.lib().sicp_release_pool(0) == sicp.OK
+        got = one()
+        assert np.array_equal(got[0], ref[0]) and got[1]["total_evals"] == ref[1]["total_evals"]
+        k1 = keeper.align(IDENT)
+        assert np.array_equal(k1[0], k0[0])
+    keeper.close()
+    assert sicp.lib().sicp_release_pool(0) == sicp.OK
+    assert np.array_equal(one()[0], ref[0])
