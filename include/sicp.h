@@ -182,6 +182,13 @@ int sicp_get_params(sicp_handle h, sicp_params* p);
  * (pcl_2_semantic.h:24-39); all outputs stay in the caller's point order. */
 int sicp_set_cloud(sicp_handle h, int which, int32_t n, const float* x, const float* y,
                    const float* z, const uint32_t* label);
+/* The same from an array of points as the reference holds them (pcl::PointCloud<pcl::PointXYZL>::points,
+ * em_icp.h:37 / exec/kitti_eval.cc:132: x y z at bytes 0 4 8 of a 32-byte point, the label at 16; a plain
+ * float[n][3] has stride 12): `xyz` = address of the first point's x, `label` = address of the first
+ * point's uint32 label or NULL; strides in bytes.  One pass over the caller's memory, no intermediate
+ * arrays. */
+int sicp_set_cloud_strided(sicp_handle h, int which, int32_t n, const void* xyz, int64_t stride_bytes,
+                           const void* label, int64_t label_stride_bytes);
 /* Non-finite points (NaN / Inf in any coordinate, e.g. the invalid pixels of an organized RGB-D
  * cloud) are accepted and LEFT OUT of the device cloud, as pcl::KdTreeFLANN::setInputCloud
  * (called by setSourceCloud / setTargetCloud, em_icp.h:50-66) leaves them out of its index: they
@@ -268,6 +275,9 @@ int sicp_stream_destroy(sicp_stream s);  /* registrations still in flight are ab
 int sicp_stream_set_confusion(sicp_stream s, int32_t C, const double* cm_rowmajor);
 int sicp_stream_add_cloud(sicp_stream s, int32_t n, const float* x, const float* y, const float* z,
                           const uint32_t* label, int64_t* cloud_id);
+/* sicp_stream_add_cloud from an array of points (see sicp_set_cloud_strided) */
+int sicp_stream_add_cloud_strided(sicp_stream s, int32_t n, const void* xyz, int64_t stride_bytes,
+                                  const void* label, int64_t label_stride_bytes, int64_t* cloud_id);
 int sicp_stream_release_cloud(sicp_stream s, int64_t cloud_id);
 int sicp_stream_submit(sicp_stream s, int64_t source_id, int64_t target_id, const double init_qt[7],
                        int64_t* ticket);

@@ -161,6 +161,7 @@ def lib():
             "sicp_set_params": [C.c_void_p, C.POINTER(SicpParams)],
             "sicp_get_params": [C.c_void_p, C.POINTER(SicpParams)],
             "sicp_set_cloud": [C.c_void_p, C.c_int, C.c_int32, _fp, _fp, _fp, _up],
+            "sicp_set_cloud_strided": [C.c_void_p, C.c_int, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64],
             "sicp_set_cloud_device": [C.c_void_p, C.c_int, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
             "sicp_share_cloud": [C.c_void_p, C.c_int, C.c_void_p, C.c_int],
             "sicp_cloud_size": [C.c_void_p, C.c_int, _ip, _ip],
@@ -181,6 +182,7 @@ def lib():
             "sicp_stream_destroy": [C.c_void_p],
             "sicp_stream_set_confusion": [C.c_void_p, C.c_int32, _dp],
             "sicp_stream_add_cloud": [C.c_void_p, C.c_int32, _fp, _fp, _fp, _up, C.POINTER(C.c_int64)],
+            "sicp_stream_add_cloud_strided": [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)],
             "sicp_stream_release_cloud": [C.c_void_p, C.c_int64],
             "sicp_stream_submit": [C.c_void_p, C.c_int64, C.c_int64, _dp, C.POINTER(C.c_int64)],
             "sicp_stream_poll": [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(SicpStreamResult), C.POINTER(C.c_int32)],
@@ -217,6 +219,24 @@ def default_params(mode: int) -> SicpParams:
 
 def _ptr(a, t):
     return None if a is None else a.ctypes.data_as(t)
+
+
+def _points_and_labels(xyz, labels):
+    """The caller's [n, >= 3] point array as float32 rows whose x, y, z are adjacent (any row stride; converted only
+    when the dtype or the layout is something else), and the labels as uint32 (any stride)."""
+    pts = np.asarray(xyz)
+    if pts.ndim != 2 or pts.shape[1] < 3:
+        raise ValueError("points must be an [n, 3] array")
+    if pts.dtype != np.float32 or pts.shape[0] == 0 or pts.strides[1] != 4 or pts.strides[0] < 12:
+        pts = np.ascontiguousarray(pts[:, :3], dtype=np.float32)
+    lab = None
+    if labels is not None:
+        lab = np.asarray(labels)
+        if lab.dtype != np.uint32 or lab.ndim != 1 or (lab.shape[0] > 1 and lab.strides[0] < 4):
+            lab = np.ascontiguousarray(lab, dtype=np.uint32).reshape(-1)
+        if lab.shape[0] != pts.shape[0]:
+            raise ValueError("one label per point")
+    return pts, lab
 
 
 class Engine:
@@ -264,14 +284,13 @@ class Engine:
         return p
 
     def set_cloud(self, which: int, xyz, labels=None):
-        xyz = np.asarray(xyz)
-        x, y, z = (np.ascontiguousarray(xyz[:, i], dtype=np.float32) for i in range(3))
-        lab = None if labels is None else np.ascontiguousarray(labels, dtype=np.uint32)
+        pts, lab = _points_and_labels(xyz, labels)   # float32 [n, 3] as it lies in memory: no per-column copies
         self._check(
-            lib().sicp_set_cloud(self._h, which, x.shape[0], _ptr(x, _fp), _ptr(y, _fp), _ptr(z, _fp), _ptr(lab, _up)),
-            "sicp_set_cloud",
+            lib().sicp_set_cloud_strided(self._h, which, pts.shape[0], pts.ctypes.data, pts.strides[0],
+                                         None if lab is None else lab.ctypes.data, 0 if lab is None else lab.strides[0]),
+            "sicp_set_cloud_strided",
         )
-        self.n[which] = x.shape[0]
+        self.n[which] = pts.shape[0]
 
     def set_source(self, xyz, labels=None):
         self.set_cloud(SOURCE, xyz, labels)
@@ -464,12 +483,11 @@ class Stream:
         self.close()
 
     def add_cloud(self, xyz, labels=None) -> int:
-        xyz = np.asarray(xyz)
-        x, y, z = (np.ascontiguousarray(xyz[:, i], dtype=np.float32) for i in range(3))
-        lab = None if labels is None else np.ascontiguousarray(labels, dtype=np.uint32)
+        pts, lab = _points_and_labels(xyz, labels)   # float32 [n, 3] as it lies in memory: no per-column copies
         cid = C.c_int64(0)
-        self._check(lib().sicp_stream_add_cloud(self._s, x.shape[0], _ptr(x, _fp), _ptr(y, _fp), _ptr(z, _fp), _ptr(lab, _up), C.byref(cid)),
-                    "sicp_stream_add_cloud")
+        self._check(lib().sicp_stream_add_cloud_strided(self._s, pts.shape[0], pts.ctypes.data, pts.strides[0],
+                                                        None if lab is None else lab.ctypes.data, 0 if lab is None else lab.strides[0], C.byref(cid)),
+                    "sicp_stream_add_cloud_strided")
         return cid.value
 
     def release_cloud(self, cloud_id: int):

@@ -133,8 +133,7 @@ class EmIterativeClosestPoint {
   void upload(int which, const PointCloudPtr& cloud) {
     sicp_handle h = engine_.get();
     configure(h);
-    detail::FlatCloud f = detail::flatten(*cloud);
-    detail::check(sicp_set_cloud(h, which, f.size(), f.x.data(), f.y.data(), f.z.data(), f.label.data()), h, "sicp_set_cloud");
+    detail::check(detail::set_cloud(h, which, *cloud), h, "sicp_set_cloud_strided");
   }
 
   int kCorrespondences_;

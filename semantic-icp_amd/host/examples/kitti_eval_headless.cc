@@ -58,9 +58,7 @@ struct MethodStream {
   }
   template <typename PointT>
   void add(size_t scan, const pcl::PointCloud<PointT>& c, bool with_labels) {
-    semanticicp::detail::FlatCloud f = semanticicp::detail::flatten(c);
-    check(sicp_stream_add_cloud(s, f.size(), f.x.data(), f.y.data(), f.z.data(), with_labels ? f.label.data() : nullptr, &cloud_of_scan[scan]),
-          "sicp_stream_add_cloud");
+    check(semanticicp::detail::stream_add_cloud(s, c, with_labels, &cloud_of_scan[scan]), "sicp_stream_add_cloud_strided");
   }
   void submit(size_t pair, size_t target, size_t source) {
     const double ident[7] = {0, 0, 0, 1, 0, 0, 0};   // exec/kitti_eval.cc:172-176

@@ -148,12 +148,8 @@ class GICP {
     // slot is replaced (the other object may be this batch slot's predecessor from the previous batch)
     if (shared_target_from_)
       detail::check(sicp_share_cloud(h, SICP_TARGET, shared_target_from_->engine_.get(), SICP_SOURCE), h, "sicp_share_cloud");
-    detail::FlatCloud s = detail::flatten(*sourceCloud_);
-    detail::check(sicp_set_cloud(h, SICP_SOURCE, s.size(), s.x.data(), s.y.data(), s.z.data(), nullptr), h, "sicp_set_cloud");
-    if (!shared_target_from_) {
-      detail::FlatCloud t = detail::flatten(*targetCloud_);
-      detail::check(sicp_set_cloud(h, SICP_TARGET, t.size(), t.x.data(), t.y.data(), t.z.data(), nullptr), h, "sicp_set_cloud");
-    }
+    detail::check(detail::set_cloud(h, SICP_SOURCE, *sourceCloud_, false), h, "sicp_set_cloud_strided");
+    if (!shared_target_from_) detail::check(detail::set_cloud(h, SICP_TARGET, *targetCloud_, false), h, "sicp_set_cloud_strided");
   }
 
   // what align() computed on the GPU (normals -> C = I - (1-eps) n n^T), copied out once per align

@@ -67,6 +67,23 @@ FlatCloud flatten(const pcl::PointCloud<PointT>& c) {
   return f;
 }
 
+// A PCL cloud goes to the engine as it lies in memory (sicp_set_cloud_strided: one pass, no SoA copies): x y z are
+// the first three floats of every PCL point type used here, the label of a PointXYZL is a uint32 member.
+inline const void* label_base(const pcl::PointCloud<pcl::PointXYZ>&) { return nullptr; }
+inline const void* label_base(const pcl::PointCloud<pcl::PointXYZL>& c) { return c.points.empty() ? nullptr : (const void*)&c.points[0].label; }
+template <typename PointT>
+inline int set_cloud(sicp_handle h, int which, const pcl::PointCloud<PointT>& c, bool with_labels = true) {
+  const void* xyz = c.points.empty() ? nullptr : (const void*)&c.points[0].x;
+  return sicp_set_cloud_strided(h, which, (int32_t)c.points.size(), xyz, (int64_t)sizeof(PointT), with_labels ? label_base(c) : nullptr,
+                                (int64_t)sizeof(PointT));
+}
+template <typename PointT>
+inline int stream_add_cloud(sicp_stream s, const pcl::PointCloud<PointT>& c, bool with_labels, int64_t* id) {
+  const void* xyz = c.points.empty() ? nullptr : (const void*)&c.points[0].x;
+  return sicp_stream_add_cloud_strided(s, (int32_t)c.points.size(), xyz, (int64_t)sizeof(PointT), with_labels ? label_base(c) : nullptr,
+                                       (int64_t)sizeof(PointT), id);
+}
+
 inline Sophus::SE3d to_se3(const double* qt) {
 #if defined(SICP_HAVE_REAL_DEPS)
   Sophus::SE3d s;

@@ -353,3 +353,60 @@ def test_release_pool_gives_the_arena_back_and_the_engine_carries_on():
     keeper.close()
     assert sicp.lib().sicp_release_pool(0) == sicp.OK
     assert np.array_equal(one()[0], ref[0])
+
+
+def test_strided_cloud_entry_equals_the_soa_entry():
+    """sicp_set_cloud_strided / sicp_stream_add_cloud_strided take the points as the reference holds them (an array of
+    pcl::PointXYZL: x y z at bytes 0 4 8 of a 32-byte point, the label at 16) or as a plain float[n][3]: the result
+    must be the bits of the SoA entry for every layout, with non-finite points dropped the same way."""
+    import ctypes as C
+    cm = synth.confusion_matrix(11)
+    src, sl, tgt, tl, T, _ = synth.lidar_pair(seed=41, n_points=30000)
+    src = src.astype(np.float32).copy(); tgt = tgt.astype(np.float32).copy()
+    src[[5, 777, 29999], 1] = np.nan      # three dropped points, first / middle / last region
+    tgt[123, 0] = np.inf
+    L = sicp.lib()
+
+    def soa():
+        with make_engine(sicp.MODE_EM, 11, cm) as e:
+            for which, pts, lab in ((sicp.SOURCE, src, sl), (sicp.TARGET, tgt, tl)):
+                x, y, z = (np.ascontiguousarray(pts[:, i]) for i in range(3))
+                lab = np.ascontiguousarray(lab, dtype=np.uint32)
+                assert L.sicp_set_cloud(e._h, which, len(x), x.ctypes.data_as(C.POINTER(C.c_float)), y.ctypes.data_as(C.POINTER(C.c_float)),
+                                        z.ctypes.data_as(C.POINTER(C.c_float)), lab.ctypes.data_as(C.POINTER(C.c_uint32))) == sicp.OK
+                e.n[which] = len(x)
+            return e.align(IDENT), e.cloud_size(sicp.SOURCE)
+
+    ref, sizes = soa()
+    assert sizes == (30000, 29997)
+
+    def pcl_like(pts, lab):   # 32-byte points: x y z pad | label pad pad pad
+        rec = np.zeros(len(pts), dtype=np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("p", "<f4"), ("label", "<u4"), ("q", "<u4", 3)]))
+        rec["x"], rec["y"], rec["z"], rec["label"] = pts[:, 0], pts[:, 1], pts[:, 2], lab
+        return rec
+
+    for layout in ("rows12", "pcl32"):
+        with make_engine(sicp.MODE_EM, 11, cm) as e:
+            keep = []
+            for which, pts, lab in ((sicp.SOURCE, src, sl), (sicp.TARGET, tgt, tl)):
+                if layout == "rows12":
+                    a = np.ascontiguousarray(pts); lb = np.ascontiguousarray(lab, dtype=np.uint32)
+                    args = (a.ctypes.data, 12, lb.ctypes.data, 4)
+                    keep += [a, lb]
+                else:
+                    rec = pcl_like(pts, lab)
+                    args = (rec.ctypes.data, 32, rec.ctypes.data + 16, 32)
+                    keep.append(rec)
+                assert L.sicp_set_cloud_strided(e._h, which, len(pts), *args) == sicp.OK
+                e.n[which] = len(pts)
+            got = e.align(IDENT)
+            assert e.cloud_size(sicp.SOURCE) == (30000, 29997)
+        assert np.array_equal(got[0], ref[0]), layout
+        for key in ("outer_iters", "total_evals", "total_corr", "total_active"):
+            assert got[1][key] == ref[1][key], (layout, key)
+    # argument checks
+    with make_engine(sicp.MODE_GICP) as e:
+        a = np.zeros((4, 3), dtype=np.float32)
+        assert L.sicp_set_cloud_strided(e._h, sicp.SOURCE, 4, a.ctypes.data, 8, None, 0) == sicp.ERR_INVALID_ARGUMENT
+        assert L.sicp_set_cloud_strided(e._h, sicp.SOURCE, 4, None, 12, None, 0) == sicp.ERR_INVALID_ARGUMENT
+        assert L.sicp_set_cloud_strided(e._h, sicp.SOURCE, 0, None, 12, None, 0) == sicp.OK
