@@ -141,6 +141,62 @@ __device__ __forceinline__ void key_sort16(u64 (&bk)[K]) {
 #undef SICP_CSWAP
 }
 
+// ---- the four lanes of a quad merge their ascending lists in registers ---------------------------------
+// Two rounds (partner = lane ^ 1, then lane ^ 2), after which every lane of the quad holds the K smallest keys of
+// all four lists, ascending.  A round is the bitonic merge of two sorted lists: min(a[i], b[N-1-i]) are the N
+// smallest of both as a bitonic sequence, which log2(N) stages of compare-exchanges sort (N = K for 1 and 4, 32
+// for the longer lists, padded with the empty key).  The lists are disjoint up to identical padding keys, so the
+// result is the one the serial four-way merge through LDS gave (one lane per query, 58 instructions per output
+// entry: 1160 of the K = 20 wave's 6118) -- in ~420 instructions for K = 20, ~50 for K = 4, all lanes working.
+template <int CTRL>
+__device__ __forceinline__ u64 quad_perm_key(u64 v) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, CTRL, 0xf, 0xf, false);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), CTRL, 0xf, 0xf, false);
+  return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u64 key_min(u64 a, u64 b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(__longlong_as_double((long long)a)), "v"(__longlong_as_double((long long)b)));
+  return (u64)__double_as_longlong(r);
+}
+template <int K, int CTRL>
+__device__ __forceinline__ void quad_merge_round(u64 (&bk)[K]) {
+  if constexpr (K == 1) {
+    bk[0] = key_min(bk[0], quad_perm_key<CTRL>(bk[0]));
+  } else if constexpr (K == 4) {
+    u64 pb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pb[i] = quad_perm_key<CTRL>(bk[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bk[i] = key_min(bk[i], pb[3 - i]);
+    key_cswap(bk[0], bk[2]); key_cswap(bk[1], bk[3]); key_cswap(bk[0], bk[1]); key_cswap(bk[2], bk[3]);
+  } else {
+    static_assert(K > 16 && K <= 32, "list lengths 20 and 32");
+    constexpr int N = 32;
+    u64 l[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int j = N - 1 - i;  // the partner's entry
+      if (i < K && j < K) l[i] = key_min(bk[i], quad_perm_key<CTRL>(bk[j]));
+      else if (i < K) l[i] = bk[i];
+      else if (j < K) l[i] = quad_perm_key<CTRL>(bk[j]);
+      else l[i] = KEY_EMPTY;
+    }
+#pragma unroll
+    for (int j = N / 2; j >= 1; j >>= 1)
+#pragma unroll
+      for (int i = 0; i < N; ++i)
+        if ((i & j) == 0) key_cswap(l[i], l[i + j]);
+#pragma unroll
+    for (int i = 0; i < K; ++i) bk[i] = l[i];
+  }
+}
+template <int K>
+__device__ __forceinline__ void quad_merge(u64 (&bk)[K]) {
+  quad_merge_round<K, 0xB1>(bk);  // quad_perm [1,0,3,2]
+  quad_merge_round<K, 0x4E>(bk);  // quad_perm [2,3,0,1]
+}
+
 // a fresh list; the asm keeps the compiler from treating the K equal constants as one value (it
 // would share one register among them and copy at every control-flow join of the first scans)
 template <int K>
@@ -695,17 +751,14 @@ __device__ __forceinline__ void lds_leaf_points(const KNN_LDS knn_v4f* buf, unsi
 // (6250 of them at 100K queries: ~1.5 waves per SIMD resident on average)
 template <int K, int WPB>
 __device__ __forceinline__ void knn_packet_body(const KnnArgs& a, int wg, int n_wg) {
-  // One wave-private LDS region, used twice: during the walk it holds s_lb[L][lane] = lane (q, c)'s lower
-  // bound of query q to child c of the node of level L + 1 the walk is below -- the bounds of the siblings
-  // that wait on every level of the current path; at the end the quad's four lists are merged through it.
-  // (As two arrays the K = 20 kernel needs 26 KB per two-wave workgroup: 3 waves per SIMD.)
-  constexpr size_t kMergeBytes = sizeof(u64) * 16 * 4 * K, kLbBytes = sizeof(float) * kWalkLevels * 64;
-  constexpr size_t kWaveBytes = kMergeBytes > kLbBytes ? kMergeBytes : kLbBytes;
+  // One wave-private LDS region: s_lb[L][lane] = lane (q, c)'s lower bound of query q to child c of the node of
+  // level L + 1 the walk is below -- the bounds of the siblings that wait on every level of the current path.
+  // (The quad's four lists are merged in registers at the end: quad_merge.)
+  constexpr size_t kWaveBytes = sizeof(float) * kWalkLevels * 64;
   __shared__ __attribute__((aligned(16))) unsigned char s_wave_all[WPB][kWaveBytes];
   constexpr bool kDma = K <= SICP_KNN_DMA_MAXK;
   __shared__ __attribute__((aligned(16))) float4 s_pts_all[kDma ? WPB : 1][kDma ? kFan * kLeaf : 1];  // the leaf group the walk is in (dma_leaf_group)
   KNN_LDS knn_v4f* const s_pts = (KNN_LDS knn_v4f*)s_pts_all[kDma ? (threadIdx.x >> 6) : 0];
-  u64 (&s_merge)[16][4][K] = *reinterpret_cast<u64 (*)[16][4][K]>(s_wave_all[threadIdx.x >> 6]);
   float (&s_lb)[kWalkLevels][64] = *reinterpret_cast<float (*)[kWalkLevels][64]>(s_wave_all[threadIdx.x >> 6]);
   const int lane = threadIdx.x & 63, sub = lane & 3, slot = lane >> 2;
   const int bid = xcd_contiguous_block(wg, n_wg) * WPB + (int)(threadIdx.x >> 6);
@@ -871,28 +924,28 @@ __device__ __forceinline__ void knn_packet_body(const KnnArgs& a, int wg, int n_
   }
   if (a.dbg && sub == 0 && q_raw < a.q_count) { a.dbg[2 * q] = n_box; a.dbg[2 * q + 1] = n_scan; }
 
-  // --- merge the quad's four ascending lists (LDS), lane 0 of the quad emits
-#pragma unroll
-  for (int k = 0; k < K; ++k) s_merge[slot][sub][k] = bk[k];
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the wave's own LDS writes, read below by its lanes 0 mod 4
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  if (sub == 0 && q_raw < a.q_count) {
-    int p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+  // --- merge the quad's four ascending lists (registers: quad_merge); lane `sub` of the quad emits the entries
+  // sub, sub + 4, ... -- [query][K] output: consecutive lanes write consecutive addresses
+  quad_merge<K>(bk);
+  if (q_raw < a.q_count) {
     // [query][K], or [K][out_stride] (consecutive queries -> consecutive addresses)
     const size_t o = a.out_stride > 0 ? (size_t)(a.q_begin + q) : (size_t)(a.q_begin + q) * a.k_out;
     const size_t ks = a.out_stride > 0 ? (size_t)a.out_stride : 1;
-    for (int k = 0; k < a.k_out; ++k) {
-      const u64 h0 = p0 < K ? s_merge[slot][0][p0] : KEY_EMPTY, h1 = p1 < K ? s_merge[slot][1][p1] : KEY_EMPTY;
-      const u64 h2 = p2 < K ? s_merge[slot][2][p2] : KEY_EMPTY, h3 = p3 < K ? s_merge[slot][3][p3] : KEY_EMPTY;
-      const u64 m01 = h0 <= h1 ? h0 : h1, m23 = h2 <= h3 ? h2 : h3;
-      const u64 best = m01 <= m23 ? m01 : m23;
-      if (best == h0 && p0 < K) ++p0; else if (best == h1 && p1 < K) ++p1; else if (best == h2 && p2 < K) ++p2; else ++p3;
-      const unsigned orig = (unsigned)best;
-      const float d = best == KEY_EMPTY ? INFINITY : key_dist(best);
-      const bool keep = orig != 0xffffffffu && d < a.gate_sq;  // strict <, float compare (em_icp.hpp:65)
-      a.out_i[o + k * ks] = keep ? a.inv[orig] : -1;
-      if (a.out_d) a.out_d[o + k * ks] = d;
+#pragma unroll
+    for (int t = 0; t < (K + 3) / 4; ++t) {
+      // entry k = 4 t + sub of the merged list (static register indices: a select per lane of the quad)
+      u64 best = bk[4 * t < K ? 4 * t : K - 1];
+#pragma unroll
+      for (int s2 = 1; s2 < 4; ++s2)
+        if (4 * t + s2 < K) best = sub == s2 ? bk[4 * t + s2] : best;
+      const int k = 4 * t + sub;
+      if (k < K && k < a.k_out) {
+        const unsigned orig = (unsigned)best;
+        const float d = best == KEY_EMPTY ? INFINITY : key_dist(best);
+        const bool keep = orig != 0xffffffffu && d < a.gate_sq;  // strict <, float compare (em_icp.hpp:65)
+        a.out_i[o + k * ks] = keep ? a.inv[orig] : -1;
+        if (a.out_d) a.out_d[o + k * ks] = d;
+      }
     }
   }
 }
