@@ -111,6 +111,14 @@ __device__ __forceinline__ void cov_body(const CovArgs& a) {
     r.nx = nx; r.ny = ny; r.nz = nz;
     r.pad_[0] = r.pad_[1] = r.pad_[2] = 0u;
     a.rec[i] = r;
+    if (a.rec_dense) {
+      typedef double dense_v2d __attribute__((ext_vector_type(2)));
+      const size_t n = (size_t)a.rec_dense_n;
+      const char* src = reinterpret_cast<const char*>(&r);
+      *reinterpret_cast<dense_v2d*>(a.rec_dense + 16 * (size_t)i) = *reinterpret_cast<const dense_v2d*>(src);
+      *reinterpret_cast<dense_v2d*>(a.rec_dense + 16 * n + 16 * (size_t)i) = *reinterpret_cast<const dense_v2d*>(src + 16);
+      *reinterpret_cast<float*>(a.rec_dense + 32 * n + 4 * (size_t)i) = r.z;
+    }
   }
   if (a.hist) {
     // label histogram as neighbour counts (em_icp.hpp:301: dist(label-1) += 1/k)

@@ -141,7 +141,14 @@ struct CovArgs {
   int float_products;
   PointRec* rec;          // out: position + normal of every point
   uint8_t* hist;          // [n][C] or nullptr
+  char* rec_dense;        // out, nullable: the same 36 data bytes per point as three dense arrays (dense_rec_*)
+  int rec_dense_n;        // points the dense arrays are laid out for (their pitch)
 };
+
+// The records again, dense: [n] x 16 B (nx ny) | [n] x 16 B (nz x y) | [n] x 4 B (z).  What the accumulate kernel STREAMS
+// -- the source points of a pass, in order -- is read from here: 36 bytes per point from HBM instead of the 48 of a
+// record (the 48-byte record is what a gather wants: one point, one place).
+SICP_HD inline size_t dense_rec_bytes(int n) { return (size_t)(n > 0 ? n : 1) * 36; }
 
 // rows of the projection arrays are padded to an even number of doubles: 16-byte aligned, read with
 // dwordx4 loads by the weight kernels
@@ -171,6 +178,7 @@ struct AccArgs {
   const int* idx;
   const double* w;  // nullable (weight 1)
   const PointRec *srec, *trec;
+  const char* srec_dense;  // nullable: the source records as dense arrays (dense_rec_*), pitch n_s
   Pose pose;            // used when lm == nullptr
   const LmState* lm;    // device-resident solve: evaluate at lm->pose, skip when it has finished
   LmState* lm_step;     // batched solve: the state lm_step_batch_kernel advances (== lm)

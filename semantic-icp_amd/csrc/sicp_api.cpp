@@ -239,6 +239,8 @@ struct Cloud {
   DevBuf<unsigned long long> keys_in, keys_out;
   DevBuf<unsigned char> sort_temp;
   DevBuf<sicp::PointRec> rec;  // position + normal of every point (what the weight / accumulate kernels gather)
+  DevBuf<char> rec_dense;      // the same as three dense arrays (what the accumulate kernel streams for the source points)
+  int rec_dense_n = 0;         // the cloud size they were written for (0: not written)
   DevBuf<uint8_t> hist;
   DevBuf<double> proj;  // [n][proj_stride(C)] label distribution x confusion matrix
   bool proj_valid = false;
@@ -869,6 +871,16 @@ int compute_features(sicp_context* h, Cloud& c, bool with_hist, hipStream_t stre
   a.float_products = P.quirk_float_products;
   a.rec = c.rec.p;
   a.hist = with_hist ? c.hist.p : nullptr;
+  // (SICP_NO_DENSE_SRC: developer switch; with it the accumulate kernel streams the 48-byte records: 814 instead of
+  //  800 us per 256-pair launch, 2.18 instead of 2.22 G corr/s)
+  static const bool dense_on = std::getenv("SICP_NO_DENSE_SRC") == nullptr;
+  a.rec_dense = nullptr; a.rec_dense_n = 0;
+  c.rec_dense_n = 0;
+  if (dense_on && n > 0) {
+    HIPCHECK(c.rec_dense.reserve(sicp::dense_rec_bytes(n)));
+    a.rec_dense = c.rec_dense.p; a.rec_dense_n = n;
+    c.rec_dense_n = n;
+  }
   if (h->collect) h->collect->cov[h->collect->slice].push_back(a);
   else HIPCHECK(sicp::launch_cov(a, stream));
   c.feat_valid = true;
@@ -993,6 +1005,7 @@ void fill_acc(sicp_context* h, sicp::AccArgs& a) {
   a.idx = h->idx.p;
   a.w = h->corr_weighted ? h->w.p : nullptr;
   a.srec = S.rec.p; a.trec = T.rec.p;
+  a.srec_dense = (S.rec_dense_n == S.n && S.n > 0 && S.n == h->corr_n) ? S.rec_dense.p : nullptr;
   a.lm = nullptr;
   a.lm_step = nullptr;
   a.one_m_eps = 1.0 - P.epsilon;

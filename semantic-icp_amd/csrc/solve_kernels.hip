@@ -203,6 +203,7 @@ struct LoadCtx {
   const SICP_GLOBAL double* w;       // nullable: weight 1
   const SICP_GLOBAL PointRec* srec;
   const SICP_GLOBAL PointRec* trec;
+  const SICP_GLOBAL char* sdense;    // nullable: the source records as dense arrays (kernels.h: dense_rec_*), pitch n_s
   int n_s, total;
 };
 struct MathCtx {
@@ -405,7 +406,18 @@ __device__ __forceinline__ void load_regs(const LoadCtx& L, int last, int g, Gro
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     const int i = max(min((e0 + s * (SG / NS)) / K, L.n_s - 1), 0);
-    load_rec(L.srec + i, G.sx[s], G.sy[s], G.sz[s], G.snx[s], G.sny[s], G.snz[s]);
+    if (L.sdense) {  // (wave-uniform) the stream of source points from the dense arrays: 36 instead of 48 bytes per point
+      const SICP_GLOBAL char* p = L.sdense + 16 * (size_t)i;
+      const size_t n = (size_t)L.n_s;
+      const v2d a = SICP_STREAM_LOAD((const SICP_GLOBAL v2d*)p);
+      const v4f b = SICP_STREAM_LOAD((const SICP_GLOBAL v4f*)(p + 16 * n));
+      const float c = SICP_STREAM_LOAD((const SICP_GLOBAL float*)(L.sdense + 32 * n + 4 * (size_t)i));
+      G.snx[s] = a.x; G.sny[s] = a.y;
+      G.snz[s] = __hiloint2double(__float_as_int(b.y), __float_as_int(b.x));
+      G.sx[s] = b.z; G.sy[s] = b.w; G.sz[s] = c;
+    } else {
+      load_rec(L.srec + i, G.sx[s], G.sy[s], G.sz[s], G.snx[s], G.sny[s], G.snz[s]);
+    }
   }
 }
 
@@ -635,6 +647,7 @@ __global__ __launch_bounds__(BS, SICP_ACC_OCC) void accumulate_staged_kernel(con
     L.w = (const SICP_GLOBAL double*)uniform_ptr(a.w);
     L.srec = (const SICP_GLOBAL PointRec*)uniform_ptr(a.srec);
     L.trec = (const SICP_GLOBAL PointRec*)uniform_ptr(a.trec);
+    L.sdense = (const SICP_GLOBAL char*)uniform_ptr(a.srec_dense);
     L.n_s = uniform_i32(a.n_s);
     L.total = uniform_i32(a.n_s * a.K);
     const AccGeometry geo = acc_geometry(L.total, SG);
@@ -803,6 +816,7 @@ __global__ __launch_bounds__(BS, 1) void solve_one_kernel(const SoloArgs A) {
   L.w = (const SICP_GLOBAL double*)uniform_ptr(a.w);
   L.srec = (const SICP_GLOBAL PointRec*)uniform_ptr(a.srec);
   L.trec = (const SICP_GLOBAL PointRec*)uniform_ptr(a.trec);
+  L.sdense = nullptr;  // (a worker loads its chunk once)
   L.n_s = uniform_i32(a.n_s);
   L.total = uniform_i32(a.n_s * a.K);
   const AccGeometry geo = acc_geometry(L.total, SG);
