@@ -10,9 +10,14 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 pre=$1
-rm -rf /tmp/pb_prof
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb_prof -- python3 bench.py --no-cpu-baseline --sequence-pairs 0 \
-  > gpurun_out/${pre}_bench_under_rocprof.json 2> /tmp/pb_prof.err
+# (rocprofv3 itself segfaults on about every other run of this command on this pool: up to three attempts)
+for attempt in 1 2 3; do
+  rm -rf /tmp/pb_prof
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb_prof -- python3 bench.py --no-cpu-baseline --sequence-pairs 0 \
+    > gpurun_out/${pre}_bench_under_rocprof.json 2> /tmp/pb_prof.err
+  [ -n "$(find /tmp/pb_prof -name '*kernel_trace.csv' 2>/dev/null | head -1)" ] && break
+  echo "attempt $attempt: no kernel trace (rocprofv3 crashed?)"
+done
 f=$(find /tmp/pb_prof -name '*kernel_stats.csv' | head -1)
 t=$(find /tmp/pb_prof -name '*kernel_trace.csv' | head -1)
 [ -n "$f" ] && cp "$f" gpurun_out/${pre}_kernel_stats_bench.csv
