@@ -18,14 +18,19 @@ n = int(sys.argv[3]) if len(sys.argv) > 3 else 100000
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 20
 sicp = importlib.import_module("semantic-icp_amd")
 cm = synth.confusion_matrix(11)
-p = sicp.default_params(sicp.MODE_EM); p.num_classes = 11
+# KNN_MODE=gicp: the K = 1 correspondence search of SE3-GICP (phases k4_* then time K = 1)
+gicp = os.environ.get("KNN_MODE", "") == "gicp"
+p = sicp.default_params(sicp.MODE_GICP if gicp else sicp.MODE_EM); p.num_classes = 0 if gicp else 11
 ident = np.array([0, 0, 0, 1, 0, 0, 0.0])
 es, poses = [], []
 for k in range(S):
     seed = 2 + k
     motion = (1.0, 2.0) if seed == 2 else (0.5 + 0.11 * (seed % 11), -2.6 + 0.65 * (seed % 9))
     ps, ls, pt, lt, T, _ = synth.lidar_pair(seed=seed, n_points=n, motion=motion)
-    e = sicp.Engine(0, p); e.set_confusion(cm); e.set_source(ps, ls); e.set_target(pt, lt)
+    e = sicp.Engine(0, p)
+    if not gicp:
+        e.set_confusion(cm)
+    e.set_source(ps, None if gicp else ls); e.set_target(pt, None if gicp else lt)
     es.append(e)
     poses.append(mat_to_qt(T))   # the planted motion: where the later outer iterations search
 poses = np.array(poses)
