@@ -2343,7 +2343,7 @@ int sicp_stream_create(int device_id, const sicp_params* params, int32_t max_in_
   S->cap = max_in_flight;
   S->params = *params;
   S->params.reuse_features = 1;  // a stream's cloud keeps its normals / histograms: computed with its first registration
-  S->params.lm_on_device = 1;
+  S->params.lm_on_device = params->lm_on_device == 2 ? 2 : 1;  // (2: never the persistent solve)
   auto cleanup = [&](int rc) {
     for (size_t k = 0; k < S->slots.size(); ++k) {
       sicp_context* g = S->slots[k];
