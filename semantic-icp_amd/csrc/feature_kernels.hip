@@ -57,23 +57,49 @@ __device__ __forceinline__ void cov_body(const CovArgs& a) {
   double c00 = 0, c10 = 0, c11 = 0, c20 = 0, c21 = 0, c22 = 0;
   const int* nn = a.nn_stride > 0 ? a.nn + i : a.nn + (size_t)i * a.k;
   const size_t js = a.nn_stride > 0 ? (size_t)a.nn_stride : 1;
-  for (int j = 0; j < a.k; ++j) {
-    const int g = nn[j * js];
-    if (g < 0) continue;
-    const float x = a.x[g], y = a.y[g], z = a.z[g];
-    mean0 += (double)x; mean1 += (double)y; mean2 += (double)z;
-    if (a.float_products) {
-      // quirk Q2: pt.y*pt.x is a float32 product (em_icp.hpp:307-314)
-      c00 += (double)__fmul_rn(x, x);
-      c10 += (double)__fmul_rn(y, x);
-      c11 += (double)__fmul_rn(y, y);
-      c20 += (double)__fmul_rn(z, x);
-      c21 += (double)__fmul_rn(z, y);
-      c22 += (double)__fmul_rn(z, z);
-    } else {
-      const double dx = x, dy = y, dz = z;
-      c00 += dx * dx; c10 += dy * dx; c11 += dy * dy;
-      c20 += dz * dx; c21 += dz * dy; c22 += dz * dz;
+  // The neighbours in batches of 8: their indices, then their coordinates (and labels), are requested together and
+  // only then summed -- in list order, so the sums are the ones a one-at-a-time loop gives.  (That loop was a chain of
+  // 2 dependent round trips to memory per neighbour, and the histogram below another 2 with a byte read-modify-write
+  // in global memory each: ~80 per point; a 100K-point cloud took 26-31 us in a 16-job launch, most of it waiting.)
+  // The label counts (k <= 32 < 256) are kept as bytes of two 64-bit registers for up to 16 classes.
+  const bool hist_regs = a.hist != nullptr && a.C <= 16;
+  unsigned long long cnt_lo = 0ull, cnt_hi = 0ull;
+  constexpr int NB = 8;
+  for (int j0 = 0; j0 < a.k; j0 += NB) {
+    int g[NB];
+#pragma unroll
+    for (int t = 0; t < NB; ++t) g[t] = j0 + t < a.k ? nn[(size_t)(j0 + t) * js] : -1;
+    float px[NB], py[NB], pz[NB];
+    uint32_t lb[NB];
+#pragma unroll
+    for (int t = 0; t < NB; ++t) {
+      const int gi = g[t] > 0 ? g[t] : 0;
+      px[t] = a.x[gi]; py[t] = a.y[gi]; pz[t] = a.z[gi];
+      lb[t] = hist_regs ? a.label[gi] : 0u;
+    }
+#pragma unroll
+    for (int t = 0; t < NB; ++t) {
+      if (g[t] < 0) continue;
+      const float x = px[t], y = py[t], z = pz[t];
+      mean0 += (double)x; mean1 += (double)y; mean2 += (double)z;
+      if (a.float_products) {
+        // quirk Q2: pt.y*pt.x is a float32 product (em_icp.hpp:307-314)
+        c00 += (double)__fmul_rn(x, x);
+        c10 += (double)__fmul_rn(y, x);
+        c11 += (double)__fmul_rn(y, y);
+        c20 += (double)__fmul_rn(z, x);
+        c21 += (double)__fmul_rn(z, y);
+        c22 += (double)__fmul_rn(z, z);
+      } else {
+        const double dx = x, dy = y, dz = z;
+        c00 += dx * dx; c10 += dy * dx; c11 += dy * dy;
+        c20 += dz * dx; c21 += dz * dy; c22 += dz * dz;
+      }
+      const uint32_t l = lb[t];
+      if (hist_regs && l >= 1u && l <= (uint32_t)a.C) {  // em_icp.hpp:301: dist(label-1) += 1/k, as a count
+        const unsigned long long one = 1ull << (8u * ((l - 1u) & 7u));
+        if (l - 1u < 8u) cnt_lo += one; else cnt_hi += one;
+      }
     }
   }
   // quirk Q3: divide by k whatever the neighbour count (em_icp.hpp:317,320)
@@ -123,12 +149,16 @@ __device__ __forceinline__ void cov_body(const CovArgs& a) {
   if (a.hist) {
     // label histogram as neighbour counts (em_icp.hpp:301: dist(label-1) += 1/k)
     uint8_t* h = a.hist + (size_t)i * a.C;  // this lane owns the row
-    for (int c = 0; c < a.C; ++c) h[c] = 0;
-    for (int j = 0; j < a.k; ++j) {
-      const int g = nn[j * js];
-      if (g < 0) continue;
-      const uint32_t l = a.label[g];
-      if (l >= 1u && l <= (uint32_t)a.C) h[l - 1] = (uint8_t)(h[l - 1] + 1);
+    if (hist_regs) {
+      for (int c = 0; c < a.C; ++c) h[c] = (uint8_t)((c < 8 ? cnt_lo >> (8 * c) : cnt_hi >> (8 * (c - 8))) & 0xffull);
+    } else {
+      for (int c = 0; c < a.C; ++c) h[c] = 0;
+      for (int j = 0; j < a.k; ++j) {
+        const int g = nn[j * js];
+        if (g < 0) continue;
+        const uint32_t l = a.label[g];
+        if (l >= 1u && l <= (uint32_t)a.C) h[l - 1] = (uint8_t)(h[l - 1] + 1);
+      }
     }
   }
 }
