@@ -1497,7 +1497,7 @@ struct BatchRun {
   std::vector<OuterState> o;
   std::vector<int> phase, search_round;
   std::vector<Start> starts;
-  double dbg_wait_ms = 0; long long dbg_ticks = 0, dbg_act = 0;  // developer aid (SICP_STREAM_LOG)
+  double dbg_wait_ms = 0, dbg_search_ms = 0, dbg_launch_ms = 0; long long dbg_ticks = 0, dbg_act = 0;  // developer aid (SICP_STREAM_LOG)
   bool solo_now = false;        // the tick in flight is a persistent solve
   std::vector<int> evals_seen;  // evaluations of the pair's running solve already counted in the statistics
   std::vector<int> first_chunk;        // PAIR_FIRST: the start-up chunk the pair belongs to
@@ -1591,6 +1591,7 @@ int BatchRun::turn(TickGroup& G, JobCollector& jc) {
     if (promote_started(G, idle) < 0) { h->last_error = "start-up pipeline: event query failed"; return SICP_ERR_HIP; }
   }
   ++G.round;
+  const double dbg_t_search0 = now_ms();
   // (1) searches of the pairs between two inner solves -> side stream
   bool any_search = false;
   for (int p = G.lo; p < G.hi; ++p) {
@@ -1646,8 +1647,11 @@ int BatchRun::turn(TickGroup& G, JobCollector& jc) {
     const sicp_context* g = hs[G.act[0]];
     solo_now = live_all == 1 && sicp::solve_one_fits(g->corr_n * g->corr_K, g->corr_K) && solo_allowed(L);
   }
+  const double dbg_t_launch0 = now_ms();
+  dbg_search_ms += dbg_t_launch0 - dbg_t_search0;
   int rc = tick_launch(h, *G.S, G.M, hs, G.lo, G.hi, G.act, G.joining, reinterpret_cast<const double(*)[7]>(starts.data()), len,
                        solo_now ? (n == 1 ? sicp::kSoloMaxEvals : 64) : 0);
+  dbg_launch_ms += now_ms() - dbg_t_launch0;
   if (rc != SICP_OK) return rc;
   G.pending = true;
   return SICP_OK;
@@ -1835,6 +1839,24 @@ int sicp_get_params(sicp_handle h, sicp_params* p) {
   return SICP_OK;
 }
 
+// The buffers a cloud's features will need, taken from the arena when the cloud is SET rather than at its first
+// align(): a new arena slab is a hipMalloc of up to 1 GB, which the driver clears before handing it out (~30 ms per
+// GB) -- inside a stream that is the worker's turn, i.e. every registration in flight waits (measured: the resident
+// leg of the open-stream bench took 1.28 instead of 0.45 s when its 1025 clouds' 27 GB of feature buffers were first
+// touched inside the timed region).
+static int reserve_features(sicp_context* h, Cloud& c) {
+  const sicp_params& P = h->params;
+  const size_t m = (size_t)(c.n > 0 ? c.n : 1);
+  HIPCHECK(c.rec.reserve(m));
+  HIPCHECK(c.nn.reserve(m * (size_t)(P.k_cov > 0 ? P.k_cov : 1)));
+  HIPCHECK(c.rec_dense.reserve(sicp::dense_rec_bytes(c.n)));
+  if (P.mode == SICP_MODE_EM && P.num_classes > 0) {
+    HIPCHECK(c.hist.reserve(m * (size_t)P.num_classes));
+    HIPCHECK(c.proj.reserve(m * (size_t)sicp::proj_stride(P.num_classes)));
+  }
+  return SICP_OK;
+}
+
 static int set_cloud_common(sicp_handle h, int which, int32_t n, const StridedCloud& in) {
   SICPCHECK(set_device(h));
   if (h->cl[which].use_count() > 1) {  // shared with another handle: leave theirs alone
@@ -1850,7 +1872,10 @@ static int set_cloud_common(sicp_handle h, int which, int32_t n, const StridedCl
   h->hint_ok = false;
   // upload now for the current mode, so that align() starts with the cloud resident in HBM;
   // a later mode change re-lays it out lazily
-  if (h->params.mode != SICP_MODE_SEMANTIC || c.has_label) return prepare_cloud(h, c);
+  if (h->params.mode != SICP_MODE_SEMANTIC || c.has_label) {
+    SICPCHECK(prepare_cloud(h, c));
+    SICPCHECK(reserve_features(h, c));
+  }
   return SICP_OK;
 }
 
@@ -2230,7 +2255,8 @@ void stream_worker(sicp_stream_ctx* S) {
   std::vector<sicp_stream_ctx::Submission> fresh;
   std::vector<int> fresh_slot;
   std::vector<sicp_stream_result> out;
-  std::vector<std::array<double, 6>> dbg_log;
+  std::vector<std::array<double, 11>> dbg_log;
+  double dbg_admit_ms = 0, dbg_flush_ms = 0, dbg_turn_ms = 0;
   for (;;) {
     // ---- admit
     fresh.clear(); fresh_slot.clear();
@@ -2239,8 +2265,8 @@ void stream_worker(sicp_stream_ctx* S) {
       S->cv_work.wait(lock, [&] { return S->stop || !S->queue.empty() || S->in_flight > 0; });
       if (S->stop) {
         for (size_t i = 0; i < dbg_log.size(); i += std::max<size_t>(1, dbg_log.size() / 40))
-          std::fprintf(stderr, "[stream] t %.1f ms completed %.0f ticks %.0f waited %.1f ms pairs-per-tick %.1f solo-allowed %.0f\n", dbg_log[i][0], dbg_log[i][1],
-                       dbg_log[i][2], dbg_log[i][3], dbg_log[i][4], dbg_log[i][5]);
+          std::fprintf(stderr, "[stream] t %.1f ms completed %.0f ticks %.0f waited %.1f ms pairs-per-tick %.1f solo-allowed %.0f | host ms: admit %.1f flush %.1f turn %.1f (of which waited; searches %.1f, tick launch %.1f)\n",
+                       dbg_log[i][0], dbg_log[i][1], dbg_log[i][2], dbg_log[i][3], dbg_log[i][4], dbg_log[i][5], dbg_log[i][6], dbg_log[i][7], dbg_log[i][8], dbg_log[i][9], dbg_log[i][10]);
         return;
       }
       while (!S->queue.empty() && !free_slots.empty()) {
@@ -2257,6 +2283,7 @@ void stream_worker(sicp_stream_ctx* S) {
       run.solo = S->params.lm_on_device != 2 && S->draining > 0 && S->queue.empty();
     }
     out.clear();
+    const double t_admit0 = now_ms();
     for (size_t k = 0; k < fresh.size(); ++k) {
       const int p = fresh_slot[k];
       sicp_context* h = S->slots[p];
@@ -2284,15 +2311,20 @@ void stream_worker(sicp_stream_ctx* S) {
     }
     // the new pairs' features (self-searches, covariances, projections): one launch per kind, on the side
     // stream, beside the tick in flight and ahead of the pairs' first searches
+    const double t_flush0 = now_ms();
+    dbg_admit_ms += t_flush0 - t_admit0;
     if (!fresh.empty()) {
       const int rc = flush_jobs(L, jc, run.side);
       if (rc != SICP_OK) { stream_fail(S, rc, L->last_error); return; }
     }
+    const double t_turn0 = now_ms();
+    dbg_flush_ms += t_turn0 - t_flush0;
     // ---- one turn
     {
       const int rc = run.turn(G, jc);
       if (rc != SICP_OK) { stream_fail(S, rc, L->last_error); return; }
     }
+    dbg_turn_ms += now_ms() - t_turn0;
     // ---- retire
     long long busy = 0, slots_sat = 0;
     for (int p = 0; p < S->cap; ++p) {
@@ -2316,7 +2348,7 @@ void stream_worker(sicp_stream_ctx* S) {
       static const bool slog = std::getenv("SICP_STREAM_LOG") != nullptr;  // developer aid: kept in memory, printed when the stream ends
       if (slog && !out.empty())
         dbg_log.push_back({now_ms(), (double)(S->completed + (long long)out.size()), (double)run.dbg_ticks, run.dbg_wait_ms,
-                           run.dbg_ticks ? (double)run.dbg_act / run.dbg_ticks : 0.0, (double)run.solo});
+                           run.dbg_ticks ? (double)run.dbg_act / run.dbg_ticks : 0.0, (double)run.solo, dbg_admit_ms, dbg_flush_ms, dbg_turn_ms, run.dbg_search_ms, run.dbg_launch_ms});
     }
     if (!out.empty()) {
       std::lock_guard<std::mutex> lock(S->m);
@@ -2446,6 +2478,7 @@ static int stream_add_common(sicp_stream S, int32_t n, const StridedCloud& in, i
   std::shared_ptr<Cloud> c = acquire_cloud(S->device);
   SICPCHECK(stage_cloud(h, *c, n, in));
   SICPCHECK(prepare_cloud(h, *c));  // H2D + search-tree build queued on the upload stream; ready_ev recorded
+  SICPCHECK(reserve_features(h, *c));  // (here, on the submitting thread: never inside the worker's turn)
   std::lock_guard<std::mutex> lock(S->m);
   const long long id = S->next_cloud++;
   S->clouds.emplace(id, std::move(c));
