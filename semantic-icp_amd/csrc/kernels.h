@@ -130,7 +130,10 @@ struct KnnArgs {
   int out_stride;  // 0: out_i / out_d are [query][k_out]; > 0: [k_out][out_stride] (packet kernel only: coalesced
                    // for the covariance kernel, which reads one neighbour rank of 64 points at a time)
   int k_out;       // neighbours written per query (<= the list length K the kernel runs with)
+  unsigned long long* live_cnt;  // nullable, packet kernel: kLiveCounters partial counters; every wave adds the number of
+                                 // neighbours it wrote that passed the gate (statistics: sicp_stats.total_active)
 };
+constexpr int kLiveCounters = 1024;  // (spread: ~6 of a 100K-query search's 6250 waves per counter)
 
 struct CovArgs {
   int n, k, C;

@@ -927,10 +927,11 @@ __device__ __forceinline__ void knn_packet_body(const KnnArgs& a, int wg, int n_
   // --- merge the quad's four ascending lists (registers: quad_merge); lane `sub` of the quad emits the entries
   // sub, sub + 4, ... -- [query][K] output: consecutive lanes write consecutive addresses
   quad_merge<K>(bk);
-  if (q_raw < a.q_count) {
+  {
     // [query][K], or [K][out_stride] (consecutive queries -> consecutive addresses)
     const size_t o = a.out_stride > 0 ? (size_t)(a.q_begin + q) : (size_t)(a.q_begin + q) * a.k_out;
     const size_t ks = a.out_stride > 0 ? (size_t)a.out_stride : 1;
+    unsigned live = 0;  // neighbours of this wave that passed the gate (statistics)
 #pragma unroll
     for (int t = 0; t < (K + 3) / 4; ++t) {
       // entry k = 4 t + sub of the merged list (static register indices: a select per lane of the quad)
@@ -939,14 +940,17 @@ __device__ __forceinline__ void knn_packet_body(const KnnArgs& a, int wg, int n_
       for (int s2 = 1; s2 < 4; ++s2)
         if (4 * t + s2 < K) best = sub == s2 ? bk[4 * t + s2] : best;
       const int k = 4 * t + sub;
-      if (k < K && k < a.k_out) {
-        const unsigned orig = (unsigned)best;
-        const float d = best == KEY_EMPTY ? INFINITY : key_dist(best);
-        const bool keep = orig != 0xffffffffu && d < a.gate_sq;  // strict <, float compare (em_icp.hpp:65)
+      const bool mine = q_raw < a.q_count && k < K && k < a.k_out;
+      const unsigned orig = (unsigned)best;
+      const float d = best == KEY_EMPTY ? INFINITY : key_dist(best);
+      const bool keep = orig != 0xffffffffu && d < a.gate_sq;  // strict <, float compare (em_icp.hpp:65)
+      if (mine) {
         a.out_i[o + k * ks] = keep ? a.inv[orig] : -1;
         if (a.out_d) a.out_d[o + k * ks] = d;
       }
+      if (a.live_cnt) live += (unsigned)__popcll(__ballot(mine && keep));
     }
+    if (a.live_cnt && lane == 0 && live) atomicAdd(a.live_cnt + (bid & (kLiveCounters - 1)), (unsigned long long)live);
   }
 }
 

@@ -396,6 +396,7 @@ struct sicp_context {
   bool solo_was_init = false, solo_failed = false;  // the launch in flight starts a solve / the last one did not run to its end
   int solo_skip = 0, solo_penalty = 0;  // after a persistent launch timed out: solves that stay with the tick graph before the next try (doubling)
   bool count_stats = false;           // the align() in progress reports statistics: every search also counts its live slots
+  bool counted_in_search = false;     // ... and the search kernel of the current correspondences did so itself
   DevBuf<double> d_bout28;
   sicp::LmState* h_bstates = nullptr;
   double* h_bout28 = nullptr;
@@ -721,6 +722,7 @@ int run_nn(sicp_context* h, int K, const Cloud& Qc, int q_begin, int q_count, co
     a.dbg = nullptr;
     a.out_stride = out_stride;
     a.k_out = K;
+    a.live_cnt = nullptr;
     // seed hint: what the previous search of the same queries found (same clouds, same K, this align)
     a.seed_hint = (!self && h->hint_ok && out_i == h->idx.p && h->corr_K == K && h->corr_n == Qc.n) ? h->idx.p : nullptr;
     a.hint_K = K;
@@ -729,6 +731,13 @@ int run_nn(sicp_context* h, int K, const Cloud& Qc, int q_begin, int q_count, co
     DevBuf<int> dbg;
     if (want_dbg) { HIPCHECK(dbg.reserve((size_t)2 * q_count)); a.dbg = dbg.p; }
     static const bool lane_per_query = std::getenv("SICP_KNN_LANE_PER_QUERY") != nullptr;  // A/B aid
+    // statistics: the packet kernel counts the neighbours that pass the gate as it writes them (spread over
+    // kLiveCounters partial counters); every other engine leaves it to a kernel of its own (count_active)
+    static const bool count_kernel = std::getenv("SICP_COUNT_KERNEL") != nullptr;  // A/B aid: always the separate kernel
+    if (h->count_stats && !self && out_i == h->idx.p && !lane_per_query && !count_kernel && h->params.nn_method == 1) {
+      a.live_cnt = (unsigned long long*)h->d_count.p;
+      h->counted_in_search = true;
+    }
     if (h->collect) {  // lock-step batch (packet search, no profiling: checked by the driver)
       JobCollector& jc = *h->collect;
       if (!jc.knn[jc.slice].empty() && jc.knn_K[jc.slice] != L) {
@@ -938,6 +947,7 @@ int run_correspondences(sicp_context* h, const double* qt, int K, bool weights) 
   double M[12];
   matrix34(qt, M);
   const bool sem = P.mode == SICP_MODE_SEMANTIC;
+  h->counted_in_search = false;
   if (sem) {  // label segments that are skipped keep (idx, d2) = (-1, +inf)
     HIPCHECK(hipMemsetAsync(h->idx.p, 0xFF, sizeof(int) * slots, h->stream));
     HIPCHECK(hipMemsetD32Async((hipDeviceptr_t)h->d2.p, 0x7f800000, slots, h->stream));
@@ -964,7 +974,7 @@ int run_correspondences(sicp_context* h, const double* qt, int K, bool weights) 
   h->hint_ok = true;
   // statistics: the live slots of this search, counted right behind it (same stream / same job flush: no extra
   // host turn between two solves)
-  if (h->count_stats) SICPCHECK(count_active(h));
+  if (h->count_stats && !h->counted_in_search) SICPCHECK(count_active(h));
   if (weights) SICPCHECK(run_weights(h, qt));
   return SICP_OK;
 }
@@ -1133,8 +1143,8 @@ int align_begin(sicp_context* h, bool want_stats) {
   std::memset(&h->st, 0, sizeof h->st);
   h->hint_ok = false;  // every align() starts its first search from the curve position, like a first call would
   Cloud &S = h->cloud(0), &T = h->cloud(1);
-  HIPCHECK(h->d_count.reserve(1));
-  if (want_stats) HIPCHECK(hipMemsetAsync(h->d_count.p, 0, sizeof(long long), h->stream));
+  HIPCHECK(h->d_count.reserve(sicp::kLiveCounters));
+  if (want_stats) HIPCHECK(hipMemsetAsync(h->d_count.p, 0, sizeof(long long) * sicp::kLiveCounters, h->stream));
   h->count_stats = want_stats;
   SICPCHECK(prepare_cloud(h, S));
   SICPCHECK(prepare_cloud(h, T));
@@ -1190,9 +1200,10 @@ void outer_finish(const sicp_params& P, OuterState& o) {
 int align_end(sicp_context* h, const OuterState& o, double t_begin, int32_t* outer_iters, sicp_stats* stats) {
   h->count_stats = false;
   if (stats) {
-    HIPCHECK(hipMemcpyAsync(h->h_count, h->d_count.p, sizeof(long long), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipMemcpyAsync(h->h_count, h->d_count.p, sizeof(long long) * sicp::kLiveCounters, hipMemcpyDeviceToHost, h->stream));
     HIPCHECK(hipStreamSynchronize(h->stream));
-    h->st.total_active = *h->h_count;
+    h->st.total_active = 0;
+    for (int k = 0; k < sicp::kLiveCounters; ++k) h->st.total_active += h->h_count[k];
   }
   h->st.outer_iters = h->params.mode == SICP_MODE_SEMANTIC ? o.count : o.outer;
   h->st.t_total_ms = now_ms() - t_begin;
@@ -1749,7 +1760,7 @@ int sicp_create(int device_id, sicp_handle* out) {
             hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) == hipSuccess &&
             hipEventCreate(&h->ev0) == hipSuccess && hipEventCreate(&h->ev1) == hipSuccess &&
             hipHostMalloc((void**)&h->h_out28, sizeof(double) * 28, hipHostMallocDefault) == hipSuccess &&
-            hipHostMalloc((void**)&h->h_count, sizeof(long long), hipHostMallocDefault) == hipSuccess &&
+            hipHostMalloc((void**)&h->h_count, sizeof(long long) * sicp::kLiveCounters, hipHostMallocDefault) == hipSuccess &&
             hipHostMalloc((void**)&h->h_lm, sizeof(sicp::LmState), hipHostMallocDefault) == hipSuccess;
   if (!ok) {
     sicp_destroy(h);
