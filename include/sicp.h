@@ -10,8 +10,12 @@
  *
  * Conventions
  *   - extern "C", plain pointers and sizes, opaque handle, int status
- *     (0 = ok, negative = error; no exceptions cross the ABI; the library
- *     never prints).
+ *     (0 = ok, negative = error).  No exception crosses the ABI: every entry
+ *     point and the stream worker thread run inside a barrier that turns
+ *     std::bad_alloc into SICP_ERR_OUT_OF_MEMORY and anything else into
+ *     SICP_ERR_INTERNAL (csrc/abi_barrier.hpp).  The library never prints --
+ *     unless the developer sets SICP_DEBUG in the environment, which unlocks
+ *     the stderr logs of SICP_KNN_STATS / SICP_SOLO_LOG / SICP_STREAM_LOG.
  *   - The caller owns every input/output buffer (host memory unless a name
  *     ends in _device); the handle owns all device memory.
  *   - One handle = one HIP device + one stream.  Handles are independent and
@@ -47,7 +51,10 @@ enum {
   SICP_ERR_TOO_FEW_POINTS = -5,  /* target has fewer than K points (reference: UB,
                                     em_icp.hpp:62-65)                             */
   SICP_ERR_BAD_LABEL = -6,       /* EM label outside 1..C (reference: UB)          */
-  SICP_ERR_OUT_OF_MEMORY = -7
+  SICP_ERR_OUT_OF_MEMORY = -7,   /* host (std::bad_alloc) or device (hipErrorOutOfMemory, or the
+                                    limit of sicp_set_memory_limit) memory exhausted     */
+  SICP_ERR_INTERNAL = -8         /* a C++ exception was caught at the ABI boundary; see
+                                    sicp_last_error() / sicp_stream_last_error()        */
 };
 
 /* ---- which reference class the handle behaves as ------------------------ */
@@ -166,6 +173,13 @@ int sicp_destroy(sicp_handle h);
  * `device_id` currently holds and every arena slab no live buffer sits in (it waits for the device
  * first).  Never required. */
 int sicp_release_pool(int device_id);
+/* Device memory the library may hold on `device_id`, in bytes (0 = no limit, the default): the arena takes no new
+ * slab from the driver beyond it, and whatever then cannot be allocated -- a cloud, a handle's buffers -- fails with
+ * SICP_ERR_OUT_OF_MEMORY (a status, like every other failure; the handle / stream stays usable for smaller work).
+ * Memory already held is not given back by lowering the limit (sicp_release_pool does that).  For a process that
+ * shares its GPU.  sicp_memory_reserved: what the arena holds right now. */
+int sicp_set_memory_limit(int device_id, int64_t bytes);
+int sicp_memory_reserved(int device_id, int64_t* bytes);
 const char* sicp_strerror(int status);
 const char* sicp_last_error(sicp_handle h); /* detail of the last SICP_ERR_HIP */
 const char* sicp_version(void);

@@ -892,6 +892,16 @@ static int solve_impl(const orc_params* p, int n_s, const float* sx, const float
   int n_eval = 0, iter = 0, status = 0;
   accumulate_mt(p, x, n_s, sx, sy, sz, scov9, tx, ty, tz, tcov9, K, idx, w, 1, o);
   n_eval++;
+  /* Ceres: ResidualBlock::Evaluate -> IsArrayValid; "Initial residual and Jacobian evaluation failed": FAILURE,
+   * the parameters stay where they were */
+  for (int k = 0; k < 28; k++)
+    if (!isfinite(o[k])) {
+      memcpy(out_qt, x, sizeof x);
+      if (lm_iters) *lm_iters = 0;
+      if (evals) *evals = n_eval;
+      if (final_cost) *final_cost = o[27];
+      return 3;
+    }
   unpack28(o, H, g, &cost);
   double x_norm = norm7(x);
   double scale[6];
@@ -949,7 +959,8 @@ static int solve_impl(const orc_params* p, int n_s, const float* sx, const float
     orc_se3_plus(x, delta, cand);
     accumulate_mt(p, cand, n_s, sx, sy, sz, scov9, tx, ty, tz, tcov9, K, idx, w, 0, oc);
     n_eval++;
-    double cand_cost = oc[27];
+    /* trust_region_minimizer.cc: "Step failed to evaluate. Treating it as a step with infinite cost" */
+    double cand_cost = isfinite(oc[27]) ? oc[27] : DBL_MAX;
     if (tr && tr->n < tr->max) { tr->cost[tr->n] = cost; tr->radius[tr->n] = radius; tr->cand_cost[tr->n] = cand_cost; tr->accepted[tr->n] = 0; tr->n++; }
     double diff[7];
     for (int i = 0; i < 7; i++) diff[i] = x[i] - cand[i];

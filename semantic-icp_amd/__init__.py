@@ -28,7 +28,7 @@ SE3_EXP, SE3_LOG, SE3_PLUS, SE3_MUL, SE3_INV = 0, 1, 2, 3, 4
 
 OK = 0
 ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_READY = -1, -2, -3, -4
-ERR_TOO_FEW_POINTS, ERR_BAD_LABEL, ERR_OUT_OF_MEMORY = -5, -6, -7
+ERR_TOO_FEW_POINTS, ERR_BAD_LABEL, ERR_OUT_OF_MEMORY, ERR_INTERNAL = -5, -6, -7, -8
 
 
 class SicpParams(C.Structure):
@@ -156,6 +156,8 @@ def lib():
             "sicp_device_count": [C.POINTER(C.c_int)],
             "sicp_create": [C.c_int, C.POINTER(C.c_void_p)],
             "sicp_release_pool": [C.c_int],
+            "sicp_set_memory_limit": [C.c_int, C.c_int64],
+            "sicp_memory_reserved": [C.c_int, C.POINTER(C.c_int64)],
             "sicp_destroy": [C.c_void_p],
             "sicp_default_params": [C.c_int, C.POINTER(SicpParams)],
             "sicp_set_params": [C.c_void_p, C.POINTER(SicpParams)],
@@ -209,6 +211,21 @@ def device_count() -> int:
     return n.value
 
 
+def set_memory_limit(device: int, n_bytes: int) -> None:
+    """Device memory the library may hold on `device` (0 = no limit); beyond it: SicpError(ERR_OUT_OF_MEMORY)."""
+    st = lib().sicp_set_memory_limit(device, n_bytes)
+    if st != OK:
+        raise SicpError(st, "sicp_set_memory_limit")
+
+
+def memory_reserved(device: int) -> int:
+    n = C.c_int64(0)
+    st = lib().sicp_memory_reserved(device, C.byref(n))
+    if st != OK:
+        raise SicpError(st, "sicp_memory_reserved")
+    return n.value
+
+
 def default_params(mode: int) -> SicpParams:
     p = SicpParams()
     st = lib().sicp_default_params(mode, C.byref(p))
@@ -254,7 +271,7 @@ class Engine:
 
     def _check(self, st, where):
         if st != OK:
-            detail = lib().sicp_last_error(self._h).decode() if st in (ERR_HIP, ERR_INVALID_ARGUMENT) else ""
+            detail = lib().sicp_last_error(self._h).decode() if st in (ERR_HIP, ERR_INVALID_ARGUMENT, ERR_OUT_OF_MEMORY, ERR_INTERNAL) else ""
             raise SicpError(st, where, detail)
 
     def close(self):

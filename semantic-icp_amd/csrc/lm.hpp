@@ -242,13 +242,22 @@ SICP_HD inline void lm_feed(LmCore& s, const LmOptions& opt, const double* o) {
   using namespace detail;
   if (s.status != LM_RUNNING) return;
   s.evaluations++;
+  // Ceres rejects an evaluation with a non-finite residual or Jacobian entry (ResidualBlock::Evaluate ->
+  // IsArrayValid): at the start point the solve FAILS ("Initial residual and Jacobian evaluation failed", x stays
+  // x0); at a candidate the step is "treated as a step with infinite cost" (trust_region_minimizer.cc:
+  // candidate_cost = DBL_MAX), i.e. rejected.  Here a non-finite residual shows up as a non-finite sum.  (The cost
+  // entry alone would not do: fast_log.hpp maps NaN / Inf to a finite number; H and g carry the NaN.)
+  bool finite = true;
+  SICP_UNROLL
+  for (int k = 0; k < 28; ++k) finite = finite && (o[k] - o[k] == 0.0);
   if (s.phase == 0) {
+    if (!finite) { s.status = LM_EVAL_FAILED; return; }
     unpack28(o, s.H, s.g, &s.cost);
     s.x_norm = se3::norm7(s.x);
     SICP_UNROLL
     for (int j = 0; j < 6; ++j) s.scale[j] = opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(s.H[6 * j + j])) : 1.0;
   } else {
-    const double cand_cost = o[27];
+    const double cand_cost = finite ? o[27] : 1.7976931348623157e308;
     double diff[7];
     SICP_UNROLL
     for (int i = 0; i < 7; ++i) diff[i] = s.x[i] - s.pose[i];

@@ -791,7 +791,7 @@ __global__ __launch_bounds__(REDUCE_THREADS) void lm_step_batch_kernel(const Bat
 // timeout the abort word is raised, every workgroup leaves, and the host reports an error instead of waiting
 // for a grid that is not resident.
 // ------------------------------------------------------------------------------------------
-// sync[0]: abort word; sync[2 .. 31]: the published pose as 15 granules {tag = evaluations fed, 32 bits of payload}
+// sync[0]: abort word (raised = the launch's first tag); sync[2 .. 31]: the published pose as 15 granules {tag = evaluations fed, 32 bits of payload}
 // (7 doubles in halves + the status: the data is its own flag -- recipe R2 -- so a worker learns the new pose in ONE
 // round trip); sync[kSoloFlags + b]: worker b's flag (= evaluations it has delivered).
 constexpr int kSoloFlags = 32, kSoloGranules = 15;
@@ -810,6 +810,9 @@ __global__ __launch_bounds__(BS, 1) void solve_one_kernel(const SoloArgs A) {
   const AccArgs& a = A.a;
   const int max_evals = A.max_evals, wait_ticks = A.wait_ticks;
   const unsigned tag_base = A.tag_base;
+  // The abort word is raised to a value only THIS launch uses (its first hand-off tag, never 0): a worker that gives
+  // up after the master has already ended regularly leaves a word behind that no later launch mistakes for its own.
+  const unsigned abort_tag = tag_base + 1u;
   unsigned* const sync = A.sync;
   LoadCtx L;
   L.idx = (const SICP_GLOBAL int*)uniform_ptr(a.idx);
@@ -863,8 +866,8 @@ __global__ __launch_bounds__(BS, 1) void solve_one_kernel(const SoloArgs A) {
           if ((spins & 15) != 15 && wait_ticks > 0) continue;  // the clock and the abort word every 16th poll
           const unsigned long long now = __builtin_amdgcn_s_memrealtime();
           if (t0 == 0) t0 = now;
-          if (now - t0 >= (unsigned long long)wait_ticks || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-            __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (now - t0 >= (unsigned long long)wait_ticks || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == abort_tag) {
+            __hip_atomic_store(abort_word, abort_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_abort = 1;
             break;
           }
@@ -995,9 +998,9 @@ __global__ __launch_bounds__(BS, 1) void solve_one_kernel(const SoloArgs A) {
         if ((spins & 15) != 15 && wait_ticks > 0) continue;  // the clock and the abort word every 16th poll
         const unsigned long long now = __builtin_amdgcn_s_memrealtime();
         if (t0 == 0) t0 = now;
-        if (now - t0 >= (unsigned long long)wait_ticks || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+        if (now - t0 >= (unsigned long long)wait_ticks || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == abort_tag) {
           if (lane == 0) {
-            __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(abort_word, abort_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_abort = 1;
           }
           break;

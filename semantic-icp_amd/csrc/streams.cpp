@@ -1,0 +1,401 @@
+// streams.cpp -- registration streams (sicp_stream_*): the continuous batching of solve.cpp without the closed batch.
+#include "engine.hpp"
+
+namespace sicp {
+namespace host {
+
+void stream_fail(sicp_stream_ctx* S, int rc, const std::string& msg) {
+  std::lock_guard<std::mutex> lock(S->m);
+  if (S->error == SICP_OK) { S->error = rc; S->error_msg = msg; }
+  S->cv_done.notify_all();
+  S->cv_space.notify_all();
+}
+
+// The worker: admit queued registrations into free slots, one turn of the continuous batching
+// (BatchRun::turn: finish the tick in flight, queue the searches of the pairs between two solves, launch
+// the next tick), retire the pairs that have converged.  One iteration per tick.
+static void stream_worker_loop(sicp_stream_ctx* S) {
+  if (hipSetDevice(S->device) != hipSuccess) { stream_fail(S, SICP_ERR_NO_DEVICE, "hipSetDevice"); return; }
+  sicp_context* L = S->slots[0];
+  BatchRun run;
+  run.L = L; run.hs = S->slots.data(); run.P = S->params; run.one_launch = true; run.want_stats = false;
+  run.resize(S->cap);
+  run.len = std::min(S->params.lm_batch > 0 ? S->params.lm_batch : 8, sicp::kMaxBatchLen);
+  run.side = L->side_stream;
+  TickGroup G;
+  G.lo = 0; G.hi = S->cap; G.M = S->own1[0]; G.S = &L->ts[0]; G.side_done = L->side_done;
+  JobCollector jc;
+  for (sicp_context* g : S->slots) g->collect = &jc;
+  std::vector<int> free_slots;
+  for (int p = S->cap - 1; p >= 0; --p) free_slots.push_back(p);
+  std::vector<sicp_stream_ctx::Submission> fresh;
+  std::vector<int> fresh_slot;
+  std::vector<sicp_stream_result> out;
+  std::vector<std::array<double, 11>> dbg_log;
+  double dbg_admit_ms = 0, dbg_flush_ms = 0, dbg_turn_ms = 0;
+  for (;;) {
+    // ---- admit
+    fresh.clear(); fresh_slot.clear();
+    {
+      std::unique_lock<std::mutex> lock(S->m);
+      S->cv_work.wait(lock, [&] { return S->stop || !S->queue.empty() || S->in_flight > 0; });
+      if (S->stop) {
+        for (size_t i = 0; i < dbg_log.size(); i += std::max<size_t>(1, dbg_log.size() / 40))
+          std::fprintf(stderr, "[stream] t %.1f ms completed %.0f ticks %.0f waited %.1f ms pairs-per-tick %.1f solo-allowed %.0f | host ms: admit %.1f flush %.1f turn %.1f (of which waited; searches %.1f, tick launch %.1f)\n",
+                       dbg_log[i][0], dbg_log[i][1], dbg_log[i][2], dbg_log[i][3], dbg_log[i][4], dbg_log[i][5], dbg_log[i][6], dbg_log[i][7], dbg_log[i][8], dbg_log[i][9], dbg_log[i][10]);
+        return;
+      }
+      while (!S->queue.empty() && !free_slots.empty()) {
+        fresh.push_back(std::move(S->queue.front()));
+        S->queue.pop_front();
+        fresh_slot.push_back(free_slots.back());
+        free_slots.pop_back();
+        ++S->in_flight;
+      }
+      if (!fresh.empty()) S->cv_space.notify_all();
+      // The last registration of a stream that is being drained may run its solves as persistent launches.  Not
+      // otherwise: a stream that has just begun is alone for a moment too, and the next registrations' feature
+      // kernels would then compete with the persistent grid for the CUs it needs all at once.
+      run.solo = S->params.lm_on_device != 2 && S->draining > 0 && S->queue.empty();
+    }
+    out.clear();
+    const double t_admit0 = now_ms();
+    for (size_t k = 0; k < fresh.size(); ++k) {
+      const int p = fresh_slot[k];
+      sicp_context* h = S->slots[p];
+      // the slot lets go of its previous pair's clouds and takes this pair's
+      h->cl[0] = fresh[k].src;
+      h->cl[1] = fresh[k].tgt;
+      h->corr_valid = false;
+      h->epoch = next_epoch();
+      S->slot_ticket[p] = fresh[k].ticket;
+      S->slot_t0[p] = now_ms();
+      jc.slice = batch_slice(p, S->cap, S->params.knn);
+      int rc = check_ready(h, false);
+      if (rc == SICP_OK) rc = align_begin(h, false);
+      if (rc != SICP_OK) {  // this registration cannot run (too few points, bad labels ...): report it, free the slot
+        sicp_stream_result r;
+        std::memset(&r, 0, sizeof r);
+        r.ticket = fresh[k].ticket; r.status = rc;
+        std::memcpy(r.qt, fresh[k].init, sizeof r.qt);
+        out.push_back(r);
+        free_slots.push_back(p);
+        if (rc == SICP_ERR_HIP) { stream_fail(S, rc, h->last_error); return; }
+        continue;
+      }
+      run.start_pair(p, fresh[k].init);
+    }
+    // the new pairs' features (self-searches, covariances, projections): one launch per kind, on the side
+    // stream, beside the tick in flight and ahead of the pairs' first searches
+    const double t_flush0 = now_ms();
+    dbg_admit_ms += t_flush0 - t_admit0;
+    if (!fresh.empty()) {
+      const int rc = flush_jobs(L, jc, run.side);
+      if (rc != SICP_OK) { stream_fail(S, rc, L->last_error); return; }
+    }
+    const double t_turn0 = now_ms();
+    dbg_flush_ms += t_turn0 - t_flush0;
+    // ---- one turn
+    {
+      const int rc = run.turn(G, jc);
+      if (rc != SICP_OK) { stream_fail(S, rc, L->last_error); return; }
+    }
+    dbg_turn_ms += now_ms() - t_turn0;
+    // ---- retire
+    long long busy = 0, slots_sat = 0;
+    for (int p = 0; p < S->cap; ++p) {
+      if (run.phase[p] != PAIR_DONE) continue;
+      sicp_context* h = S->slots[p];
+      sicp_stream_result r;
+      std::memset(&r, 0, sizeof r);
+      r.ticket = S->slot_ticket[p];
+      r.status = SICP_OK;
+      h->st.outer_iters = S->params.mode == SICP_MODE_SEMANTIC ? run.o[p].count : run.o[p].outer;
+      h->st.t_total_ms = now_ms() - S->slot_t0[p];
+      r.outer_iters = h->st.outer_iters;
+      std::memcpy(r.qt, run.o[p].cur, sizeof r.qt);
+      r.stats = h->st;
+      busy += h->st.total_evals; slots_sat += h->st.lockstep_slots;
+      out.push_back(r);
+      run.phase[p] = PAIR_FREE;
+      free_slots.push_back(p);
+    }
+    {
+      static const bool slog = debug_enabled() && std::getenv("SICP_STREAM_LOG") != nullptr;  // developer aid (needs SICP_DEBUG): kept in memory, printed when the stream ends
+      if (slog && !out.empty())
+        dbg_log.push_back({now_ms(), (double)(S->completed + (long long)out.size()), (double)run.dbg_ticks, run.dbg_wait_ms,
+                           run.dbg_ticks ? (double)run.dbg_act / run.dbg_ticks : 0.0, (double)run.solo, dbg_admit_ms, dbg_flush_ms, dbg_turn_ms, run.dbg_search_ms, run.dbg_launch_ms});
+    }
+    if (!out.empty()) {
+      std::lock_guard<std::mutex> lock(S->m);
+      for (const sicp_stream_result& r : out) S->done.push_back(r);
+      S->in_flight -= (int)out.size();
+      S->completed += (long long)out.size();
+      S->busy_evals += busy; S->slot_evals += slots_sat;
+      S->cv_done.notify_all();
+    }
+  }
+}
+
+// The thread function: an exception that left it would end the process (std::terminate) from inside the library;
+// it becomes the stream's fatal error instead -- every caller blocked in submit / poll wakes up with a status.
+void stream_worker(sicp_stream_ctx* S) {
+  const char* what = nullptr;
+  int rc = SICP_ERR_INTERNAL;
+  try {
+    stream_worker_loop(S);
+    return;
+  } catch (const std::bad_alloc&) {
+    rc = SICP_ERR_OUT_OF_MEMORY; what = "stream worker: out of host memory";
+  } catch (const std::exception& e) {
+    try { stream_fail(S, SICP_ERR_INTERNAL, std::string("stream worker: ") + e.what()); return; } catch (...) { what = "stream worker: exception"; }
+  } catch (...) {
+    what = "stream worker: unknown exception";
+  }
+  try {
+    stream_fail(S, rc, what);
+  } catch (...) {  // (not even the message could be stored: the status alone)
+    std::lock_guard<std::mutex> lock(S->m);
+    if (S->error == SICP_OK) S->error = rc;
+    S->cv_done.notify_all();
+    S->cv_space.notify_all();
+  }
+}
+
+}  // namespace host
+}  // namespace sicp
+
+using namespace sicp::host;
+
+extern "C" {
+
+int sicp_stream_create(int device_id, const sicp_params* params, int32_t max_in_flight, sicp_stream* out) {
+  return abi_guard([&]() -> int {
+    if (!out || !params || max_in_flight < 1 || max_in_flight > 4096) return SICP_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (params->nn_method != 1 || params->lm_on_device == 0 || params->profile != 0) return SICP_ERR_INVALID_ARGUMENT;
+    std::unique_ptr<sicp_stream_ctx> S(new (std::nothrow) sicp_stream_ctx());
+    if (!S) return SICP_ERR_OUT_OF_MEMORY;
+    S->device = device_id;
+    S->cap = max_in_flight;
+    S->params = *params;
+    S->params.reuse_features = 1;  // a stream's cloud keeps its normals / histograms: computed with its first registration
+    S->params.lm_on_device = params->lm_on_device == 2 ? 2 : 1;  // (2: never the persistent solve)
+    auto cleanup = [&](int rc) {
+      for (size_t k = 0; k < S->slots.size(); ++k) {
+        sicp_context* g = S->slots[k];
+        g->collect = nullptr; g->stream = S->own1[k]; g->stream2 = S->own2[k];
+        sicp_destroy(g);
+      }
+      if (S->uploader) sicp_destroy(S->uploader);
+      return rc;
+    };
+    int rc = sicp_create(device_id, &S->uploader);
+    if (rc != SICP_OK) return cleanup(rc);
+    rc = sicp_set_params(S->uploader, &S->params);
+    if (rc != SICP_OK) return cleanup(rc);
+    for (int p = 0; p < S->cap; ++p) {
+      sicp_context* g = nullptr;
+      rc = sicp_create(device_id, &g);
+      if (rc != SICP_OK) return cleanup(rc);
+      S->slots.push_back(g);
+      S->own1.push_back(g->stream);
+      S->own2.push_back(g->stream2);
+      rc = sicp_set_params(g, &S->params);
+      if (rc != SICP_OK) return cleanup(rc);
+    }
+    {  // the leader's batch machinery (what sicp_align_batch sets up per call)
+      sicp_context* h = S->slots[0];
+      rc = batch_reserve(h, S->cap);
+      if (rc != SICP_OK) return cleanup(rc);
+      h->ts[0].tick_valid = false;
+      if (!h->side_stream) {
+        if (hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&h->side_done, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->main_done, hipEventDisableTiming) != hipSuccess)
+          return cleanup(SICP_ERR_HIP);
+      }
+      // every slot's own launches (memsets of the semantic search, cloud waits) go to the side stream
+      for (sicp_context* g : S->slots) { g->stream = h->side_stream; g->stream2 = h->side_stream; g->wait_on_device = true; }
+    }
+    S->slot_ticket.assign(S->cap, 0);
+    S->slot_t0.assign(S->cap, 0.0);
+    S->worker = std::thread(stream_worker, S.get());
+    *out = S.release();
+    return SICP_OK;
+  });
+}
+
+int sicp_stream_destroy(sicp_stream S) {
+  return abi_guard(S, [&]() -> int {
+    if (!S) return SICP_OK;
+    {
+      std::lock_guard<std::mutex> lock(S->m);
+      S->stop = true;
+      S->cv_work.notify_all();
+      S->cv_space.notify_all();
+      S->cv_done.notify_all();
+    }
+    if (S->worker.joinable()) S->worker.join();
+    (void)hipSetDevice(S->device);
+    if (!S->slots.empty() && S->slots[0]->side_stream) (void)hipStreamSynchronize(S->slots[0]->side_stream);
+    for (size_t k = 0; k < S->slots.size(); ++k) (void)hipStreamSynchronize(S->own1[k]);
+    if (S->uploader) (void)hipStreamSynchronize(S->uploader->stream);
+    // the clouds go back to the pool once nothing refers to them: settle their uploads while the upload stream exists
+    for (auto& kv : S->clouds) settle_cloud(*kv.second);
+    for (auto& q : S->queue) { settle_cloud(*q.src); settle_cloud(*q.tgt); }
+    for (size_t k = 0; k < S->slots.size(); ++k) {
+      sicp_context* g = S->slots[k];
+      g->collect = nullptr; g->stream = S->own1[k]; g->stream2 = S->own2[k];
+      sicp_destroy(g);
+    }
+    S->clouds.clear();
+    S->queue.clear();
+    if (S->uploader) sicp_destroy(S->uploader);
+    delete S;
+    return SICP_OK;
+  });
+}
+
+// The worker (error_msg) or another caller thread (api_error) may be writing its string: what is handed out is a copy
+// taken under the lock, stable until the next call of this function on the same stream.
+const char* sicp_stream_last_error(sicp_stream S) {
+  if (!S) return "";
+  try {
+    std::lock_guard<std::mutex> lock(S->m);
+    S->error_copy = !S->error_msg.empty() ? S->error_msg : S->api_error;
+    return S->error_copy.c_str();
+  } catch (...) {
+    return "";
+  }
+}
+
+int sicp_stream_set_confusion(sicp_stream S, int32_t C, const double* cm) {
+  return abi_guard(S, [&]() -> int {
+    if (!S || C < 1 || C > 255 || !cm) return SICP_ERR_INVALID_ARGUMENT;
+    {
+      std::lock_guard<std::mutex> lock(S->m);
+      if (S->submitted > 0) return SICP_ERR_INVALID_ARGUMENT;  // before the first registration
+    }
+    for (size_t k = 0; k < S->slots.size(); ++k) {
+      // (sicp_set_confusion uploads on the handle's stream and waits for it: the slot's own stream, not the side stream)
+      sicp_context* g = S->slots[k];
+      hipStream_t keep = g->stream;
+      g->stream = S->own1[k];
+      int rc = sicp_set_confusion(g, C, cm);
+      if (rc == SICP_OK) rc = ensure_hval(g, S->params.k_cov);  // (one small upload + wait per slot, here rather than in the worker)
+      g->stream = keep;
+      if (rc != SICP_OK) return rc;
+    }
+    return sicp_set_confusion(S->uploader, C, cm);
+  });
+}
+
+static int stream_add_common(sicp_stream S, int32_t n, const StridedCloud& in, int64_t* cloud_id) {
+  if (S->params.mode != SICP_MODE_GICP && !in.label) return SICP_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> up(S->up_m);
+  sicp_context* h = S->uploader;
+  SICPCHECK(set_device(h));
+  std::shared_ptr<Cloud> c = acquire_cloud(S->device);
+  SICPCHECK(stage_cloud(h, *c, n, in));
+  SICPCHECK(prepare_cloud(h, *c));  // H2D + search-tree build queued on the upload stream; ready_ev recorded
+  SICPCHECK(reserve_features(h, *c));  // (here, on the submitting thread: never inside the worker's turn)
+  std::lock_guard<std::mutex> lock(S->m);
+  const long long id = S->next_cloud++;
+  S->clouds.emplace(id, std::move(c));
+  *cloud_id = id;
+  return SICP_OK;
+}
+
+int sicp_stream_add_cloud(sicp_stream S, int32_t n, const float* x, const float* y, const float* z, const uint32_t* label, int64_t* cloud_id) {
+  return abi_guard(S, [&]() -> int {
+    if (!S || !cloud_id || n < 0 || (n > 0 && (!x || !y || !z))) return SICP_ERR_INVALID_ARGUMENT;
+    const StridedCloud in = {(const char*)x, (const char*)y, (const char*)z, (const char*)label, 4, 4};
+    return stream_add_common(S, n, in, cloud_id);
+  });
+}
+
+int sicp_stream_add_cloud_strided(sicp_stream S, int32_t n, const void* xyz, int64_t stride_bytes, const void* label, int64_t label_stride_bytes,
+                                  int64_t* cloud_id) {
+  return abi_guard(S, [&]() -> int {
+    if (!S || !cloud_id || n < 0) return SICP_ERR_INVALID_ARGUMENT;
+    if (n > 0 && (!xyz || stride_bytes < 12 || (label && label_stride_bytes < 4))) return SICP_ERR_INVALID_ARGUMENT;
+    const char* b = (const char*)xyz;
+    const StridedCloud in = {b, b + 4, b + 8, (const char*)label, stride_bytes, label_stride_bytes};
+    return stream_add_common(S, n, in, cloud_id);
+  });
+}
+
+int sicp_stream_release_cloud(sicp_stream S, int64_t cloud_id) {
+  return abi_guard(S, [&]() -> int {
+    if (!S) return SICP_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> lock(S->m);
+    return S->clouds.erase(cloud_id) ? SICP_OK : SICP_ERR_INVALID_ARGUMENT;
+  });
+}
+
+int sicp_stream_submit(sicp_stream S, int64_t source_id, int64_t target_id, const double init_qt[7], int64_t* ticket) {
+  return abi_guard(S, [&]() -> int {
+    if (!S || !init_qt) return SICP_ERR_INVALID_ARGUMENT;
+    std::unique_lock<std::mutex> lock(S->m);
+    if (S->error != SICP_OK) return S->error;
+    // The clouds are taken (as shared references) BEFORE the back-pressure wait: the wait releases the lock, and a
+    // concurrent sicp_stream_release_cloud of either id, or an add_cloud that rehashes the map, would invalidate
+    // iterators held across it.  A cloud released meanwhile still takes part in this registration.
+    std::shared_ptr<Cloud> src, tgt;
+    {
+      auto a = S->clouds.find(source_id), b = S->clouds.find(target_id);
+      if (a == S->clouds.end() || b == S->clouds.end()) return SICP_ERR_INVALID_ARGUMENT;
+      src = a->second; tgt = b->second;
+    }
+    S->cv_space.wait(lock, [&] { return S->stop || S->error != SICP_OK || (int)S->queue.size() < S->cap; });
+    if (S->error != SICP_OK) return S->error;
+    if (S->stop) return SICP_ERR_INVALID_ARGUMENT;
+    sicp_stream_ctx::Submission q;
+    q.ticket = S->next_ticket++;
+    q.src = std::move(src); q.tgt = std::move(tgt);
+    std::memcpy(q.init, init_qt, sizeof q.init);
+    S->queue.push_back(std::move(q));
+    ++S->submitted;
+    if (ticket) *ticket = S->next_ticket - 1;
+    S->cv_work.notify_all();
+    return SICP_OK;
+  });
+}
+
+int sicp_stream_poll(sicp_stream S, int32_t wait, int32_t max_results, sicp_stream_result* results, int32_t* n_results) {
+  return abi_guard(S, [&]() -> int {
+    if (!S || !n_results || max_results < 0 || (max_results > 0 && !results)) return SICP_ERR_INVALID_ARGUMENT;
+    *n_results = 0;
+    std::unique_lock<std::mutex> lock(S->m);
+    const long long want = S->submitted;
+    if (wait == 1)
+      S->cv_done.wait(lock, [&] { return S->stop || S->error != SICP_OK || !S->done.empty() || S->completed >= S->submitted; });
+    else if (wait >= 2) {
+      ++S->draining;
+      S->cv_done.wait(lock, [&] { return S->stop || S->error != SICP_OK || S->completed >= want; });
+      --S->draining;
+    }
+    int k = 0;
+    while (k < max_results && !S->done.empty()) {
+      results[k++] = S->done.front();
+      S->done.pop_front();
+    }
+    *n_results = k;
+    return S->error;
+  });
+}
+
+int sicp_stream_counters(sicp_stream S, int64_t* submitted, int64_t* completed, int64_t* busy_evals, int64_t* slot_evals) {
+  return abi_guard(S, [&]() -> int {
+    if (!S) return SICP_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> lock(S->m);
+    if (submitted) *submitted = S->submitted;
+    if (completed) *completed = S->completed;
+    if (busy_evals) *busy_evals = S->busy_evals;
+    if (slot_evals) *slot_evals = S->slot_evals;
+    return SICP_OK;
+  });
+}
+
+}  // extern "C"

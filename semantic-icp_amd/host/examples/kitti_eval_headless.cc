@@ -49,6 +49,9 @@ struct MethodStream {
     sicp_params p;
     check(sicp_default_params(mode, &p), "sicp_default_params");
     p.num_classes = classes;
+    // two streams (one per method) share the device: neither is ever alone on it, so the persistent one-workgroup-per-CU
+    // solve of a draining stream could not become resident beside the other's ticks -- ticks only
+    p.lm_on_device = 2;
     const char* dev = std::getenv("SICP_DEVICE");
     check(sicp_stream_create(dev ? std::atoi(dev) : 0, &p, in_flight, &s), "sicp_stream_create");
     if (cm) check(sicp_stream_set_confusion(s, classes, cm), "sicp_stream_set_confusion");

@@ -410,3 +410,70 @@ def test_strided_cloud_entry_equals_the_soa_entry():
         assert L.sicp_set_cloud_strided(e._h, sicp.SOURCE, 4, a.ctypes.data, 8, None, 0) == sicp.ERR_INVALID_ARGUMENT
         assert L.sicp_set_cloud_strided(e._h, sicp.SOURCE, 4, None, 12, None, 0) == sicp.ERR_INVALID_ARGUMENT
         assert L.sicp_set_cloud_strided(e._h, sicp.SOURCE, 0, None, 12, None, 0) == sicp.OK
+
+
+def test_memory_limit_turns_into_a_status_not_a_crash():
+    """sicp_set_memory_limit caps what the arena may take from the driver.  An upload that does not fit fails with
+    SICP_ERR_OUT_OF_MEMORY -- a status through the C ABI, from a plain handle and from a stream -- and once the limit
+    is lifted the SAME handle and the SAME stream carry on and produce the bits of an undisturbed run."""
+    cm = synth.confusion_matrix(11)
+    src, sl, tgt, tl, T, _ = synth.lidar_pair(seed=41, n_points=60000)
+    with make_engine(sicp.MODE_EM, 11, cm) as e:
+        e.set_source(src, sl); e.set_target(tgt, tl)
+        ref = e.align(IDENT)
+    assert sicp.lib().sicp_release_pool(0) == sicp.OK
+    assert sicp.lib().sicp_set_memory_limit(-1, 0) == sicp.ERR_INVALID_ARGUMENT
+    assert sicp.lib().sicp_set_memory_limit(0, -5) == sicp.ERR_INVALID_ARGUMENT
+    e = make_engine(sicp.MODE_EM, 11, cm)
+    p = sicp.default_params(sicp.MODE_EM)
+    p.num_classes = 11
+    s = sicp.Stream(0, p, 4, cm)
+    try:
+        held = sicp.memory_reserved(0)
+        sicp.set_memory_limit(0, held + (1 << 20))       # one more megabyte: a 60K-point cloud needs ~10
+        with pytest.raises(sicp.SicpError) as err:
+            e.set_source(src, sl)
+        assert err.value.status == sicp.ERR_OUT_OF_MEMORY
+        with pytest.raises(sicp.SicpError) as err:
+            s.add_cloud(src, sl)
+        assert err.value.status == sicp.ERR_OUT_OF_MEMORY
+        assert sicp.memory_reserved(0) <= held + (1 << 20)
+        sicp.set_memory_limit(0, 0)
+        e.set_source(src, sl); e.set_target(tgt, tl)
+        got = e.align(IDENT)
+        assert np.array_equal(got[0], ref[0]) and got[1]["total_evals"] == ref[1]["total_evals"]
+        a, b = s.add_cloud(src, sl), s.add_cloud(tgt, tl)
+        t = s.submit(a, b, IDENT)
+        res = s.drain()
+        assert len(res) == 1 and res[0][0] == t and res[0][1] == sicp.OK
+        assert np.array_equal(res[0][2], ref[0])
+    finally:
+        sicp.set_memory_limit(0, 0)
+        s.close()
+        e.close()
+
+
+@pytest.mark.parametrize("lm_on_device", [1, 2, 0])
+def test_inner_solve_from_a_non_finite_start_fails_like_ceres(lm_on_device):
+    """A NaN in the start pose makes every residual NaN.  Ceres: "Initial residual and Jacobian evaluation failed",
+    the parameters stay where they were; the oracle says so with status 3 after one evaluation, the product's
+    trust-region machine (all three drivers of it) stops after one evaluation with the start pose untouched."""
+    src, sl, tgt, tl, T_gt, cm = synth.lidar_pair(seed=2, n_points=20000)
+    bad = IDENT.copy()
+    bad[5] = np.nan
+    with make_engine(sicp.MODE_EM, 11, cm, lm_on_device=lm_on_device) as e:
+        e.set_source(src, sl); e.set_target(tgt, tl)
+        idx, d2, w = e.correspondences(IDENT)
+        qt, info = e.solve(bad)
+        cov_s, _, _, _ = e.covariances(sicp.SOURCE)
+        cov_t, _, _, _ = e.covariances(sicp.TARGET)
+        again, info2 = e.solve(IDENT)      # the handle is fine afterwards
+    assert info["evals"] == 1 and info["lm_iters"] == 0
+    assert np.array_equal(qt, bad, equal_nan=True)
+    op = oracle_params(O.MODE_EM, 11)
+    oq, oinfo = O.solve(op, src, cov_s, tgt, cov_t, idx, w, bad)
+    assert oinfo["status"] == 3 and oinfo["evals"] == 1 and np.array_equal(oq, bad, equal_nan=True)
+    oq2, oinfo2 = O.solve(op, src, cov_s, tgt, cov_t, idx, w, IDENT)
+    assert info2["lm_iters"] == oinfo2["lm_iters"]
+    rot, trn = pose_delta(oq2, again)
+    assert rot < 1e-7 and trn < 1e-7
