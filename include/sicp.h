@@ -295,6 +295,19 @@ int sicp_stream_add_cloud_strided(sicp_stream s, int32_t n, const void* xyz, int
 int sicp_stream_release_cloud(sicp_stream s, int64_t cloud_id);
 int sicp_stream_submit(sicp_stream s, int64_t source_id, int64_t target_id, const double init_qt[7],
                        int64_t* ticket);
+/* sicp_stream_submit with options (flags = 0: the same):
+ *   SICP_SUBMIT_FUSED_LABELS   SICP_MODE_EM: getFusedLabels(out, final pose) (em_icp.hpp:202-268, what
+ *       exec/scenenet_eval.cc:193-198 calls right after align) is computed when the registration retires -- one more
+ *       K = 4 search and one label kernel, queued beside the running registrations -- and kept until
+ *       sicp_stream_take_labels(ticket) fetches it (once; n = the source cloud's point count, caller order).  The
+ *       registration's result is only handed out by sicp_stream_poll when its labels are there.
+ *   SICP_SUBMIT_FRESH_FEATURES the normals / label histograms of BOTH clouds are recomputed for this registration,
+ *       like every align() of the reference does (em_icp.hpp:28-29, gicp.hpp:33-34), instead of being kept with the
+ *       cloud (a stream's default: what setSourceCloud(cloud, kdtree, covs) exists for).  Same values either way. */
+enum { SICP_SUBMIT_FUSED_LABELS = 1, SICP_SUBMIT_FRESH_FEATURES = 2 };
+int sicp_stream_submit_ex(sicp_stream s, int64_t source_id, int64_t target_id, const double init_qt[7],
+                          uint32_t flags, int64_t* ticket);
+int sicp_stream_take_labels(sicp_stream s, int64_t ticket, int32_t n, uint32_t* out_labels);
 int sicp_stream_poll(sicp_stream s, int32_t wait, int32_t max_results, sicp_stream_result* results,
                      int32_t* n_results);
 /* counters since creation: registrations submitted / finished, and -- over the finished ones -- their

@@ -29,6 +29,7 @@ SE3_EXP, SE3_LOG, SE3_PLUS, SE3_MUL, SE3_INV = 0, 1, 2, 3, 4
 OK = 0
 ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_READY = -1, -2, -3, -4
 ERR_TOO_FEW_POINTS, ERR_BAD_LABEL, ERR_OUT_OF_MEMORY, ERR_INTERNAL = -5, -6, -7, -8
+SUBMIT_FUSED_LABELS, SUBMIT_FRESH_FEATURES = 1, 2
 
 
 class SicpParams(C.Structure):
@@ -187,6 +188,8 @@ def lib():
             "sicp_stream_add_cloud_strided": [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)],
             "sicp_stream_release_cloud": [C.c_void_p, C.c_int64],
             "sicp_stream_submit": [C.c_void_p, C.c_int64, C.c_int64, _dp, C.POINTER(C.c_int64)],
+            "sicp_stream_submit_ex": [C.c_void_p, C.c_int64, C.c_int64, _dp, C.c_uint32, C.POINTER(C.c_int64)],
+            "sicp_stream_take_labels": [C.c_void_p, C.c_int64, C.c_int32, _up],
             "sicp_stream_poll": [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(SicpStreamResult), C.POINTER(C.c_int32)],
             "sicp_stream_counters": [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
             "sicp_synchronize": [C.c_void_p],
@@ -510,11 +513,22 @@ class Stream:
     def release_cloud(self, cloud_id: int):
         self._check(lib().sicp_stream_release_cloud(self._s, cloud_id), "sicp_stream_release_cloud")
 
-    def submit(self, source_id: int, target_id: int, init_qt=None) -> int:
+    def submit(self, source_id: int, target_id: int, init_qt=None, fused_labels: bool = False, fresh_features: bool = False) -> int:
+        """fused_labels: getFusedLabels at the final pose comes with the result (take_labels); fresh_features: the
+        normals / histograms of both clouds are recomputed for this registration, like an align() of the reference"""
         init = np.array([0, 0, 0, 1, 0, 0, 0], dtype=np.float64) if init_qt is None else np.ascontiguousarray(init_qt, dtype=np.float64)
         t = C.c_int64(0)
-        self._check(lib().sicp_stream_submit(self._s, source_id, target_id, _ptr(init, _dp), C.byref(t)), "sicp_stream_submit")
+        flags = (SUBMIT_FUSED_LABELS if fused_labels else 0) | (SUBMIT_FRESH_FEATURES if fresh_features else 0)
+        if flags:
+            self._check(lib().sicp_stream_submit_ex(self._s, source_id, target_id, _ptr(init, _dp), flags, C.byref(t)), "sicp_stream_submit_ex")
+        else:
+            self._check(lib().sicp_stream_submit(self._s, source_id, target_id, _ptr(init, _dp), C.byref(t)), "sicp_stream_submit")
         return t.value
+
+    def take_labels(self, ticket: int, n_source: int):
+        out = np.empty(n_source, dtype=np.uint32)
+        self._check(lib().sicp_stream_take_labels(self._s, ticket, n_source, _ptr(out, _up)), "sicp_stream_take_labels")
+        return out
 
     def poll(self, wait: int = 0, max_results: int = 1024):
         buf = (SicpStreamResult * max_results)()

@@ -364,6 +364,7 @@ struct sicp_context {
   long long* h_count = nullptr;   // pinned
   DevBuf<float> tmpx, tmpy, tmpz;
   DevBuf<uint32_t> tmpl;
+  HostBuf<uint32_t> h_labels;  // pinned: fused labels of a stream slot on their way back
   // lock-step batch (sicp_align_batch), owned by the batch's first handle: one BatchArgs and one LM
   // state per pair, pinned mirrors, and the captured [accumulate_batch, lm_step_batch] x lm_batch graph
   TickSet ts[2];  // two sets: the halves of a batch alternate, one's tick runs while the host turns the other around
@@ -412,9 +413,11 @@ struct sicp_stream_ctx {
     long long ticket;
     std::shared_ptr<Cloud> src, tgt;
     double init[7];
+    unsigned flags;  // SICP_SUBMIT_*
   };
   std::deque<Submission> queue;
   std::deque<sicp_stream_result> done;
+  std::unordered_map<long long, std::vector<uint32_t>> labels;  // ticket -> getFusedLabels of a SICP_SUBMIT_FUSED_LABELS registration, until taken
   std::unordered_map<long long, std::shared_ptr<Cloud>> clouds;
   long long next_cloud = 1, next_ticket = 1;
   long long submitted = 0, completed = 0, busy_evals = 0, slot_evals = 0;
@@ -428,6 +431,8 @@ struct sicp_stream_ctx {
   // ---- worker only
   std::vector<long long> slot_ticket;
   std::vector<double> slot_t0;
+  std::vector<unsigned> slot_flags;
+  std::vector<hipEvent_t> slot_ev;  // SICP_SUBMIT_FUSED_LABELS: recorded behind the label kernel + read-back of the slot
   std::thread worker;
 };
 
@@ -576,7 +581,8 @@ int run_tick(sicp_context* h, hipStream_t M, sicp_handle* hs, int n, const std::
 // loop -- only for the end of the current tick.
 // PAIR_FIRST: the pair's start-up pipeline (features, first search, weights) is queued on the start-up stream; it joins
 // the ticks when the event of its chunk has completed
-enum { PAIR_FREE = -1, PAIR_NEED_SEARCH = 0, PAIR_JOINING, PAIR_SOLVING, PAIR_DONE, PAIR_FIRST };
+// PAIR_LABELS (streams only): converged; its getFusedLabels pass is queued and the slot waits for the labels
+enum { PAIR_FREE = -1, PAIR_NEED_SEARCH = 0, PAIR_JOINING, PAIR_SOLVING, PAIR_DONE, PAIR_FIRST, PAIR_LABELS };
 
 // pairs [lo, hi) that advance together: one tick stream, one argument set
 struct TickGroup {
@@ -650,6 +656,11 @@ struct BatchRun {
   int turn(TickGroup& G, JobCollector& jc);
 };
 
+// getFusedLabels (em_icp.hpp:202-268) in two halves, so that a stream slot need not wait for it: queue the K = 4 search
+// (collected into the handle's job list when it has one: flush before `labels_launch`) ...
+int labels_search(sicp_context* h, const double* qt);
+// ... and the label kernel behind it on `st`, device order -> h->tmpl
+int labels_launch(sicp_context* h, const double* qt, hipStream_t st);
 int align_batch(sicp_handle* hs, int32_t n, const double* init_qt, double* out_qt, int32_t* outer_iters, sicp_stats* stats);
 
 }  // namespace host

@@ -366,7 +366,9 @@ int sicp_accumulate_batch(sicp_handle* hs, int32_t n, const double* qt, double* 
       h->ts[0].h_batch[p].nb = nb;
       HIPCHECK(hipStreamSynchronize(g->stream));  // the pair's correspondences are complete
     }
-    *h->ts[0].h_bhdr = sicp::BatchHeader{n, {0, 0, 0}};
+    // (SICP_ACC_INNER_REPEAT, developer aid: the kernel repeats its range that many times inside one launch)
+    static const int inner = [] { const char* e = std::getenv("SICP_ACC_INNER_REPEAT"); return e ? std::atoi(e) : 0; }();
+    *h->ts[0].h_bhdr = sicp::BatchHeader{n, {inner, 0, 0}};
     HIPCHECK(hipMemcpyAsync(h->ts[0].d_bhdr.p, h->ts[0].h_bhdr, sizeof(sicp::BatchHeader), hipMemcpyHostToDevice, h->stream));
     HIPCHECK(hipMemcpyAsync(h->ts[0].d_batch.p, h->ts[0].h_batch, sizeof(sicp::BatchArgs) * n, hipMemcpyHostToDevice, h->stream));
     if (repeat < 1) repeat = 1;
@@ -608,7 +610,6 @@ int sicp_fused_labels(sicp_handle h, const double qt[7], uint32_t* out_labels) {
     SICPCHECK(set_device(h));
     if (h->params.mode != SICP_MODE_EM) return SICP_ERR_INVALID_ARGUMENT;
     SICPCHECK(check_ready(h, true));
-    const sicp_params& P = h->params;
     Cloud &S = h->cloud(0), &T = h->cloud(1);
     if (T.n < 4) return SICP_ERR_TOO_FEW_POINTS;
     SICPCHECK(prepare_cloud(h, S));
@@ -616,22 +617,8 @@ int sicp_fused_labels(sicp_handle h, const double qt[7], uint32_t* out_labels) {
     // getFusedLabels reuses what align() left behind (em_icp.hpp:230-241)
     if (!features_current(h, S, true)) SICPCHECK(compute_features(h, S, true));
     if (!features_current(h, T, true)) SICPCHECK(compute_features(h, T, true));
-    SICPCHECK(run_correspondences(h, qt, 4, false));  // K = 4 is a literal here (em_icp.hpp:221)
-    h->corr_valid = false;                            // K may differ from params.knn
-    h->hint_ok = false;
-    sicp::WeightArgs a;
-    a.n_s = S.n; a.K = 4; a.C = P.num_classes;
-    a.idx = h->idx.p;
-    a.srec = S.rec.p; a.trec = T.rec.p;
-    SICPCHECK(ensure_proj(h, S));
-    SICPCHECK(ensure_proj(h, T));
-    a.s_proj = S.proj.p; a.t_proj = T.proj.p;
-    fill_pose(qt, a.pose);
-    a.one_m_eps = 1.0 - P.epsilon;
-    a.bool_probability = P.quirk_bool_probability;
-    a.w = nullptr;
-    HIPCHECK(h->tmpl.reserve((size_t)(S.n > 0 ? S.n : 1)));
-    HIPCHECK(sicp::launch_fused_labels(a, h->tmpl.p, h->stream));
+    SICPCHECK(labels_search(h, qt));
+    SICPCHECK(labels_launch(h, qt, h->stream));
     std::vector<uint32_t> tmp(S.n);
     if (S.n > 0) HIPCHECK(hipMemcpyAsync(tmp.data(), h->tmpl.p, sizeof(uint32_t) * S.n, hipMemcpyDeviceToHost, h->stream));
     HIPCHECK(hipStreamSynchronize(h->stream));

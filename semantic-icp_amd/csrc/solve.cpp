@@ -188,13 +188,23 @@ int tick_launch(sicp_context* h, TickSet& S, hipStream_t M, sicp_handle* hs, int
   // [accumulate, lm_step_batch] x len as an explicit graph with fixed grids: the kernels read the
   // number of pairs from the header and their status from the LM states, so the graph is instantiated once per tick set
   // (buffer addresses) and never touched when pairs come and go or batches differ in size.
-  {
+  // SICP_NO_GRAPH: the same 2 x len kernels as plain launches.  For profilers: rocprofv3 (ROCm 7.2) dies with a segmentation
+  // fault when a thread other than the main one launches graphs while it traces kernels (tools/r04/two_thread_dispatch.hip
+  // reproduces it without this library), and a stream's ticks are launched by its worker thread.  Same kernels, same bits.
+  static const bool no_graph = std::getenv("SICP_NO_GRAPH") != nullptr;
+  if (no_graph) {
+    const int cap = std::min(S.cap, kMaxActivePairs);
+    for (int b = 0; b < len; ++b) {
+      HIPCHECK(sicp::launch_accumulate_batch(hs[act[0]]->corr_K, h->params.use_sqloss, S.d_bhdr.p, S.d_batch.p, cap, M));
+      HIPCHECK(sicp::launch_lm_step_batch(S.d_bhdr.p, S.d_batch.p, cap, M));
+    }
+  } else {
     int built = 0;
     HIPCHECK(sicp::batch_graph_prepare(S.graph, hs[act[0]]->corr_K, h->params.use_sqloss, S.d_bhdr.p, S.d_batch.p, std::min(S.cap, kMaxActivePairs),
                                        len, &built));
     h->st.graph_builds += built;
+    HIPCHECK(hipGraphLaunch(S.graph.exec, M));
   }
-  HIPCHECK(hipGraphLaunch(S.graph.exec, M));
   HIPCHECK(hipMemcpyAsync(h->h_bstates + lo, h->d_bstates.p + lo, sizeof(sicp::LmState) * (hi - lo), hipMemcpyDeviceToHost, M));
   return SICP_OK;
 }
@@ -329,12 +339,18 @@ int BatchRun::turn(TickGroup& G, JobCollector& jc) {
       HIPCHECK(hipStreamWaitEvent(G.M, hs[p]->ev_join, 0));
     }
   }
-  // this round's searches run beside the tick
-  if (any_search && one_launch) {
-    SICPCHECK(flush_jobs(h, jc, side));
-    HIPCHECK(hipEventRecord(G.side_done, side));
-    G.side_recorded = true;
-  }
+  // this round's searches run beside the tick (SICP_TICK_FIRST, tuning aid: they are queued AFTER the tick's launch)
+  static const bool tick_first = std::getenv("SICP_TICK_FIRST") != nullptr;
+  auto flush_round = [&]() -> int {
+    if (any_search && one_launch) {
+      SICPCHECK(flush_jobs(h, jc, side));
+      HIPCHECK(hipEventRecord(G.side_done, side));
+      G.side_recorded = true;
+      any_search = false;
+    }
+    return SICP_OK;
+  };
+  if (!tick_first || G.act.empty()) SICPCHECK(flush_round());
   if (G.act.empty()) return SICP_OK;
   // the tick reads its pairs' arguments in ascending slot order (the order of the argument array)
   std::sort(G.act.begin(), G.act.end());
@@ -355,6 +371,7 @@ int BatchRun::turn(TickGroup& G, JobCollector& jc) {
                        solo_now ? (n == 1 ? sicp::kSoloMaxEvals : 64) : 0);
   dbg_launch_ms += now_ms() - dbg_t_launch0;
   if (rc != SICP_OK) return rc;
+  SICPCHECK(flush_round());
   G.pending = true;
   return SICP_OK;
 }

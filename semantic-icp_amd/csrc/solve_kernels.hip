@@ -434,7 +434,10 @@ __device__ __forceinline__ void load_regs(const LoadCtx& L, int last, int g, Gro
 constexpr int RED_ROWS = SICP_RED_ROWS;  // divides 28; RED_ROWS * 4 <= 64 lanes
 constexpr int RED_STRIDE = 66;
 static_assert(28 % RED_ROWS == 0 && RED_ROWS * 4 <= 64, "one lane per (row, quarter)");
-constexpr int COMB_CHUNKS = 8;  // chunks whose four wave sums wait in LDS for one combining pass
+#ifndef SICP_COMB_CHUNKS
+#define SICP_COMB_CHUNKS 8
+#endif
+constexpr int COMB_CHUNKS = SICP_COMB_CHUNKS;  // chunks whose four wave sums wait in LDS for one combining pass
 __device__ __forceinline__ void wave_reduce(const double (&acc)[28], SICP_LDS double* tile, SICP_LDS double* out28, int lane) {
   const int r = lane >> 2, q = lane & 3;
   const SICP_LDS v2d* mine = (const SICP_LDS v2d*)(tile + min(r, RED_ROWS - 1) * RED_STRIDE + 16 * q);
@@ -631,6 +634,12 @@ __global__ __launch_bounds__(BS, SICP_ACC_OCC) void accumulate_staged_kernel(con
   SICP_LDS char* stage = (SICP_LDS char*)stage_all + wave * (SG * STAGE_SLOT_BYTES);
   SICP_LDS double* tile = (SICP_LDS double*)smem + wave * (RED_ROWS * RED_STRIDE);
 
+  // developer aid (tools/corun_probe.py): hdr->pad_[0] > 1 repeats the workgroup's whole range that many times inside
+  // ONE launch -- the same sums every time -- which keeps the persistent workgroups resident the way a fused multi-
+  // evaluation kernel would, so that what co-resides with them can be measured.  0 / 1 in every product launch.
+  const int item_first = item;
+  for (int rep = uniform_i32(hdr->pad_[0] > 1 ? hdr->pad_[0] : 1); rep > 0; --rep) {
+  item = item_first;
   while (item < item_end) {
     // the pair this item belongs to: the last one that begins at or before it (always a running one)
     int lo = 0, hi = n_pairs - 1;
@@ -675,6 +684,7 @@ __global__ __launch_bounds__(BS, SICP_ACC_OCC) void accumulate_staged_kernel(con
 
     accumulate_segment<K, SQLOSS, BS>(L, M, chunk_lo, n_here, n_chunks, steps, uniform_i32(geo.chunk_groups), partials, stage, tile, comb, lane, wave);
     item += n_here;
+  }
   }
 }
 
@@ -747,7 +757,10 @@ __device__ __forceinline__ void reduce_partials_block(const double* __restrict__
 // (lm.hpp: the same lm_feed the host loop runs).  One workgroup per pair; the grid is the capacity of
 // the batch buffers, the blocks beyond the number of active pairs leave at once.  Thread 0 takes the
 // trust-region step (serial: ~10 us, the longest link of a pair-alone evaluation).
-__global__ __launch_bounds__(REDUCE_THREADS) void lm_step_batch_kernel(const BatchHeader* __restrict__ hdr, const BatchArgs* __restrict__ batch) {
+#ifndef SICP_LM_STEP_WAVES
+#define SICP_LM_STEP_WAVES 1  // waves per SIMD the LM step is compiled for (1: lm_feed gets the 312 VGPRs it wants)
+#endif
+__global__ __launch_bounds__(REDUCE_THREADS, SICP_LM_STEP_WAVES) void lm_step_batch_kernel(const BatchHeader* __restrict__ hdr, const BatchArgs* __restrict__ batch) {
   if ((int)blockIdx.x >= hdr->n_pairs) return;
   const BatchArgs& B = batch[blockIdx.x];
   LmState* lm = B.a.lm_step;

@@ -500,6 +500,34 @@ int flush_jobs(sicp_context* h, JobCollector& jc, hipStream_t base) {
   return SICP_OK;
 }
 
+// getFusedLabels (em_icp.hpp:202-268): the K = 4 search at the final pose ...
+int labels_search(sicp_context* h, const double* qt) {
+  SICPCHECK(run_correspondences(h, qt, 4, false));  // K = 4 is a literal there (em_icp.hpp:221)
+  h->corr_valid = false;                            // K may differ from params.knn
+  h->hint_ok = false;
+  return SICP_OK;
+}
+
+// ... and arg-max of the label posterior over the classes (em_icp.hpp:230-266), one lane per source point
+int labels_launch(sicp_context* h, const double* qt, hipStream_t st) {
+  const sicp_params& P = h->params;
+  Cloud &S = h->cloud(0), &T = h->cloud(1);
+  sicp::WeightArgs a;
+  a.n_s = S.n; a.K = 4; a.C = P.num_classes;
+  a.idx = h->idx.p;
+  a.srec = S.rec.p; a.trec = T.rec.p;
+  SICPCHECK(ensure_proj(h, S));
+  SICPCHECK(ensure_proj(h, T));
+  a.s_proj = S.proj.p; a.t_proj = T.proj.p;
+  fill_pose(qt, a.pose);
+  a.one_m_eps = 1.0 - P.epsilon;
+  a.bool_probability = P.quirk_bool_probability;
+  a.w = nullptr;
+  HIPCHECK(h->tmpl.reserve((size_t)(S.n > 0 ? S.n : 1)));
+  HIPCHECK(sicp::launch_fused_labels(a, h->tmpl.p, st));
+  return SICP_OK;
+}
+
 // statistics only: add the number of live slots of the current search to the device counter (run_correspondences)
 int count_active(sicp_context* h) {
   if (h->collect) {

@@ -70,9 +70,14 @@ static void stream_worker_loop(sicp_stream_ctx* S) {
       h->epoch = next_epoch();
       S->slot_ticket[p] = fresh[k].ticket;
       S->slot_t0[p] = now_ms();
+      S->slot_flags[p] = fresh[k].flags;
       jc.slice = batch_slice(p, S->cap, S->params.knn);
       int rc = check_ready(h, false);
+      // SICP_SUBMIT_FRESH_FEATURES: this registration recomputes the features of both its clouds, like an align() of
+      // the reference (the slot's epoch is new, so align_begin finds them stale)
+      h->params.reuse_features = (fresh[k].flags & SICP_SUBMIT_FRESH_FEATURES) ? 0 : 1;
       if (rc == SICP_OK) rc = align_begin(h, false);
+      h->params.reuse_features = 1;
       if (rc != SICP_OK) {  // this registration cannot run (too few points, bad labels ...): report it, free the slot
         sicp_stream_result r;
         std::memset(&r, 0, sizeof r);
@@ -101,9 +106,61 @@ static void stream_worker_loop(sicp_stream_ctx* S) {
       if (rc != SICP_OK) { stream_fail(S, rc, L->last_error); return; }
     }
     dbg_turn_ms += now_ms() - t_turn0;
+    // ---- fused labels of the pairs that have just converged (SICP_SUBMIT_FUSED_LABELS): the K = 4 searches of all of
+    //      them in one job launch on the side stream, then per pair the label kernel, the read-back into the slot's
+    //      pinned buffer and an event; the slot stays taken (PAIR_LABELS) until that event has completed
+    {
+      bool any = false;
+      for (int p = 0; p < S->cap; ++p) {
+        if (run.phase[p] != PAIR_DONE || !(S->slot_flags[p] & SICP_SUBMIT_FUSED_LABELS)) continue;
+        sicp_context* h = S->slots[p];
+        jc.slice = 0;
+        const sicp_stats keep = h->st;  // (the registration's own counters: the label pass is not part of its align())
+        const int rc = labels_search(h, run.o[p].cur);
+        h->st = keep;
+        if (rc != SICP_OK) { stream_fail(S, rc, h->last_error); return; }
+        run.phase[p] = PAIR_LABELS;
+        S->slot_flags[p] |= 0x80000000u;  // queued in this turn
+        any = true;
+      }
+      if (any) {
+        int rc = flush_jobs(L, jc, run.side);
+        if (rc != SICP_OK) { stream_fail(S, rc, L->last_error); return; }
+        for (int p = 0; p < S->cap; ++p) {
+          if (!(S->slot_flags[p] & 0x80000000u)) continue;
+          S->slot_flags[p] &= ~0x80000000u;
+          sicp_context* h = S->slots[p];
+          const int n = h->cloud(0).n;
+          rc = labels_launch(h, run.o[p].cur, run.side);
+          hipError_t e = rc == SICP_OK ? h->h_labels.resize((size_t)(n > 0 ? n : 1)) : hipSuccess;
+          if (rc == SICP_OK && e == hipSuccess && n > 0)
+            e = hipMemcpyAsync(h->h_labels.data(), h->tmpl.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, run.side);
+          if (rc == SICP_OK && e == hipSuccess && !S->slot_ev[p]) e = hipEventCreateWithFlags(&S->slot_ev[p], hipEventDisableTiming);
+          if (rc == SICP_OK && e == hipSuccess) e = hipEventRecord(S->slot_ev[p], run.side);
+          if (rc != SICP_OK || e != hipSuccess) { stream_fail(S, rc != SICP_OK ? rc : SICP_ERR_HIP, rc != SICP_OK ? h->last_error : std::string("fused labels: ") + hipGetErrorString(e)); return; }
+        }
+      }
+    }
     // ---- retire
     long long busy = 0, slots_sat = 0;
+    int labels_waiting = -1;
     for (int p = 0; p < S->cap; ++p) {
+      if (run.phase[p] == PAIR_LABELS) {
+        const hipError_t q = hipEventQuery(S->slot_ev[p]);
+        if (q == hipErrorNotReady) { if (labels_waiting < 0) labels_waiting = p; continue; }
+        if (q != hipSuccess) { stream_fail(S, SICP_ERR_HIP, std::string("fused labels: ") + hipGetErrorString(q)); return; }
+        // device order -> the caller's order (a point that never went to the device has no correspondences: label 0)
+        sicp_context* h = S->slots[p];
+        const Cloud& C0 = h->cloud(0);
+        std::vector<uint32_t> lab((size_t)C0.n_caller, 0u);
+        for (int d = 0; d < C0.n; ++d) lab[(size_t)C0.caller_index(d)] = h->h_labels[d];
+        {
+          std::lock_guard<std::mutex> lock(S->m);
+          S->labels[S->slot_ticket[p]] = std::move(lab);
+        }
+        run.phase[p] = PAIR_DONE;
+        S->slot_flags[p] &= ~(unsigned)SICP_SUBMIT_FUSED_LABELS;
+      }
       if (run.phase[p] != PAIR_DONE) continue;
       sicp_context* h = S->slots[p];
       sicp_stream_result r;
@@ -126,6 +183,8 @@ static void stream_worker_loop(sicp_stream_ctx* S) {
         dbg_log.push_back({now_ms(), (double)(S->completed + (long long)out.size()), (double)run.dbg_ticks, run.dbg_wait_ms,
                            run.dbg_ticks ? (double)run.dbg_act / run.dbg_ticks : 0.0, (double)run.solo, dbg_admit_ms, dbg_flush_ms, dbg_turn_ms, run.dbg_search_ms, run.dbg_launch_ms});
     }
+    // nothing left to advance but label read-backs: wait for the first instead of spinning through empty turns
+    if (out.empty() && labels_waiting >= 0 && run.live(G) == 0 && !G.pending) (void)hipEventSynchronize(S->slot_ev[labels_waiting]);
     if (!out.empty()) {
       std::lock_guard<std::mutex> lock(S->m);
       for (const sicp_stream_result& r : out) S->done.push_back(r);
@@ -220,6 +279,8 @@ int sicp_stream_create(int device_id, const sicp_params* params, int32_t max_in_
     }
     S->slot_ticket.assign(S->cap, 0);
     S->slot_t0.assign(S->cap, 0.0);
+    S->slot_flags.assign(S->cap, 0u);
+    S->slot_ev.assign(S->cap, nullptr);
     S->worker = std::thread(stream_worker, S.get());
     *out = S.release();
     return SICP_OK;
@@ -249,6 +310,8 @@ int sicp_stream_destroy(sicp_stream S) {
       g->collect = nullptr; g->stream = S->own1[k]; g->stream2 = S->own2[k];
       sicp_destroy(g);
     }
+    for (hipEvent_t e : S->slot_ev)
+      if (e) (void)hipEventDestroy(e);
     S->clouds.clear();
     S->queue.clear();
     if (S->uploader) sicp_destroy(S->uploader);
@@ -335,8 +398,27 @@ int sicp_stream_release_cloud(sicp_stream S, int64_t cloud_id) {
 }
 
 int sicp_stream_submit(sicp_stream S, int64_t source_id, int64_t target_id, const double init_qt[7], int64_t* ticket) {
+  return abi_guard(S, [&]() -> int { return sicp_stream_submit_ex(S, source_id, target_id, init_qt, 0u, ticket); });
+}
+
+int sicp_stream_take_labels(sicp_stream S, int64_t ticket, int32_t n, uint32_t* out_labels) {
+  return abi_guard(S, [&]() -> int {
+    if (!S || n < 0 || (n > 0 && !out_labels)) return SICP_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> lock(S->m);
+    auto it = S->labels.find(ticket);
+    if (it == S->labels.end()) return SICP_ERR_NOT_READY;  // not submitted with SICP_SUBMIT_FUSED_LABELS, not finished yet, or taken already
+    if ((size_t)n != it->second.size()) return SICP_ERR_INVALID_ARGUMENT;
+    if (n > 0) std::memcpy(out_labels, it->second.data(), sizeof(uint32_t) * (size_t)n);
+    S->labels.erase(it);
+    return SICP_OK;
+  });
+}
+
+int sicp_stream_submit_ex(sicp_stream S, int64_t source_id, int64_t target_id, const double init_qt[7], uint32_t flags, int64_t* ticket) {
   return abi_guard(S, [&]() -> int {
     if (!S || !init_qt) return SICP_ERR_INVALID_ARGUMENT;
+    if (flags & ~(uint32_t)(SICP_SUBMIT_FUSED_LABELS | SICP_SUBMIT_FRESH_FEATURES)) return SICP_ERR_INVALID_ARGUMENT;
+    if ((flags & SICP_SUBMIT_FUSED_LABELS) && S->params.mode != SICP_MODE_EM) return SICP_ERR_INVALID_ARGUMENT;  // getFusedLabels is EmIterativeClosestPoint's
     std::unique_lock<std::mutex> lock(S->m);
     if (S->error != SICP_OK) return S->error;
     // The clouds are taken (as shared references) BEFORE the back-pressure wait: the wait releases the lock, and a
@@ -355,6 +437,7 @@ int sicp_stream_submit(sicp_stream S, int64_t source_id, int64_t target_id, cons
     q.ticket = S->next_ticket++;
     q.src = std::move(src); q.tgt = std::move(tgt);
     std::memcpy(q.init, init_qt, sizeof q.init);
+    q.flags = flags;
     S->queue.push_back(std::move(q));
     ++S->submitted;
     if (ticket) *ticket = S->next_ticket - 1;

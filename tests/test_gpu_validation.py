@@ -428,16 +428,30 @@ def test_memory_limit_turns_into_a_status_not_a_crash():
     p = sicp.default_params(sicp.MODE_EM)
     p.num_classes = 11
     s = sicp.Stream(0, p, 4, cm)
+    fillers = []
     try:
+        # no NEW slab from here on; what the slabs already held by the arena have left is used up first (a slab is
+        # at most 1 GB, a 60K-point cloud with its feature buffers ~12 MB)
         held = sicp.memory_reserved(0)
-        sicp.set_memory_limit(0, held + (1 << 20))       # one more megabyte: a 60K-point cloud needs ~10
+        sicp.set_memory_limit(0, 1)
+        hit = False
+        for _ in range(200):
+            f = make_engine(sicp.MODE_EM, 11, cm)
+            fillers.append(f)
+            try:
+                f.set_source(src, sl)
+            except sicp.SicpError as err:
+                assert err.status == sicp.ERR_OUT_OF_MEMORY
+                hit = True
+                break
+        assert hit, "the memory limit never became a status"
         with pytest.raises(sicp.SicpError) as err:
             e.set_source(src, sl)
         assert err.value.status == sicp.ERR_OUT_OF_MEMORY
         with pytest.raises(sicp.SicpError) as err:
             s.add_cloud(src, sl)
         assert err.value.status == sicp.ERR_OUT_OF_MEMORY
-        assert sicp.memory_reserved(0) <= held + (1 << 20)
+        assert sicp.memory_reserved(0) == held
         sicp.set_memory_limit(0, 0)
         e.set_source(src, sl); e.set_target(tgt, tl)
         got = e.align(IDENT)
@@ -451,6 +465,8 @@ def test_memory_limit_turns_into_a_status_not_a_crash():
         sicp.set_memory_limit(0, 0)
         s.close()
         e.close()
+        for f in fillers:
+            f.close()
 
 
 @pytest.mark.parametrize("lm_on_device", [1, 2, 0])
