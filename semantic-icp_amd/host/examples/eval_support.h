@@ -6,10 +6,12 @@
 #include <dirent.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iostream>
 #include <sstream>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -199,6 +201,70 @@ class NYUMetrics {
   std::string outName_;
   semanticicp::detail::Engine engine_;
 };
+
+// One registration method of an experiment as an OPEN STREAM (sicp_stream_*, include/sicp.h): a scan is added once
+// (cloud_of_scan[file index]) however many registrations it takes part in, a pair is submitted when both its scans are
+// there, results come back in order of completion and are filed by pair.  What the three headless drivers' -S modes share.
+struct MethodStream {
+  sicp_stream s = nullptr;
+  std::vector<int64_t> cloud_of_scan;   // cloud id per file index, 0 = not uploaded
+  std::vector<int64_t> ticket_of_pair;
+  std::vector<sicp_stream_result> result_of_pair;
+  MethodStream() = default;
+  MethodStream(const MethodStream&) = delete;
+  MethodStream& operator=(const MethodStream&) = delete;
+  ~MethodStream() { if (s) sicp_stream_destroy(s); }
+  void check(int rc, const char* where) {
+    if (rc != SICP_OK) throw std::runtime_error(std::string(where) + ": " + sicp_strerror(rc) + " " + (s ? sicp_stream_last_error(s) : ""));
+  }
+  // epsilon <= 0: the constructors' default (em_icp.h:43)
+  void open(int mode, int classes, const double* cm, int in_flight, size_t n_files, size_t n_pairs, int device, double epsilon = 0.0) {
+    sicp_params p;
+    check(sicp_default_params(mode, &p), "sicp_default_params");
+    p.num_classes = classes;
+    if (epsilon > 0) p.epsilon = epsilon;
+    // the drivers run two streams (two methods) on one device: neither is ever alone on it, so the persistent
+    // one-workgroup-per-CU solve of a draining stream could not become resident beside the other's ticks -- ticks only
+    p.lm_on_device = 2;
+    check(sicp_stream_create(device, &p, in_flight, &s), "sicp_stream_create");
+    if (cm) check(sicp_stream_set_confusion(s, classes, cm), "sicp_stream_set_confusion");
+    cloud_of_scan.assign(n_files, 0);
+    ticket_of_pair.assign(n_pairs, 0);
+    result_of_pair.resize(n_pairs);
+  }
+  template <typename PointT>
+  void add(size_t scan, const pcl::PointCloud<PointT>& c, bool with_labels) {
+    check(semanticicp::detail::stream_add_cloud(s, c, with_labels, &cloud_of_scan[scan]), "sicp_stream_add_cloud_strided");
+  }
+  // source -> target from the identity (exec/kitti_eval.cc:172-176); flags: SICP_SUBMIT_*
+  void submit(size_t pair, size_t target, size_t source, uint32_t flags = 0) {
+    const double ident[7] = {0, 0, 0, 1, 0, 0, 0};
+    check(sicp_stream_submit_ex(s, cloud_of_scan[source], cloud_of_scan[target], ident, flags, &ticket_of_pair[pair]), "sicp_stream_submit_ex");
+  }
+  void collect(int wait) {
+    sicp_stream_result r[64];
+    for (;;) {
+      int32_t n = 0;
+      check(sicp_stream_poll(s, wait, 64, r, &n), "sicp_stream_poll");
+      for (int32_t k = 0; k < n; ++k)
+        for (size_t q = 0; q < ticket_of_pair.size(); ++q)
+          if (ticket_of_pair[q] == r[k].ticket) { result_of_pair[q] = r[k]; break; }
+      if (n < 64) break;
+      wait = 0;
+    }
+  }
+  // getFusedLabels of a pair submitted with SICP_SUBMIT_FUSED_LABELS (once)
+  std::vector<uint32_t> labels(size_t pair, size_t n_source) {
+    std::vector<uint32_t> out(n_source);
+    check(sicp_stream_take_labels(s, ticket_of_pair[pair], (int32_t)n_source, out.data()), "sicp_stream_take_labels");
+    return out;
+  }
+};
+
+inline int device_from_env() {
+  const char* dev = std::getenv("SICP_DEVICE");
+  return dev ? std::atoi(dev) : 0;
+}
 
 inline const char* arg(int argc, char** argv, const char* flag) {
   for (int i = 1; i + 1 < argc; ++i)

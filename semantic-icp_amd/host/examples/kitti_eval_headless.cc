@@ -16,6 +16,10 @@
 // <in flight> registrations sharing the GPU while this thread reads the next files -- no closed batches, no
 // pair waiting for the slowest pair of its batch.  Same rows again (the time column is the run's wall time
 // per pair).
+// -G <n>: the sequence sharded over the GPUs of the node (BASELINE config 5; exec/kitti_eval.cc:124-249 is the loop that
+// shards): the pair list is cut into n contiguous runs, each an open stream per method with its own host thread on device
+// g % (devices visible), no exchange between them; the rows are merged in pair order.  Same rows again.  -S sets the
+// registrations in flight per stream (default 64).
 #include <chrono>
 #include <cstdio>
 #include <fstream>
@@ -25,6 +29,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <em_icp.h>
@@ -34,52 +39,61 @@
 
 namespace {
 
-// one registration method of the experiment as a stream: scans are added once (ids[scan index]), pair
-// (target n, source n + 3) is submitted when both are there, a scan is released after its second submit
-struct MethodStream {
-  sicp_stream s = nullptr;
-  std::vector<int64_t> cloud_of_scan;   // cloud id per file index, 0 = not uploaded
-  std::vector<int64_t> ticket_of_pair;
-  std::vector<sicp_stream_result> result_of_pair;
-  ~MethodStream() { if (s) sicp_stream_destroy(s); }
-  void check(int rc, const char* where) {
-    if (rc != SICP_OK) throw std::runtime_error(std::string(where) + ": " + sicp_strerror(rc) + " " + (s ? sicp_stream_last_error(s) : ""));
-  }
-  void open(int mode, int classes, const double* cm, int in_flight, size_t n_files, size_t n_pairs) {
-    sicp_params p;
-    check(sicp_default_params(mode, &p), "sicp_default_params");
-    p.num_classes = classes;
-    // two streams (one per method) share the device: neither is ever alone on it, so the persistent one-workgroup-per-CU
-    // solve of a draining stream could not become resident beside the other's ticks -- ticks only
-    p.lm_on_device = 2;
-    const char* dev = std::getenv("SICP_DEVICE");
-    check(sicp_stream_create(dev ? std::atoi(dev) : 0, &p, in_flight, &s), "sicp_stream_create");
-    if (cm) check(sicp_stream_set_confusion(s, classes, cm), "sicp_stream_set_confusion");
-    cloud_of_scan.assign(n_files, 0);
-    ticket_of_pair.assign(n_pairs, 0);
-    result_of_pair.resize(n_pairs);
-  }
-  template <typename PointT>
-  void add(size_t scan, const pcl::PointCloud<PointT>& c, bool with_labels) {
-    check(semanticicp::detail::stream_add_cloud(s, c, with_labels, &cloud_of_scan[scan]), "sicp_stream_add_cloud_strided");
-  }
-  void submit(size_t pair, size_t target, size_t source) {
-    const double ident[7] = {0, 0, 0, 1, 0, 0, 0};   // exec/kitti_eval.cc:172-176
-    check(sicp_stream_submit(s, cloud_of_scan[source], cloud_of_scan[target], ident, &ticket_of_pair[pair]), "sicp_stream_submit");
-  }
-  void collect(int wait) {
-    sicp_stream_result r[64];
-    for (;;) {
-      int32_t n = 0;
-      check(sicp_stream_poll(s, wait, 64, r, &n), "sicp_stream_poll");
-      for (int32_t k = 0; k < n; ++k)
-        for (size_t q = 0; q < ticket_of_pair.size(); ++q)
-          if (ticket_of_pair[q] == r[k].ticket) { result_of_pair[q] = r[k]; break; }
-      if (n < 64) break;
-      wait = 0;
-    }
-  }
+using evalsupport::MethodStream;
+
+// One contiguous run [q0, q1) of the pair list through two streams (EM-ICP and SE3-GICP) on one device: every scan of the run
+// read, uploaded and indexed once, its registrations submitted as soon as it is there.  Runs in its own host thread under -G;
+// nothing is shared between runs but the read-only file list.
+struct ShardResult {
+  size_t q0 = 0;
+  int device = 0;
+  std::vector<sicp_stream_result> em, gi;  // per pair of the run
+  double secs_per_pair = 0;
+  std::string error;
 };
+
+void run_shard(ShardResult& out, int device, int in_flight, const double* cmv, const std::vector<std::string>& pcd_fns,
+               const std::vector<size_t>& starts, size_t q0, size_t q1) {
+  out.q0 = q0;
+  out.device = device;
+  try {
+    const size_t n_pairs = q1 - q0;
+    if (n_pairs == 0) return;
+    MethodStream em, gi;
+    em.open(SICP_MODE_EM, 11, cmv, in_flight, pcd_fns.size(), n_pairs, device);
+    gi.open(SICP_MODE_GICP, 0, nullptr, in_flight, pcd_fns.size(), n_pairs, device);
+    auto upload = [&](size_t scan) {
+      if (em.cloud_of_scan[scan]) return true;
+      pcl::PointCloud<pcl::PointXYZL>::Ptr cl(new pcl::PointCloud<pcl::PointXYZL>);
+      if (pcl::io::loadPCDFile<pcl::PointXYZL>(pcd_fns[scan], *cl) == -1) return false;
+      evalsupport::filterRange(cl, 40.0);  // :138, :159
+      em.add(scan, *cl, true);
+      // the reference re-loads the files as PointXYZ (:201-204): same points, no labels, no range filter
+      pcl::PointCloud<pcl::PointXYZ>::Ptr raw(new pcl::PointCloud<pcl::PointXYZ>);
+      pcl::io::loadPCDFile<pcl::PointXYZ>(pcd_fns[scan], *raw);
+      gi.add(scan, *raw, false);
+      return true;
+    };
+    const auto begin = std::chrono::steady_clock::now();
+    for (size_t q = q0; q < q1; ++q) {
+      const size_t t = starts[q], sidx = t + 3;
+      if (!upload(t) || !upload(sidx)) throw std::runtime_error("couldn't read scan file " + pcd_fns[t] + " / " + pcd_fns[sidx]);
+      em.submit(q - q0, t, sidx);
+      gi.submit(q - q0, t, sidx);
+      // scan t has now been the source of pair q - 1 and the target of pair q: the caller is done with it
+      sicp_stream_release_cloud(em.s, em.cloud_of_scan[t]);
+      sicp_stream_release_cloud(gi.s, gi.cloud_of_scan[t]);
+      if ((q - q0) % 16 == 15) { em.collect(0); gi.collect(0); }
+    }
+    em.collect(2);
+    gi.collect(2);
+    out.secs_per_pair = std::chrono::duration<double>(std::chrono::steady_clock::now() - begin).count() / double(n_pairs);
+    out.em = em.result_of_pair;
+    out.gi = gi.result_of_pair;
+  } catch (const std::exception& e) {
+    out.error = e.what();
+  }
+}
 
 }  // namespace
 
@@ -102,50 +116,45 @@ int main(int argc, char** argv) {
   typedef semanticicp::EmIterativeClosestPoint<11> Em;
   typedef semanticicp::GICP<pcl::PointXYZ> Gicp;
   const char* sarg = arg(argc, argv, "-S");
-  if (sarg) {
+  const char* garg = arg(argc, argv, "-G");
+  if (sarg || garg) {
     try {
-      const int in_flight = std::max(1, std::atoi(sarg));
+      const int in_flight = std::max(1, sarg ? std::atoi(sarg) : 64);
       std::vector<size_t> starts;
       for (size_t n = 0; n + 3 < pcd_fns.size(); n += 3) starts.push_back(n);  // exec/kitti_eval.cc:124-129
       double cmv[121];
       for (int r = 0; r < 11; ++r)
         for (int c = 0; c < 11; ++c) cmv[11 * r + c] = cm(r, c);
-      MethodStream em, gi;
-      em.open(SICP_MODE_EM, 11, cmv, in_flight, pcd_fns.size(), starts.size());
-      gi.open(SICP_MODE_GICP, 0, nullptr, in_flight, pcd_fns.size(), starts.size());
-      auto upload = [&](size_t scan) {
-        if (em.cloud_of_scan[scan]) return true;
-        pcl::PointCloud<pcl::PointXYZL>::Ptr cl(new pcl::PointCloud<pcl::PointXYZL>);
-        if (pcl::io::loadPCDFile<pcl::PointXYZL>(pcd_fns[scan], *cl) == -1) return false;
-        filterRange(cl, 40.0);  // :138, :159
-        em.add(scan, *cl, true);
-        // the reference re-loads the files as PointXYZ (:201-204): same points, no labels, no range filter
-        pcl::PointCloud<pcl::PointXYZ>::Ptr raw(new pcl::PointCloud<pcl::PointXYZ>);
-        pcl::io::loadPCDFile<pcl::PointXYZ>(pcd_fns[scan], *raw);
-        gi.add(scan, *raw, false);
-        return true;
-      };
-      const auto begin = std::chrono::steady_clock::now();
-      for (size_t q = 0; q < starts.size(); ++q) {
-        const size_t t = starts[q], sidx = t + 3;
-        if (!upload(t) || !upload(sidx)) { std::cerr << "Couldn't read scan file\n"; return -1; }
-        em.submit(q, t, sidx);
-        gi.submit(q, t, sidx);
-        // scan t has now been the source of pair q - 1 and the target of pair q: the caller is done with it
-        sicp_stream_release_cloud(em.s, em.cloud_of_scan[t]);
-        sicp_stream_release_cloud(gi.s, gi.cloud_of_scan[t]);
-        if (q % 16 == 15) { em.collect(0); gi.collect(0); }
+      // -G <n>: the pair list cut into n contiguous runs, one host thread + one stream per method for each, on device
+      // g % (devices visible) -- independent scan pairs shard across the GPUs of a node without any exchange; a scan on
+      // the border of two runs is uploaded by both.  One run = -S.
+      int n_dev = 1;
+      if (sicp_device_count(&n_dev) != SICP_OK || n_dev < 1) throw std::runtime_error(std::string("sicp_device_count: ") + sicp_strerror(SICP_ERR_NO_DEVICE));
+      const char* dev_env = std::getenv("SICP_DEVICE");
+      const int shards = std::max(1, std::min<int>(garg ? std::atoi(garg) : 1, (int)std::max<size_t>(1, starts.size())));
+      std::vector<ShardResult> shard(shards);
+      std::vector<std::thread> threads;
+      for (int g = 0; g < shards; ++g) {
+        const size_t q0 = starts.size() * g / shards, q1 = starts.size() * (g + 1) / shards;
+        const int device = garg ? g % n_dev : (dev_env ? std::atoi(dev_env) : 0);
+        auto work = [&, g, q0, q1, device] { run_shard(shard[g], device, in_flight, cmv, pcd_fns, starts, q0, q1); };
+        if (shards == 1) work(); else threads.emplace_back(work);
       }
-      em.collect(2);
-      gi.collect(2);
-      const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - begin).count() / double(std::max<size_t>(1, starts.size()));
-      for (size_t q = 0; q < starts.size(); ++q) {
-        const size_t t = starts[q], sidx = t + 3;
-        if (em.result_of_pair[q].status != SICP_OK || gi.result_of_pair[q].status != SICP_OK)
-          throw std::runtime_error(std::string("registration failed: ") + sicp_strerror(em.result_of_pair[q].status ? em.result_of_pair[q].status : gi.result_of_pair[q].status));
-        const double e1 = semanticICPMetrics.evaluate(semanticicp::detail::to_se3(em.result_of_pair[q].qt), t, sidx, secs, em.result_of_pair[q].outer_iters);
-        const double e2 = se3GICPMetrics.evaluate(semanticicp::detail::to_se3(gi.result_of_pair[q].qt), t, sidx, secs, gi.result_of_pair[q].outer_iters);
-        std::printf("pair %zu<-%zu  SICP MSE %.3e  se3GICP MSE %.3e\n", t, sidx, e1, e2);
+      for (std::thread& t : threads) t.join();
+      for (int g = 0; g < shards; ++g)
+        if (!shard[g].error.empty()) throw std::runtime_error("run " + std::to_string(g) + ": " + shard[g].error);
+      // the rows, in pair order whatever run produced them
+      for (int g = 0; g < shards; ++g) {
+        const ShardResult& R = shard[g];
+        for (size_t k = 0; k < R.em.size(); ++k) {
+          const size_t t = starts[R.q0 + k], sidx = t + 3;
+          if (R.em[k].status != SICP_OK || R.gi[k].status != SICP_OK)
+            throw std::runtime_error(std::string("registration failed: ") + sicp_strerror(R.em[k].status ? R.em[k].status : R.gi[k].status));
+          const double e1 = semanticICPMetrics.evaluate(semanticicp::detail::to_se3(R.em[k].qt), t, sidx, R.secs_per_pair, R.em[k].outer_iters);
+          const double e2 = se3GICPMetrics.evaluate(semanticicp::detail::to_se3(R.gi[k].qt), t, sidx, R.secs_per_pair, R.gi[k].outer_iters);
+          std::printf("pair %zu<-%zu  SICP MSE %.3e  se3GICP MSE %.3e\n", t, sidx, e1, e2);
+        }
+        if (shards > 1) std::printf("run %d: pairs [%zu, %zu) on device %d, %.3f s per pair\n", g, R.q0, R.q0 + R.em.size(), R.device, R.secs_per_pair);
       }
     } catch (const std::exception& e) {
       std::cerr << "error: " << e.what() << "\n";

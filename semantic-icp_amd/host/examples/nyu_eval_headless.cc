@@ -6,11 +6,17 @@
 // registered source with the target (exec/nyu_metrics.h:36-84) into <prefix>SICPnyu.csv /
 // <prefix>se3GICPnyu.csv (+ Label<num>-*, Matrix*).  The reference names its outputs by date; here
 // the prefix is -o.  Not reproduced: the pcl::GeneralizedIterativeClosestPoint comparison.
+// -S <in flight>: every pair of the test file through two OPEN STREAMS (labelled / single class; sicp_stream_*,
+// SICP_MODE_SEMANTIC): a frame is read, uploaded, grouped by label and indexed once per stream however many pairs
+// name it, up to <in flight> registrations share the GPU, and the metrics are evaluated in the file's order once the
+// poses are back.  Same lines, same files.
 #include <chrono>
 #include <cstdio>
 #include <iostream>
 #include <sstream>
 #include <string>
+#include <utility>
+#include <vector>
 
 #include <pcl_2_semantic.h>
 #include <semantic_icp.h>
@@ -27,6 +33,69 @@ int main(int argc, char** argv) {
   const std::string pre = prefix ? prefix : "";
   const size_t numClasses = nc ? (size_t)std::stoul(nc) : 895;  // nyu_metrics.h:19
   const std::vector<std::string> pcd_fns = get_pcd_in_dir(dir);
+  if (const char* sarg = arg(argc, argv, "-S")) {
+    try {
+      const int in_flight = std::max(1, std::atoi(sarg));
+      NYUMetrics semanticICPMetrics(test, pre + "SICPnyu.csv", 0, numClasses);
+      NYUMetrics se3GICPMetrics(test, pre + "se3GICPnyu.csv", 0, numClasses);
+      std::vector<std::pair<size_t, size_t>> pairs;   // (source, target), exec/nyu_eval.cc:95-99
+      while (semanticICPMetrics.morePairs()) {
+        const std::vector<size_t> row = semanticICPMetrics.getPairs();
+        for (size_t n = 0; n + 1 < row.size(); ++n) {
+          if (row[n] >= pcd_fns.size() || row[n + 1] >= pcd_fns.size()) { std::cerr << "pair index beyond the PCD files\n"; return -1; }
+          pairs.push_back({row[n], row[n + 1]});
+        }
+      }
+      MethodStream lab, nol;
+      lab.open(SICP_MODE_SEMANTIC, 0, nullptr, in_flight, pcd_fns.size(), pairs.size(), device_from_env());
+      nol.open(SICP_MODE_SEMANTIC, 0, nullptr, in_flight, pcd_fns.size(), pairs.size(), device_from_env());
+      std::vector<pcl::PointCloud<pcl::PointXYZL>::Ptr> frame(pcd_fns.size());
+      auto upload = [&](size_t k) {
+        if (lab.cloud_of_scan[k]) return true;
+        frame[k].reset(new pcl::PointCloud<pcl::PointXYZL>);
+        if (pcl::io::loadPCDFile<pcl::PointXYZL>(pcd_fns[k], *frame[k]) == -1) return false;
+        lab.add(k, *frame[k], true);
+        pcl::PointCloud<pcl::PointXYZL> zero;   // the same cloud with every label set to 0 (:147-170)
+        for (pcl::PointXYZL p : frame[k]->points) { p.label = 0; zero.push_back(p); }
+        nol.add(k, zero, true);
+        return true;
+      };
+      const auto begin = std::chrono::steady_clock::now();
+      for (size_t q = 0; q < pairs.size(); ++q) {
+        if (!upload(pairs[q].first) || !upload(pairs[q].second)) { std::cerr << "Couldn't read frame file\n"; return -1; }
+        lab.submit(q, pairs[q].second, pairs[q].first);
+        nol.submit(q, pairs[q].second, pairs[q].first);
+        if (q % 16 == 15) { lab.collect(0); nol.collect(0); }
+      }
+      lab.collect(2);
+      nol.collect(2);
+      const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - begin).count() / double(std::max<size_t>(1, pairs.size()));
+      for (size_t q = 0; q < pairs.size(); ++q) {
+        const size_t indxS = pairs[q].first, indxT = pairs[q].second;
+        std::string numSource;
+        for (char c : pcd_fns[indxS].substr(pcd_fns[indxS].find_last_of('/') + 1))
+          if (c >= '0' && c <= '9') numSource.push_back(c);
+        if (numSource.empty()) numSource = "0";
+        int which = 0;
+        for (MethodStream* M : {&lab, &nol}) {
+          const sicp_stream_result& r = M->result_of_pair[q];
+          if (r.status != SICP_OK) throw std::runtime_error(std::string("registration failed: ") + sicp_strerror(r.status));
+          const Sophus::SE3d T = semanticicp::detail::to_se3(r.qt);
+          pcl::PointCloud<pcl::PointXYZL>::Ptr moved(new pcl::PointCloud<pcl::PointXYZL>());
+          pcl::transformPointCloud(*frame[indxS], *moved, (T.matrix()).cast<float>());  // :141-142
+          const double acc = (which == 0 ? semanticICPMetrics : se3GICPMetrics).evaluate(moved, frame[indxT], numSource);
+          const double* qd = T.data();
+          std::printf("pair %zu->%zu %s pose %.17g %.17g %.17g %.17g %.17g %.17g %.17g accuracy %.6f time %.3f\n", indxS, indxT,
+                      which == 0 ? "SICP" : "se3GICP", qd[0], qd[1], qd[2], qd[3], qd[4], qd[5], qd[6], acc, secs);
+          ++which;
+        }
+      }
+    } catch (const std::exception& e) {
+      std::cerr << "error: " << e.what() << "\n";
+      return 2;
+    }
+    return 0;
+  }
   try {
     NYUMetrics semanticICPMetrics(test, pre + "SICPnyu.csv", 0, numClasses);
     NYUMetrics se3GICPMetrics(test, pre + "se3GICPnyu.csv", 0, numClasses);

@@ -6,6 +6,10 @@
 // CSV rows to <prefix>EMICPscenenet.csv / <prefix>se3GICPscenenet.csv.
 // Not reproduced: the pcl::GeneralizedIterativeClosestPoint comparison and the disabled bootstrap.
 // -b <pairs>: register that many frame pairs at a time in lock step (alignBatch); same rows and files.
+// -S <in flight>: the whole sequence as an OPEN STREAM per method (sicp_stream_*): every frame read, uploaded and indexed
+// once (it is the source of one registration and the target of the next), up to <in flight> registrations sharing the
+// GPU; the fused labels of a pair come back WITH its registration (SICP_SUBMIT_FUSED_LABELS: one more K = 4 search and
+// the label kernel when it retires -- no second pass over the sequence).  Same rows and files.
 #include <chrono>
 #include <cstdio>
 #include <fstream>
@@ -39,6 +43,67 @@ int main(int argc, char** argv) {
   const size_t batch = barg ? (size_t)std::max(1, std::atoi(barg)) : 1;
   typedef semanticicp::EmIterativeClosestPoint<13> Em;
   typedef semanticicp::GICP<pcl::PointXYZ> Gicp;
+  if (const char* sarg = arg(argc, argv, "-S")) {
+    try {
+      const int in_flight = std::max(1, std::atoi(sarg));
+      std::vector<size_t> starts;
+      for (size_t n = 0; n + STEP < pcd_fns.size(); n += STEP) starts.push_back(n);
+      double cmv[169];
+      for (int r = 0; r < 13; ++r)
+        for (int c = 0; c < 13; ++c) cmv[13 * r + c] = cm(r, c);
+      MethodStream em, gi;
+      em.open(SICP_MODE_EM, 13, cmv, in_flight, pcd_fns.size(), starts.size(), device_from_env(), 1e-6);   // Em(20, 1e-6), :174
+      gi.open(SICP_MODE_GICP, 0, nullptr, in_flight, pcd_fns.size(), starts.size(), device_from_env(), 1e-6);  // Gicp(20, 1e-6), :206
+      std::vector<pcl::PointCloud<pcl::PointXYZL>::Ptr> frame(pcd_fns.size());  // kept: the label files repeat the source's points
+      auto upload = [&](size_t k) {
+        if (em.cloud_of_scan[k]) return true;
+        frame[k].reset(new pcl::PointCloud<pcl::PointXYZL>);
+        if (pcl::io::loadPCDFile<pcl::PointXYZL>(pcd_fns[k], *frame[k]) == -1) return false;
+        em.add(k, *frame[k], true);
+        pcl::PointCloud<pcl::PointXYZ>::Ptr raw(new pcl::PointCloud<pcl::PointXYZ>);
+        pcl::io::loadPCDFile<pcl::PointXYZ>(pcd_fns[k], *raw);
+        gi.add(k, *raw, false);
+        return true;
+      };
+      const auto begin = std::chrono::steady_clock::now();
+      for (size_t q = 0; q < starts.size(); ++q) {
+        const size_t t = starts[q], sidx = t + STEP;
+        if (!upload(t) || !upload(sidx)) { std::cerr << "Couldn't read frame file\n"; return -1; }
+        em.submit(q, t, sidx, SICP_SUBMIT_FUSED_LABELS);
+        gi.submit(q, t, sidx);
+        sicp_stream_release_cloud(em.s, em.cloud_of_scan[t]);
+        sicp_stream_release_cloud(gi.s, gi.cloud_of_scan[t]);
+        if (q % 16 == 15) { em.collect(0); gi.collect(0); }
+      }
+      em.collect(2);
+      gi.collect(2);
+      const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - begin).count() / double(std::max<size_t>(1, starts.size()));
+      for (size_t q = 0; q < starts.size(); ++q) {
+        const size_t t = starts[q], sidx = t + STEP;
+        if (em.result_of_pair[q].status != SICP_OK || gi.result_of_pair[q].status != SICP_OK)
+          throw std::runtime_error(std::string("registration failed: ") + sicp_strerror(em.result_of_pair[q].status ? em.result_of_pair[q].status : gi.result_of_pair[q].status));
+        const double e1 = semanticICPMetrics.evaluate(semanticicp::detail::to_se3(em.result_of_pair[q].qt), t, sidx, secs, em.result_of_pair[q].outer_iters);
+        const std::vector<uint32_t> lab = em.labels(q, frame[sidx]->size());   // getFusedLabels(out, final pose), :193-195
+        pcl::PointCloud<pcl::PointXYZL> labeled;
+        for (size_t i = 0; i < frame[sidx]->size(); ++i) {
+          pcl::PointXYZL p = frame[sidx]->points[i];
+          p.label = lab[i];
+          labeled.push_back(p);
+        }
+        std::ostringstream name;
+        name << pre << sidx << ".pcd";
+        pcl::io::savePCDFileASCII(name.str(), labeled);  // :196-198
+        const double e2 = se3GICPMetrics.evaluate(semanticicp::detail::to_se3(gi.result_of_pair[q].qt), t, sidx, secs, gi.result_of_pair[q].outer_iters);
+        std::printf("pair %zu<-%zu  SICP MSE %.3e  se3GICP MSE %.3e\n", t, sidx, e1, e2);
+      }
+    } catch (const std::exception& e) {
+      std::cerr << "error: " << e.what() << "\n";
+      return 2;
+    }
+    std::printf("SICP FINAL MSE %.6e rot %.6e trans %.6e\n", semanticICPMetrics.getTransformMSE(), semanticICPMetrics.getRotMSE(), semanticICPMetrics.getTransMSE());
+    std::printf("se3GICP FINAL MSE %.6e rot %.6e trans %.6e\n", se3GICPMetrics.getTransformMSE(), se3GICPMetrics.getRotMSE(), se3GICPMetrics.getTransMSE());
+    return 0;
+  }
   try {
     std::vector<std::unique_ptr<Em>> em(batch);
     std::vector<std::unique_ptr<Gicp>> gi(batch);

@@ -33,6 +33,26 @@ def test_world_size_2_gloo_dry_run():
     assert abs(one["value"] * one["ms_per_step"] * 2e-3 - corr_per_rank) < 1e-6 * corr_per_rank
     assert abs(two["value"] * two["ms_per_step"] * 2e-3 - 2 * corr_per_rank) < 1e-6 * corr_per_rank
     assert two["ms_per_step"] > 1.5 * one["ms_per_step"]  # max over ranks, rank 1 is slower
+    # every rank's own figures: the straggler (rank 1 sleeps twice as long) is visible in the line
+    assert [r["rank"] for r in two["per_rank"]] == [0, 1] and len(one["per_rank"]) == 1
+    assert two["per_rank"][1]["elapsed_ms"] > 1.5 * two["per_rank"][0]["elapsed_ms"]
+    assert two["rank_time_spread_max_over_min"] > 1.5 and one["rank_time_spread_max_over_min"] == 1.0
+    for r in two["per_rank"]:
+        assert abs(r["value"] * r["elapsed_ms"] * 1e-3 - corr_per_rank) < 1e-6 * corr_per_rank
+
+
+def test_gpu_numa_lookup_is_harmless_without_a_gpu():
+    """bench.py binds a rank to the CPUs next to its GPU from sysfs alone; where the box says nothing (this container:
+    no kfd) it changes nothing."""
+    sys.path.insert(0, ROOT)
+    import importlib
+
+    bench = importlib.import_module("bench")
+    before = os.sched_getaffinity(0)
+    got = bench.bind_to_gpu_numa_node(0)
+    assert got is None or set(os.sched_getaffinity(0)) <= set(before)
+    if not os.path.exists("/sys/class/kfd/kfd/topology/nodes"):
+        assert got is None and os.sched_getaffinity(0) == before
 
 
 def test_bare_gpus_flag_fans_out_by_itself():

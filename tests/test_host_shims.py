@@ -23,7 +23,7 @@ def build_example(tmp_path, name="test_icp_headless"):
     cmd = [
         "g++", "-std=c++17", "-O2", "-DEM_CLASSES=4", "-I", os.path.join(ROOT, "include"), "-I", HOST,
         os.path.join(HOST, "examples", name + ".cc"), "-L", os.path.join(ROOT, "semantic-icp_amd"), "-lsicp",
-        "-Wl,-rpath," + os.path.join(ROOT, "semantic-icp_amd"), "-Wl,-rpath,/opt/rocm/lib", "-o", exe,
+        "-Wl,-rpath," + os.path.join(ROOT, "semantic-icp_amd"), "-Wl,-rpath,/opt/rocm/lib", "-pthread", "-o", exe,
     ]
     subprocess.run(cmd, check=True, capture_output=True)
     return exe
@@ -200,6 +200,19 @@ def test_kitti_eval_headless_rows_match_oracle(tmp_path):
         assert len(one) == len(four) == 3
         for ra, rb in zip(one, four):
             assert ra[:5] == rb[:5] and ra[6:] == rb[6:]
+    # -G 2: the pair list sharded into two contiguous runs, one host thread + one stream per method each, on devices
+    # g % (devices visible) -- both on device 0 of a one-GPU box (the multi-GPU code path, oversubscribed); rows merged
+    # in pair order: the same text again
+    prefix5 = str(tmp_path / "sharded_")
+    r5 = subprocess.run([exe, "-s", d, "-t", gt, "-m", cmf, "-o", prefix5, "-G", "2", "-S", "4"], capture_output=True, text=True, timeout=900)
+    assert r5.returncode == 0, r5.stderr
+    assert "run 0: pairs [0, 1)" in r5.stdout and "run 1: pairs [1, 3)" in r5.stdout
+    for fname in ("EMICPkitti.csv", "se3GICPkitti.csv"):
+        one = [line.split(",") for line in open(prefix + fname) if line.strip()]
+        five = [line.split(",") for line in open(prefix5 + fname) if line.strip()]
+        assert len(one) == len(five) == 3
+        for ra, rb in zip(one, five):
+            assert ra[:5] == rb[:5] and ra[6:] == rb[6:]
 
 
 # ------------------------------------------------------------------------------------------------
@@ -262,6 +275,17 @@ def test_scenenet_eval_headless_rows_and_fused_labels(tmp_path):
         assert len(one) == len(two) and all(ra[:5] == rb[:5] and ra[6:] == rb[6:] for ra, rb in zip(one, two))
     for k in (1, 2):
         assert open(f"{prefix}{k}.pcd").read() == open(f"{prefix2}{k}.pcd").read()
+    # -S 2: the sequence as an open stream per method; the fused labels come back with each registration
+    # (SICP_SUBMIT_FUSED_LABELS), every frame uploaded once: identical rows and label files
+    prefix3 = str(tmp_path / "s_")
+    r3 = subprocess.run([exe, "-s", str(d), "-t", gt, "-m", cmf, "-o", prefix3, "-S", "2"], capture_output=True, text=True, timeout=900)
+    assert r3.returncode == 0, r3.stderr
+    for fname in ("EMICPscenenet.csv", "se3GICPscenenet.csv"):
+        one = [line.split(",") for line in open(prefix + fname) if line.strip()]
+        three = [line.split(",") for line in open(prefix3 + fname) if line.strip()]
+        assert len(one) == len(three) and all(ra[:5] == rb[:5] and ra[6:] == rb[6:] for ra, rb in zip(one, three))
+    for k in (1, 2):
+        assert open(f"{prefix}{k}.pcd").read() == open(f"{prefix3}{k}.pcd").read()
 
 
 # ------------------------------------------------------------------------------------------------
@@ -328,3 +352,23 @@ def test_nyu_eval_headless_poses_and_label_agreement(tmp_path):
     assert lab.shape[1] == 2 and len(lab) == int(summary["SICPnyu.csv"][-1][3])
     mat = np.loadtxt(f"{tmp_path}/Matrixo_SICPnyu.csv")
     assert mat.shape == (16, 16) and mat.sum() == sum(r_[3] for r_ in summary["SICPnyu.csv"])
+    # -S 3: every pair of the test file through two open streams (labelled / single class), a frame uploaded once per
+    # stream however many pairs name it: the same lines in the same order.  (The class shim hands the engine the points
+    # grouped by label, the stream takes them in file order: two points in one cell of the curve may swap places on the
+    # device, so poses are compared to 1e-9 rather than as text.)
+    prefix_s = str(tmp_path / "s_")
+    rs = subprocess.run([exe, "-s", str(d), "-t", str(tmp_path / "pairs.txt"), "-o", prefix_s, "-c", "16", "-S", "3"], capture_output=True,
+                        text=True, timeout=900)
+    assert rs.returncode == 0, rs.stderr
+    lines_s = [l.split() for l in rs.stdout.splitlines() if l.startswith("pair ")]
+    assert [(l[1], l[2]) for l in lines_s] == [(l[1], l[2]) for l in lines]
+    for a, b in zip(lines, lines_s):
+        qa, qb = np.array([float(v) for v in a[4:11]]), np.array([float(v) for v in b[4:11]])
+        D = np.linalg.inv(O.se3_matrix(qa)) @ O.se3_matrix(qb)
+        assert np.linalg.norm(Rotation.from_matrix(D[:3, :3]).as_rotvec()) < 1e-9 and np.linalg.norm(D[:3, 3]) < 1e-9
+        assert abs(float(a[12]) - float(b[12])) < 1e-4
+    for name in ("SICPnyu.csv", "se3GICPnyu.csv"):
+        rows_s = [[float(v) for v in row.split(",")] for row in open(prefix_s + name) if row.strip()]
+        assert len(rows_s) == len(summary[name])
+        for ra, rb in zip(summary[name], rows_s):
+            assert ra[0] == rb[0] and abs(ra[3] - rb[3]) <= 2 and abs(ra[1] - rb[1]) < 2e-3
