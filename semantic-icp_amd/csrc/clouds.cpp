@@ -213,8 +213,8 @@ int reserve_features(sicp_context* h, Cloud& c) {
   HIPCHECK(c.nn.reserve(m * (size_t)(P.k_cov > 0 ? P.k_cov : 1)));
   HIPCHECK(c.rec_dense.reserve(sicp::dense_rec_bytes(c.n)));
   if (P.mode == SICP_MODE_EM && P.num_classes > 0) {
-    HIPCHECK(c.hist.reserve(m * (size_t)P.num_classes));
-    HIPCHECK(c.proj.reserve(m * (size_t)sicp::proj_stride(P.num_classes)));
+    HIPCHECK(c.hist.reserve(m * (size_t)sicp::hist_stride(P.num_classes)));
+    if (!weights_from_histograms(P, P.knn)) HIPCHECK(c.proj.reserve(m * (size_t)sicp::proj_stride(P.num_classes)));
   }
   return SICP_OK;
 }

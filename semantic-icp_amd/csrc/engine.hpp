@@ -518,6 +518,7 @@ int check_ready(sicp_context* h, bool need_cm);
 void fill_pose(const double* qt, sicp::Pose& p);
 int segment_of(const Cloud& c, uint32_t label);
 int count_active(sicp_context* h);
+bool weights_from_histograms(const sicp_params& P, int K);
 int run_weights(sicp_context* h, const double* qt);
 int run_correspondences(sicp_context* h, const double* qt, int K, bool weights);
 void fill_acc(sicp_context* h, sicp::AccArgs& a);

@@ -148,11 +148,13 @@ __device__ __forceinline__ void cov_body(const CovArgs& a) {
   }
   if (a.hist) {
     // label histogram as neighbour counts (em_icp.hpp:301: dist(label-1) += 1/k)
-    uint8_t* h = a.hist + (size_t)i * a.C;  // this lane owns the row
-    if (hist_regs) {
-      for (int c = 0; c < a.C; ++c) h[c] = (uint8_t)((c < 8 ? cnt_lo >> (8 * c) : cnt_hi >> (8 * (c - 8))) & 0xffull);
+    const int HS = hist_stride(a.C);
+    uint8_t* h = a.hist + (size_t)i * HS;  // this lane owns the row (16-byte aligned)
+    if (hist_regs) {  // byte c of the two registers is the count of class c + 1; the bytes past C are zero
+      typedef unsigned long long hist_v2 __attribute__((ext_vector_type(2)));
+      *reinterpret_cast<hist_v2*>(h) = hist_v2{cnt_lo, cnt_hi};
     } else {
-      for (int c = 0; c < a.C; ++c) h[c] = 0;
+      for (int c = 0; c < HS; ++c) h[c] = 0;
       for (int j = 0; j < a.k; ++j) {
         const int g = nn[j * js];
         if (g < 0) continue;
@@ -174,7 +176,7 @@ __device__ __forceinline__ void proj_body(const ProjArgs& a) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= a.n * a.C) return;
   const int i = e / a.C, s = e - i * a.C;
-  const uint8_t* h = a.hist + (size_t)i * a.C;
+  const uint8_t* h = a.hist + (size_t)i * hist_stride(a.C);
   double temp = 0.0;
   for (int r = 0; r < a.C; ++r) temp += a.hval[h[r]] * a.cm[r * a.C + s];
   const int PS = proj_stride(a.C);
@@ -199,7 +201,7 @@ __device__ __forceinline__ void proj_rows_body(const ProjArgs& a) {
   const int i0 = blockIdx.x * 256, i = i0 + (int)threadIdx.x;
   if (i0 >= a.n) return;
   if (i < a.n) {
-    const uint8_t* h = a.hist + (size_t)i * C;
+    const uint8_t* h = a.hist + (size_t)i * hist_stride(C);
     double hv[PROJ_CMAX];
 #pragma unroll
     for (int r = 0; r < PROJ_CMAX; ++r) hv[r] = r < C ? s_hval[h[r]] : 0.0;
@@ -294,6 +296,84 @@ __device__ __forceinline__ void em_weight_rows_body(const WeightArgs& a) {
   for (int c = 0; c < K; ++c) a.w[(size_t)i * K + c] = w[c];
 }
 
+// The same weights WITHOUT the projection arrays (K = 4, C <= 16).  em_weight_rows_body gathers, per slot, the target's
+// projection row -- 8 (C + C % 2) = 96 bytes at C = 11 -- and is bound by exactly that gather traffic (77 MB through the
+// L1s per 100K x 4 search).  A point's label distribution is 16 BYTES of neighbour counts; here a lane gathers those
+// and forms the projections it needs itself: proj[s] = sum_r hval[count[r]] * CM[r][s], r ascending, every product rounded
+// on its own -- the very sums proj_kernel forms (same operations, same order: same bits), with CM^T and the count table in
+// LDS (broadcast reads).  The source point's projections are formed once and parked in LDS (they are indexed by the class
+// loop's counter), then slot after slot: counts -> table values, class after class the target's projection, times the
+// source's, added up in the reference's order (em_icp.hpp:84-89).  ~300 float64 operations per slot instead of a
+// 96-byte gather, and the projection kernel + arrays (9.6 MB per cloud) drop out of align().  Measured (round 4): 37 us per
+// search alone against 13, the same 256-pair step time -- see stages.cpp: weights_from_histograms; behind SICP_WEIGHTS_FROM_HIST.
+constexpr int HW_CMAX = 16;
+__device__ __forceinline__ double hist_value(const uint4& row, int r, const double* s_hval) {
+  const unsigned word = r < 4 ? row.x : (r < 8 ? row.y : (r < 12 ? row.z : row.w));
+  return s_hval[(word >> (8 * (r & 3))) & 0xffu];
+}
+
+__device__ __forceinline__ void em_weight_hist4_body(const WeightArgs& a) {
+  __shared__ __attribute__((aligned(16))) double s_cmT[HW_CMAX * HW_CMAX];  // CM transposed: [s][r], rows of 16
+  __shared__ double s_hval[256];
+  __shared__ double s_ps[HW_CMAX * 256];  // the source points' projections: [s][thread]
+  const int C = a.C;
+  for (int k = threadIdx.x; k < HW_CMAX * HW_CMAX; k += 256) {
+    const int s = k / HW_CMAX, r = k - s * HW_CMAX;
+    s_cmT[k] = (s < C && r < C) ? a.cm[r * C + s] : 0.0;
+  }
+  for (int k = threadIdx.x; k < 256; k += 256) s_hval[k] = k <= 32 ? a.hval[k] : 0.0;  // counts are at most k_cov <= 32
+  __syncthreads();
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n_s) return;
+  // ---- the source point: its own projections (what proj_kernel would have stored for it)
+  {
+    const uint4 row = *reinterpret_cast<const uint4*>(a.s_hist + (size_t)i * 16);
+    double hv[HW_CMAX];
+#pragma unroll
+    for (int r = 0; r < HW_CMAX; ++r) hv[r] = hist_value(row, r, s_hval);
+    for (int s = 0; s < C; ++s) {
+      const double* cm = s_cmT + s * HW_CMAX;
+      double temp = 0.0;
+#pragma unroll
+      for (int r = 0; r < HW_CMAX; ++r)
+        if (r < C) temp += hv[r] * cm[r];
+      s_ps[s * 256 + threadIdx.x] = temp;
+    }
+  }
+  const int4 jj = *reinterpret_cast<const int4*>(a.idx + (size_t)i * 4);
+  const PointRec sr = a.srec[i];
+  double w0 = 0.0, w1 = 0.0, w2 = 0.0, w3 = 0.0;
+  for (int c = 0; c < 4; ++c) {
+    const int j = c == 0 ? jj.x : (c == 1 ? jj.y : (c == 2 ? jj.z : jj.w));
+    double w = 0.0;
+    if (j >= 0) {
+      const uint4 row = *reinterpret_cast<const uint4*>(a.t_hist + (size_t)j * 16);
+      const PointRec tr = a.trec[j];
+      double hv[HW_CMAX];
+#pragma unroll
+      for (int r = 0; r < HW_CMAX; ++r) hv[r] = hist_value(row, r, s_hval);
+      double prob = 0.0;
+      for (int s = 0; s < C; ++s) {
+        const double* cm = s_cmT + s * HW_CMAX;
+        double temp = 0.0;  // the target's projection on class s (proj_kernel's sum)
+#pragma unroll
+        for (int r = 0; r < HW_CMAX; ++r)
+          if (r < C) temp += hv[r] * cm[r];
+        temp *= s_ps[s * 256 + threadIdx.x];  // em_icp.hpp:86-88
+        prob += temp;
+      }
+      Corr cr;
+      corr_eval<false>(a.pose, a.one_m_eps, sr.x, sr.y, sr.z, sr.nx, sr.ny, sr.nz, tr.x, tr.y, tr.z, tr.nx, tr.ny, tr.nz, cr);
+      w = prob * geometric_gate(cr, a.bool_probability);  // em_icp.hpp:108
+    }
+    w0 = c == 0 ? w : w0; w1 = c == 1 ? w : w1; w2 = c == 2 ? w : w2; w3 = c == 3 ? w : w3;
+  }
+  typedef double w_v2 __attribute__((ext_vector_type(2)));
+  w_v2* out = reinterpret_cast<w_v2*>(a.w + (size_t)i * 4);
+  out[0] = w_v2{w0, w1};
+  out[1] = w_v2{w2, w3};
+}
+
 // any K and C: one lane per slot
 __device__ __forceinline__ void em_weight_body(const WeightArgs& a) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -320,6 +400,8 @@ __global__ __launch_bounds__(256) void em_weight_kernel(WeightArgs a) { em_weigh
 __global__ __launch_bounds__(256) void em_weight_jobs_kernel(WeightJobs jobs) { em_weight_body(jobs.job[blockIdx.y]); }
 __global__ __launch_bounds__(256) void em_weight_rows4_kernel(WeightArgs a) { em_weight_rows_body<4>(a); }
 __global__ __launch_bounds__(256) void em_weight_rows4_jobs_kernel(WeightJobs jobs) { em_weight_rows_body<4>(jobs.job[blockIdx.y]); }
+__global__ __launch_bounds__(256) void em_weight_hist4_kernel(WeightArgs a) { em_weight_hist4_body(a); }
+__global__ __launch_bounds__(256) void em_weight_hist4_jobs_kernel(WeightJobs jobs) { em_weight_hist4_body(jobs.job[blockIdx.y]); }
 
 __global__ void transform_float_kernel(int n, const float* x, const float* y, const float* z, Mat4f M,
                                        float* ox, float* oy, float* oz) {
@@ -400,7 +482,8 @@ hipError_t launch_proj(const ProjArgs& a, hipStream_t st) {
 hipError_t launch_em_weight(const WeightArgs& a, hipStream_t st) {
   const int total = a.n_s * a.K;
   if (total <= 0) return hipSuccess;
-  if (a.K == 4 && a.C <= WEIGHT_CMAX) hipLaunchKernelGGL(em_weight_rows4_kernel, dim3((a.n_s + 255) / 256), dim3(256), 0, st, a);
+  if (a.s_hist && a.K == 4 && a.C <= HW_CMAX) hipLaunchKernelGGL(em_weight_hist4_kernel, dim3((a.n_s + 255) / 256), dim3(256), 0, st, a);
+  else if (a.K == 4 && a.C <= WEIGHT_CMAX) hipLaunchKernelGGL(em_weight_rows4_kernel, dim3((a.n_s + 255) / 256), dim3(256), 0, st, a);
   else hipLaunchKernelGGL(em_weight_kernel, dim3((total + 255) / 256), dim3(256), 0, st, a);
   return hipGetLastError();
 }
@@ -440,15 +523,17 @@ hipError_t launch_em_weight_jobs(const WeightArgs* jobs, int n, hipStream_t st) 
     const int cnt = n - b < kMaxKnnJobs ? n - b : kMaxKnnJobs;
     WeightJobs J;
     int mx = 0, mx_n = 0;
-    bool rows = true;
+    bool rows = true, hist = true;
     for (int i = 0; i < cnt; ++i) {
       J.job[i] = jobs[b + i];
       const int t = jobs[b + i].n_s * jobs[b + i].K;
       mx = t > mx ? t : mx; mx_n = jobs[b + i].n_s > mx_n ? jobs[b + i].n_s : mx_n;
       rows = rows && jobs[b + i].K == 4 && jobs[b + i].C <= WEIGHT_CMAX;
+      hist = hist && jobs[b + i].s_hist != nullptr && jobs[b + i].K == 4 && jobs[b + i].C <= HW_CMAX;
     }
     if (mx <= 0) continue;
-    if (rows) hipLaunchKernelGGL(em_weight_rows4_jobs_kernel, dim3((mx_n + 255) / 256, cnt), dim3(256), 0, st, J);
+    if (hist) hipLaunchKernelGGL(em_weight_hist4_jobs_kernel, dim3((mx_n + 255) / 256, cnt), dim3(256), 0, st, J);
+    else if (rows) hipLaunchKernelGGL(em_weight_rows4_jobs_kernel, dim3((mx_n + 255) / 256, cnt), dim3(256), 0, st, J);
     else hipLaunchKernelGGL(em_weight_jobs_kernel, dim3((mx + 255) / 256, cnt), dim3(256), 0, st, J);
   }
   return hipGetLastError();

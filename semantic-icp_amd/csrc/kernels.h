@@ -143,7 +143,7 @@ struct CovArgs {
   int nn_stride;
   int float_products;
   PointRec* rec;          // out: position + normal of every point
-  uint8_t* hist;          // [n][C] or nullptr
+  uint8_t* hist;          // [n][hist_stride(C)] or nullptr
   char* rec_dense;        // out, nullable: the same 36 data bytes per point as three dense arrays (dense_rec_*)
   int rec_dense_n;        // points the dense arrays are laid out for (their pitch)
 };
@@ -153,13 +153,17 @@ struct CovArgs {
 // record (the 48-byte record is what a gather wants: one point, one place).
 SICP_HD inline size_t dense_rec_bytes(int n) { return (size_t)(n > 0 ? n : 1) * 36; }
 
+// rows of the label histograms (uint8 neighbour counts) are padded to 16 bytes: one aligned dwordx4 load fetches the row of up
+// to 16 classes (the EM weight kernel gathers a target's 16-byte row instead of its 96-byte projection row)
+SICP_HD inline int hist_stride(int C) { return (C + 15) & ~15; }
+
 // rows of the projection arrays are padded to an even number of doubles: 16-byte aligned, read with
 // dwordx4 loads by the weight kernels
 SICP_HD inline int proj_stride(int C) { return (C + 1) & ~1; }
 
 struct ProjArgs {
   int n, C;
-  const uint8_t* hist;  // [n][C] neighbour counts
+  const uint8_t* hist;  // [n][hist_stride(C)] neighbour counts
   const double* cm;     // C*C row-major
   const double* hval;   // hval[c] = c additions of 1/k (em_icp.hpp:279,301)
   double* proj;         // [n][proj_stride(C)]
@@ -169,7 +173,11 @@ struct WeightArgs {
   int n_s, K, C;
   const int* idx;
   const PointRec *srec, *trec;
-  const double *s_proj, *t_proj;  // [n][proj_stride(C)] label distributions projected through CM (proj_kernel)
+  const double *s_proj, *t_proj;  // [n][proj_stride(C)] label distributions projected through CM (proj_kernel); unused with histograms
+  // K = 4, C <= 16: the weights straight from the label histograms (rows of hist_stride(C) = 16 bytes), the projections
+  // formed in the kernel -- the same sums in the same order as proj_kernel's, so the same bits -- from cm / hval
+  const uint8_t *s_hist, *t_hist;  // nullable: then s_proj / t_proj are read
+  const double *cm, *hval;         // C*C row-major; hval[c] = c additions of 1/k
   Pose pose;
   double one_m_eps;
   int bool_probability;

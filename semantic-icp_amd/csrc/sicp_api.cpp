@@ -500,8 +500,9 @@ int sicp_covariances(sicp_handle h, int which, double* cov9, double* normal3, ui
     if (n > 0) HIPCHECK(hipMemcpyAsync(rec.data(), c.rec.p, sizeof(sicp::PointRec) * n, hipMemcpyDeviceToHost, h->stream));
     std::vector<uint8_t> hh;
     std::vector<int> nn;
+    const size_t HS = (size_t)sicp::hist_stride(P.num_classes);  // rows are padded to 16 bytes on the device
     if (hist && n > 0) {
-      hh.resize((size_t)n * P.num_classes);
+      hh.resize((size_t)n * HS);
       HIPCHECK(hipMemcpyAsync(hh.data(), c.hist.p, hh.size(), hipMemcpyDeviceToHost, h->stream));
     }
     if (nn_idx && n > 0) {
@@ -524,7 +525,7 @@ int sicp_covariances(sicp_handle h, int which, double* cov9, double* normal3, ui
       if (cov9)  // the covariance the kernels use: C = I - (1-eps) n n^T  (== em_icp.hpp:331-338)
         for (int a = 0; a < 3; ++a)
           for (int b = 0; b < 3; ++b) cov9[9 * (size_t)i + 3 * a + b] = (a == b ? 1.0 : 0.0) - ome * v[a] * v[b];
-      if (hist) std::memcpy(hist + (size_t)i * P.num_classes, hh.data() + (size_t)d * P.num_classes, P.num_classes);
+      if (hist) std::memcpy(hist + (size_t)i * P.num_classes, hh.data() + (size_t)d * HS, P.num_classes);
       if (nn_idx)
         for (int j = 0; j < k; ++j) {
           const int g = c.nn_stride > 0 ? nn[(size_t)j * c.nn_stride + d] : nn[(size_t)d * k + j];

@@ -174,7 +174,7 @@ int compute_features(sicp_context* h, Cloud& c, bool with_hist, hipStream_t stre
   // and weights them by exactly zero, which needs finite values there
   if (n == 0) HIPCHECK(hipMemsetAsync(c.rec.p, 0, sizeof(sicp::PointRec), stream));
   HIPCHECK(c.nn.reserve(m * k));
-  if (with_hist) HIPCHECK(c.hist.reserve(m * P.num_classes));
+  if (with_hist) HIPCHECK(c.hist.reserve(m * (size_t)sicp::hist_stride(P.num_classes)));
   // the packet search writes the lists rank-major ([k][n]): coalesced stores there and coalesced
   // loads in the covariance kernel; the other engines keep [n][k]
   static const bool no_lane_per_query = std::getenv("SICP_KNN_LANE_PER_QUERY") == nullptr && !(debug_enabled() && std::getenv("SICP_KNN_STATS") != nullptr);
@@ -293,6 +293,17 @@ int run_correspondences(sicp_context* h, const double* qt, int K, bool weights) 
   return SICP_OK;
 }
 
+// SICP_WEIGHTS_FROM_HIST (developer switch; K = 4 and at most 16 classes): the weight kernel reads the 16-byte label
+// histograms themselves and forms the projections it needs (feature_kernels.hip: em_weight_hist4_body; same bits), no
+// projection array is computed for align().  Built and measured in round 4 (profiles/r04/weights_from_histograms.json): the
+// kernel alone takes 37 us instead of 13 (121 multiply-adds per slot against a 96-byte gather), and a 256-pair step takes the
+// SAME time (186.3-186.6 against 184.0-186.6 ms) -- a kernel bound by the vector pipe runs beside the accumulate launches for
+// free, the gather-bound one competes with them for the L1 miss queue.  Not the default: one pair alone pays the 24 us per search.
+bool weights_from_histograms(const sicp_params& P, int K) {
+  static const bool on = std::getenv("SICP_WEIGHTS_FROM_HIST") != nullptr;
+  return on && P.mode == SICP_MODE_EM && K == 4 && P.num_classes >= 1 && P.num_classes <= 16;
+}
+
 // the EM weights of the current correspondences (em_icp.hpp:62-107): what run_correspondences(..., true) ends with
 int run_weights(sicp_context* h, const double* qt) {
   const sicp_params& P = h->params;
@@ -301,13 +312,19 @@ int run_weights(sicp_context* h, const double* qt) {
   if (P.mode == SICP_MODE_EM) {
     KernelTimer kt(h, SICP_PROFILE_WEIGHT);
     const double t0 = now_ms();
-    sicp::WeightArgs a;
+    sicp::WeightArgs a{};
     a.n_s = S.n; a.K = K; a.C = P.num_classes;
     a.idx = h->idx.p;
     a.srec = S.rec.p; a.trec = T.rec.p;
-    SICPCHECK(ensure_proj(h, S));
-    SICPCHECK(ensure_proj(h, T));
-    a.s_proj = S.proj.p; a.t_proj = T.proj.p;
+    if (weights_from_histograms(P, K)) {  // the kernel forms the projections it needs from the 16-byte count rows
+      SICPCHECK(ensure_hval(h, P.k_cov));
+      a.s_hist = S.hist.p; a.t_hist = T.hist.p;
+      a.cm = h->d_cm.p; a.hval = h->d_hval.p;
+    } else {
+      SICPCHECK(ensure_proj(h, S));
+      SICPCHECK(ensure_proj(h, T));
+      a.s_proj = S.proj.p; a.t_proj = T.proj.p;
+    }
     fill_pose(qt, a.pose);
     a.one_m_eps = 1.0 - P.epsilon;
     a.bool_probability = P.quirk_bool_probability;
@@ -405,7 +422,7 @@ int align_begin(sicp_context* h, bool want_stats) {
       HIPCHECK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
     }
   }
-  if (em) {  // label distributions through the confusion matrix: same phase as the features they read
+  if (em && !weights_from_histograms(P, P.knn)) {  // label distributions through the confusion matrix: same phase as the features they read
     SICPCHECK(ensure_proj(h, S));
     SICPCHECK(ensure_proj(h, T));
   }
@@ -502,6 +519,10 @@ int flush_jobs(sicp_context* h, JobCollector& jc, hipStream_t base) {
 
 // getFusedLabels (em_icp.hpp:202-268): the K = 4 search at the final pose ...
 int labels_search(sicp_context* h, const double* qt) {
+  // the label kernel reads the projections of both clouds; align() no longer computes them when its weights come straight
+  // from the histograms: queued here, with the search (collected into the same job flush inside a batch / stream)
+  SICPCHECK(ensure_proj(h, h->cloud(0)));
+  SICPCHECK(ensure_proj(h, h->cloud(1)));
   SICPCHECK(run_correspondences(h, qt, 4, false));  // K = 4 is a literal there (em_icp.hpp:221)
   h->corr_valid = false;                            // K may differ from params.knn
   h->hint_ok = false;
@@ -512,7 +533,7 @@ int labels_search(sicp_context* h, const double* qt) {
 int labels_launch(sicp_context* h, const double* qt, hipStream_t st) {
   const sicp_params& P = h->params;
   Cloud &S = h->cloud(0), &T = h->cloud(1);
-  sicp::WeightArgs a;
+  sicp::WeightArgs a{};
   a.n_s = S.n; a.K = 4; a.C = P.num_classes;
   a.idx = h->idx.p;
   a.srec = S.rec.p; a.trec = T.rec.p;
