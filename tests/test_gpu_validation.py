@@ -493,3 +493,48 @@ def test_inner_solve_from_a_non_finite_start_fails_like_ceres(lm_on_device):
     assert info2["lm_iters"] == oinfo2["lm_iters"]
     rot, trn = pose_delta(oq2, again)
     assert rot < 1e-7 and trn < 1e-7
+
+
+def _poses_in_a_subprocess(env_extra):
+    """8 different 20K-point pairs as a closed batch and through a stream, in a fresh process with `env_extra` set (the
+    developer switches are read once per process); returns the 16 poses as hex strings + one weight checksum"""
+    import json, os, subprocess, sys
+
+    code = r'''
+import importlib, json, sys
+import numpy as np
+sys.path.insert(0, "tests")
+import synth
+sicp = importlib.import_module("semantic-icp_amd")
+cm = synth.confusion_matrix(11)
+p = sicp.default_params(sicp.MODE_EM); p.num_classes = 11
+ident = np.array([0, 0, 0, 1, 0, 0, 0.0])
+pairs = [synth.lidar_pair(seed=60 + k, n_points=20000)[:4] for k in range(8)]
+es = []
+for src, sl, tgt, tl in pairs:
+    e = sicp.Engine(0, p); e.set_confusion(cm); e.set_source(src, sl); e.set_target(tgt, tl); es.append(e)
+out = [q.tobytes().hex() for q, _ in sicp.align_batch(es)]
+idx, d2, w = es[0].correspondences(ident)
+with sicp.Stream(0, p, max_in_flight=4, confusion=cm) as S:
+    ids = [(S.add_cloud(src, sl), S.add_cloud(tgt, tl)) for src, sl, tgt, tl in pairs]
+    tk = {S.submit(a, b, ident, fused_labels=(k == 0)): k for k, (a, b) in enumerate(ids)}
+    res = sorted(S.drain(), key=lambda r: tk[r[0]])
+    lab = S.take_labels([t for t, k in tk.items() if k == 0][0], len(pairs[0][0]))
+out += [r[2].tobytes().hex() for r in res]
+print(json.dumps({"poses": out, "w": w.tobytes().hex()[:4000], "wsum": float(w.sum()), "labels": lab.tolist()[:2000]}))
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_developer_switches_do_not_change_a_bit():
+    """SICP_NO_GRAPH (ticks as plain launches: what lets rocprofv3 trace a stream), SICP_WEIGHTS_FROM_HIST (EM weights straight
+    from the label histograms) and SICP_TICK_FIRST are different schedules / kernels for the same arithmetic: poses of a
+    closed batch and of a stream, the weights and the fused labels are bit-identical to the default build's."""
+    base = _poses_in_a_subprocess({})
+    assert len(base["poses"]) == 16 and base["poses"][:8] == base["poses"][8:]   # batch == stream, pair by pair
+    for env in ({"SICP_NO_GRAPH": "1"}, {"SICP_WEIGHTS_FROM_HIST": "1"}, {"SICP_TICK_FIRST": "1"}):
+        got = _poses_in_a_subprocess(env)
+        assert got == base, env

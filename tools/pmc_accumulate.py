@@ -20,7 +20,7 @@ for S in shapes:
         d = f"/tmp/acc_pmc_{c}_{S}"
         subprocess.run(["rm", "-rf", d])
         r = subprocess.run(["rocprofv3", "--pmc", c, "--output-format", "csv", "-d", d, "--", "python3", "tools/bench_acc_batch.py", str(S)],
-                           capture_output=True, text=True, timeout=1200)
+                           capture_output=True, text=True, timeout=240)
         f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
         if not f:
             rec[c] = {"error": (r.stderr or r.stdout)[-300:]}

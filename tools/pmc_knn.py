@@ -29,7 +29,7 @@ def prof(args, phase):
     d = f"/tmp/pk_{phase}"
     subprocess.run(["rm", "-rf", d])
     cmd = ["rocprofv3", *args, "--output-format", "csv", "-d", d, "--", "python3", "tools/bench_knn_jobs.py", phase, S, N, REPS]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
     info = json.loads(line[-1]) if line else None
     return d, info, r

@@ -1,8 +1,8 @@
 #!/bin/bash
 # usage (GPU box): tools/profile_bench.sh <prefix>
-# rocprofv3 --kernel-trace --stats of the default bench command with the CPU leg and the open-stream leg off (on the
-# full default command rocprofv3 itself died with a segmentation fault in round 3; the open-stream leg, which adds a
-# worker thread, is the new element -- not investigated further), the per-kernel statistics csv,
+# rocprofv3 --kernel-trace --stats of the default bench command with the CPU leg off and SICP_NO_GRAPH=1 (rocprofv3 of
+# ROCm 7.2 dies with a segmentation fault on hipGraphLaunch -- tools/r04/two_thread_dispatch.hip reproduces it without this
+# library; with the ticks as plain launches the whole bench, stream legs included, profiles), the per-kernel statistics csv,
 # and a summary of the accumulate launches that separates the roofline legs of bench.py -- the LAST 60 launches
 # of accumulate_staged_kernel<4, true, 256> are its 256-pair leg (6 x 10 launches), the 300 before them its
 # 32-pair leg (6 x 50): the launches bench.py brackets with HIP events -- from the launches of the timed
@@ -10,10 +10,10 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 pre=$1
-# (rocprofv3 itself segfaults on about every other run of this command on this pool: up to three attempts)
-for attempt in 1 2 3; do
+export SICP_NO_GRAPH=1
+for attempt in 1 2; do
   rm -rf /tmp/pb_prof
-  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb_prof -- python3 bench.py --no-cpu-baseline --sequence-pairs 0 \
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb_prof -- python3 bench.py --no-cpu-baseline \
     > gpurun_out/${pre}_bench_under_rocprof.json 2> /tmp/pb_prof.err
   [ -n "$(find /tmp/pb_prof -name '*kernel_trace.csv' 2>/dev/null | head -1)" ] && break
   echo "attempt $attempt: no kernel trace (rocprofv3 crashed?)"
