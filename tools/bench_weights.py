@@ -1,5 +1,5 @@
 """The EM weight kernel alone (HIP events, SICP_PROFILE_WEIGHT) on one 100K x 100K pair at the identity and at the planted pose.
-usage (GPU box): [SICP_WEIGHTS_FROM_PROJ=1] bench_weights.py"""
+usage (GPU box): [SICP_WEIGHTS_FROM_HIST=1] bench_weights.py"""
 import importlib, os, sys
 import numpy as np
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
@@ -18,7 +18,7 @@ with sicp.Engine(0, p) as e:
         for _ in range(30):
             idx, d2, w = e.correspondences(q)
         s1 = e.stats()
-        print(f"{'proj' if os.environ.get('SICP_WEIGHTS_FROM_PROJ') else 'hist'}: weight kernel {1e3 * (s1['weight_kernel_ms'] - s0['weight_kernel_ms']) / (s1['weight_launches'] - s0['weight_launches']):.2f} us "
+        print(f"{'hist' if os.environ.get('SICP_WEIGHTS_FROM_HIST') else 'proj'}: weight kernel {1e3 * (s1['weight_kernel_ms'] - s0['weight_kernel_ms']) / (s1['weight_launches'] - s0['weight_launches']):.2f} us "
               f"(live slots {(idx >= 0).mean():.3f}, checksum {w.sum():.12e})")
     cov, nrm, hist, nn = e.covariances(sicp.TARGET, want_hist=True)
     nz = (hist > 0).sum(axis=1)
