@@ -1,0 +1,5 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" || exit 1
+timeout 600 python3 tools/soak_stream.py 90 3 8000; echo "soak_stream exit $?"
+timeout 600 python3 tools/stress_batch.py 2>&1 | tail -3; echo "stress_batch exit $?"
+timeout 600 python3 tools/soak_persistent.py 2>&1 | tail -2; echo "soak_persistent exit $?"
