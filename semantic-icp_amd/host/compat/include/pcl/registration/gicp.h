@@ -1,10 +1,13 @@
 // <pcl/registration/gicp.h>: pcl::GeneralizedIterativeClosestPoint is PCL's own (third-party) GICP, which
-// the reference's drivers run beside semanticicp::GICP as a comparison (exec/test_icp.cc:107-113,
-// exec/kitti_eval.cc:229-247).  It is NOT part of the path this engine replaces (SURVEY.md section 2:
-// out of scope): the declaration below only lets those drivers compile; calling align() throws.
+// the reference's drivers run beside semanticicp::GICP as a comparison column (exec/test_icp.cc:107-113,
+// exec/kitti_eval.cc:229-247, nyu_eval.cc:193-210, scenenet_eval.cc:229-247, roc_eval.cc:160-176).  It is NOT
+// part of the path this engine replaces (out of scope).  So that those drivers still RUN
+// end to end without PCL, the stand-in does no registration at all: align() hands back the initial guess
+// (identity when none is given), reports hasConverged() == false and says so once on stderr.  Build against
+// real PCL to get PCL's numbers in that column.
 #ifndef SICP_COMPAT_INCLUDE_PCL_REGISTRATION_GICP_H_
 #define SICP_COMPAT_INCLUDE_PCL_REGISTRATION_GICP_H_
-#include <stdexcept>
+#include <cstdio>
 
 #include "pcl/point_types.h"
 
@@ -14,18 +17,27 @@ class GeneralizedIterativeClosestPoint {
  public:
   typedef typename PointCloud<PointSource>::Ptr PointCloudSourcePtr;
   typedef typename PointCloud<PointTarget>::Ptr PointCloudTargetPtr;
-  void setInputCloud(const PointCloudSourcePtr&) {}
-  void setInputSource(const PointCloudSourcePtr&) {}
+  void setInputCloud(const PointCloudSourcePtr& c) { source_ = c; }
+  void setInputSource(const PointCloudSourcePtr& c) { source_ = c; }
   void setInputTarget(const PointCloudTargetPtr&) {}
   void setMaxCorrespondenceDistance(double) {}
   void setMaximumIterations(int) {}
-  void align(PointCloud<PointSource>&) { out_of_scope(); }
-  void align(PointCloud<PointSource>&, const Eigen::Matrix4f&) { out_of_scope(); }
-  Eigen::Matrix4f getFinalTransformation() const { return Eigen::Matrix4f::Identity(); }
- private:
-  static void out_of_scope() {
-    throw std::runtime_error("pcl::GeneralizedIterativeClosestPoint is third-party PCL code outside the MI355X engine's scope; build against real PCL to run it");
+  void align(PointCloud<PointSource>& out) { align(out, Eigen::Matrix4f::Identity()); }
+  void align(PointCloud<PointSource>& out, const Eigen::Matrix4f& guess) {
+    static bool told = false;
+    if (!told) {
+      told = true;
+      std::fprintf(stderr, "[sicp compat] pcl::GeneralizedIterativeClosestPoint is third-party PCL code outside the MI355X engine: "
+                           "the stand-in returns the initial guess (build against real PCL for PCL's own GICP column)\n");
+    }
+    final_ = guess;
+    if (source_) transformPointCloud(*source_, out, guess);
   }
+  bool hasConverged() const { return false; }
+  Eigen::Matrix4f getFinalTransformation() const { return final_; }
+ private:
+  PointCloudSourcePtr source_;
+  Eigen::Matrix4f final_ = Eigen::Matrix4f::Identity();
 };
 }  // namespace pcl
 #endif

@@ -93,7 +93,7 @@ class KittiMetrics {
   double evaluate(const Sophus::SE3d& transform, size_t poseIDA, size_t poseIDB, double timeSeconds, int outer_iter) {
     const Sophus::SE3d diff = getGTtransfrom(poseIDA, poseIDB) * transform.inverse();
     const double transformError = diff.log().squaredNorm();
-    const double rotError = diff.rotationLog().squaredNorm();
+    const double rotError = diff.so3().log().squaredNorm();
     const double transError = diff.translation().squaredNorm();
     transformMSE_ += transformError; rotMSE_ += rotError; transMSE_ += transError; count_++;
     std::ostream& o = *out_;
