@@ -69,7 +69,7 @@ class PointCloud {
 // its label metrics search on the host (exec/nyu_metrics.h:47-56, exec/roc_metrics.h:27-32).  The search is
 // exact with FLANN's L2_Simple<float> arithmetic -- d2 = ((dx*dx) + dy*dy) + dz*dz in float -- over the finite
 // points of the cloud (PCL leaves non-finite points out of the index), results ascending by (d2, index): the
-// order the engine's GPU search and the oracle's kd-tree also produce.  The tree is built at the first
+// order the engine's GPU search produces too.  The tree is built at the first
 // nearestKSearch, not in setInputCloud: the registration classes hold these objects without ever searching them.
 template <typename PointT>
 class KdTreeFLANN {
