@@ -366,8 +366,12 @@ int sicp_accumulate_batch(sicp_handle* hs, int32_t n, const double* qt, double* 
       h->ts[0].h_batch[p].nb = nb;
       HIPCHECK(hipStreamSynchronize(g->stream));  // the pair's correspondences are complete
     }
-    // (SICP_ACC_INNER_REPEAT, developer aid: the kernel repeats its range that many times inside one launch)
+#ifdef SICP_DEV_PROBES
+    // (developer build only: SICP_ACC_INNER_REPEAT makes the kernel repeat its range that many times inside one launch)
     static const int inner = [] { const char* e = std::getenv("SICP_ACC_INNER_REPEAT"); return e ? std::atoi(e) : 0; }();
+#else
+    const int inner = 0;
+#endif
     *h->ts[0].h_bhdr = sicp::BatchHeader{n, {inner, 0, 0}};
     HIPCHECK(hipMemcpyAsync(h->ts[0].d_bhdr.p, h->ts[0].h_bhdr, sizeof(sicp::BatchHeader), hipMemcpyHostToDevice, h->stream));
     HIPCHECK(hipMemcpyAsync(h->ts[0].d_batch.p, h->ts[0].h_batch, sizeof(sicp::BatchArgs) * n, hipMemcpyHostToDevice, h->stream));

@@ -634,12 +634,15 @@ __global__ __launch_bounds__(BS, SICP_ACC_OCC) void accumulate_staged_kernel(con
   SICP_LDS char* stage = (SICP_LDS char*)stage_all + wave * (SG * STAGE_SLOT_BYTES);
   SICP_LDS double* tile = (SICP_LDS double*)smem + wave * (RED_ROWS * RED_STRIDE);
 
-  // developer aid (tools/corun_probe.py): hdr->pad_[0] > 1 repeats the workgroup's whole range that many times inside
-  // ONE launch -- the same sums every time -- which keeps the persistent workgroups resident the way a fused multi-
-  // evaluation kernel would, so that what co-resides with them can be measured.  0 / 1 in every product launch.
+#ifdef SICP_DEV_PROBES
+  // developer build only (-DSICP_DEV_PROBES, tools/corun_probe.py): hdr->pad_[0] > 1 repeats the workgroup's whole range
+  // that many times inside ONE launch -- the same sums every time -- which keeps the persistent workgroups resident the
+  // way a fused multi-evaluation kernel would, so that what co-resides with them can be measured.  The product kernel
+  // has neither the loop nor the header read.
   const int item_first = item;
   for (int rep = uniform_i32(hdr->pad_[0] > 1 ? hdr->pad_[0] : 1); rep > 0; --rep) {
   item = item_first;
+#endif
   while (item < item_end) {
     // the pair this item belongs to: the last one that begins at or before it (always a running one)
     int lo = 0, hi = n_pairs - 1;
@@ -685,7 +688,9 @@ __global__ __launch_bounds__(BS, SICP_ACC_OCC) void accumulate_staged_kernel(con
     accumulate_segment<K, SQLOSS, BS>(L, M, chunk_lo, n_here, n_chunks, steps, uniform_i32(geo.chunk_groups), partials, stage, tile, comb, lane, wave);
     item += n_here;
   }
+#ifdef SICP_DEV_PROBES
   }
+#endif
 }
 
 // Hand-offs between workgroups of one launch (the persistent solve): write-through stores and agent-scope loads of

@@ -30,6 +30,23 @@ static void stream_worker_loop(sicp_stream_ctx* S) {
   for (int p = S->cap - 1; p >= 0; --p) free_slots.push_back(p);
   std::vector<sicp_stream_ctx::Submission> fresh;
   std::vector<int> fresh_slot;
+  // Registrations in flight per cloud.  A SICP_SUBMIT_FRESH_FEATURES registration REWRITES the feature buffers of its
+  // two clouds (records, dense records, neighbour lists, histograms, projections) on the side stream, and nothing
+  // orders that stream against the tick of the pairs already solving, whose accumulate kernel reads those very
+  // buffers: such a registration is admitted only while no other live registration -- nor an earlier one of the same
+  // admission round -- refers to either of its clouds.  It waits in the queue meanwhile, later registrations that touch
+  // none of its clouds overtake it (results carry tickets, not positions), and later registrations that DO touch them
+  // stay behind it, so it cannot starve.  A registration that reuses features only reads: it is admitted as before,
+  // its reads follow any rewrite queued earlier on the side stream in stream order.
+  std::unordered_map<const Cloud*, int> users;
+  std::vector<const Cloud*> held;
+  auto release_users = [&](const Cloud* a, const Cloud* b) {
+    for (const Cloud* c : {a, b}) {
+      auto it = users.find(c);
+      if (it != users.end() && --it->second <= 0) users.erase(it);
+    }
+  };
+  std::vector<std::pair<const Cloud*, const Cloud*>> slot_clouds((size_t)S->cap, {nullptr, nullptr});
   std::vector<sicp_stream_result> out;
   std::vector<std::array<double, 11>> dbg_log;
   double dbg_admit_ms = 0, dbg_flush_ms = 0, dbg_turn_ms = 0;
@@ -45,9 +62,21 @@ static void stream_worker_loop(sicp_stream_ctx* S) {
                        dbg_log[i][0], dbg_log[i][1], dbg_log[i][2], dbg_log[i][3], dbg_log[i][4], dbg_log[i][5], dbg_log[i][6], dbg_log[i][7], dbg_log[i][8], dbg_log[i][9], dbg_log[i][10]);
         return;
       }
-      while (!S->queue.empty() && !free_slots.empty()) {
-        fresh.push_back(std::move(S->queue.front()));
-        S->queue.pop_front();
+      held.clear();
+      for (auto it = S->queue.begin(); it != S->queue.end() && !free_slots.empty();) {
+        const Cloud* a = it->src.get();
+        const Cloud* b = it->tgt.get();
+        const bool behind = std::find(held.begin(), held.end(), a) != held.end() || std::find(held.begin(), held.end(), b) != held.end();
+        const bool rewrites = (it->flags & SICP_SUBMIT_FRESH_FEATURES) != 0;
+        if (behind || (rewrites && (users.count(a) || users.count(b)))) {
+          held.push_back(a); held.push_back(b);
+          ++it;
+          continue;
+        }
+        ++users[a]; ++users[b];
+        slot_clouds[(size_t)free_slots.back()] = {a, b};
+        fresh.push_back(std::move(*it));
+        it = S->queue.erase(it);
         fresh_slot.push_back(free_slots.back());
         free_slots.pop_back();
         ++S->in_flight;
@@ -72,6 +101,11 @@ static void stream_worker_loop(sicp_stream_ctx* S) {
       S->slot_t0[p] = now_ms();
       S->slot_flags[p] = fresh[k].flags;
       jc.slice = batch_slice(p, S->cap, S->params.knn);
+      size_t mark[5][kParts];  // what the collector held before this registration queued anything
+      for (int q = 0; q < kParts; ++q) {
+        mark[0][q] = jc.knn[q].size(); mark[1][q] = jc.cov[q].size(); mark[2][q] = jc.proj[q].size();
+        mark[3][q] = jc.weight[q].size(); mark[4][q] = jc.count[q].size();
+      }
       int rc = check_ready(h, false);
       // SICP_SUBMIT_FRESH_FEATURES: this registration recomputes the features of both its clouds, like an align() of
       // the reference (the slot's epoch is new, so align_begin finds them stale)
@@ -86,6 +120,16 @@ static void stream_worker_loop(sicp_stream_ctx* S) {
         out.push_back(r);
         free_slots.push_back(p);
         if (rc == SICP_ERR_HIP) { stream_fail(S, rc, h->last_error); return; }
+        // nothing of it runs: the jobs it had queued are dropped, its clouds go back (a released cloud's memory must not
+        // stay pinned by an idle slot), and the registrations waiting for those clouds may come in
+        for (int q = 0; q < kParts; ++q) {
+          jc.knn[q].resize(mark[0][q]); jc.cov[q].resize(mark[1][q]); jc.proj[q].resize(mark[2][q]);
+          jc.weight[q].resize(mark[3][q]); jc.count[q].resize(mark[4][q]);
+        }
+        release_users(slot_clouds[(size_t)p].first, slot_clouds[(size_t)p].second);
+        slot_clouds[(size_t)p] = {nullptr, nullptr};
+        h->cl[0] = acquire_cloud(S->device);
+        h->cl[1] = acquire_cloud(S->device);
         continue;
       }
       run.start_pair(p, fresh[k].init);
@@ -176,6 +220,8 @@ static void stream_worker_loop(sicp_stream_ctx* S) {
       out.push_back(r);
       run.phase[p] = PAIR_FREE;
       free_slots.push_back(p);
+      release_users(slot_clouds[(size_t)p].first, slot_clouds[(size_t)p].second);
+      slot_clouds[(size_t)p] = {nullptr, nullptr};
     }
     {
       static const bool slog = debug_enabled() && std::getenv("SICP_STREAM_LOG") != nullptr;  // developer aid (needs SICP_DEBUG): kept in memory, printed when the stream ends
@@ -392,8 +438,17 @@ int sicp_stream_add_cloud_strided(sicp_stream S, int32_t n, const void* xyz, int
 int sicp_stream_release_cloud(sicp_stream S, int64_t cloud_id) {
   return abi_guard(S, [&]() -> int {
     if (!S) return SICP_ERR_INVALID_ARGUMENT;
-    std::lock_guard<std::mutex> lock(S->m);
-    return S->clouds.erase(cloud_id) ? SICP_OK : SICP_ERR_INVALID_ARGUMENT;
+    // the reference is dropped AFTER the lock is gone: a cloud's deleter may wait for its upload event and, beyond the
+    // pool's cap, free ~26 device buffers -- not something the worker and every submit / poll caller should queue behind
+    std::shared_ptr<Cloud> dead;
+    {
+      std::lock_guard<std::mutex> lock(S->m);
+      auto it = S->clouds.find(cloud_id);
+      if (it == S->clouds.end()) return SICP_ERR_INVALID_ARGUMENT;
+      dead = std::move(it->second);
+      S->clouds.erase(it);
+    }
+    return SICP_OK;
   });
 }
 

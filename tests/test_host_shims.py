@@ -215,6 +215,28 @@ def test_kitti_eval_headless_rows_match_oracle(tmp_path):
             assert ra[:5] == rb[:5] and ra[6:] == rb[6:]
 
 
+@pytest.mark.gpu
+def test_kitti_eval_headless_eight_runs_plumbing(tmp_path):
+    """PLUMBING, NOT SCALING: -G 8 -- the pair list cut into eight contiguous runs, sixteen host threads and streams (one
+    per run and method), devices g % (devices visible) -- on this box's one GPU: the rows, merged in pair order, are the
+    text of a single run (exec/kitti_eval.cc:124-249 is the loop being sharded)."""
+    exe = build_example(tmp_path, "kitti_eval_headless")
+    scans, poses, cm, d, gt, cmf = make_sequence(tmp_path, n_scans=31, n_points=3000)   # 10 stride-3 pairs
+    one, eight = str(tmp_path / "one_"), str(tmp_path / "eight_")
+    r1 = subprocess.run([exe, "-s", d, "-t", gt, "-m", cmf, "-o", one, "-G", "1", "-S", "2"], capture_output=True, text=True, timeout=900)
+    assert r1.returncode == 0, r1.stderr
+    r8 = subprocess.run([exe, "-s", d, "-t", gt, "-m", cmf, "-o", eight, "-G", "8", "-S", "2"], capture_output=True, text=True, timeout=900)
+    assert r8.returncode == 0, r8.stderr
+    runs = [l for l in r8.stdout.splitlines() if l.startswith("run ")]
+    assert len(runs) == 8 and "run 0: pairs [0, 1)" in runs[0] and "run 7: pairs [8, 10)" in runs[7]
+    for fname in ("EMICPkitti.csv", "se3GICPkitti.csv"):
+        a = [line.split(",") for line in open(one + fname) if line.strip()]
+        b = [line.split(",") for line in open(eight + fname) if line.strip()]
+        assert len(a) == len(b) == 10
+        for ra, rb in zip(a, b):
+            assert ra[:5] == rb[:5] and ra[6:] == rb[6:]
+
+
 # ------------------------------------------------------------------------------------------------
 # f2: headless scenenet_eval (exec/scenenet_eval.cc:110-250 + exec/scenenet_metrics.h)
 # ------------------------------------------------------------------------------------------------

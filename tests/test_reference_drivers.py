@@ -125,7 +125,9 @@ def test_reference_kitti_eval_runs_on_the_engine(tmp_path):
         assert all(row[2] < 1e-4 for row in ref_rows)   # the reference's own error column: the pairs are registered
     # the bootstrap column is the identity guess, PCL's GICP column is the stand-in (returns the guess): both equal GT error
     init = rows_of(one(str(run_dir / "*initkitti.csv")))
-    pclg = rows_of(one(str(run_dir / "*-*,*-*GICPkitti.csv").replace("GICPkitti", "[0-9]GICPkitti")))
+    pcl_files = [f for f in glob.glob(str(run_dir / "*GICPkitti.csv")) if not f.endswith("se3GICPkitti.csv")]
+    assert len(pcl_files) == 1
+    pclg = rows_of(pcl_files[0])
     for a, b in zip(init, pclg):
         T_gt = np.linalg.inv(poses[int(a[0])]) @ poses[int(a[1])]
         assert np.allclose(np.array(a[6:22]).reshape(4, 4), T_gt, atol=1e-4)

@@ -3,7 +3,7 @@ repeats its range SICP_ACC_INNER_REPEAT times inside one launch, as a fused mult
 host thread / stream the search kernels of S other pairs are launched as sicp_align_batch launches them.  Wall time of each
 alone and of both together: together ~ max(...) means the idle issue slots of one are filled by the other, together ~ sum
 means they time-slice.  Run once per build / grid (SICP_LIB, SICP_ACC_GRID).
-usage (GPU box): SICP_ACC_INNER_REPEAT=40 corun_probe.py [acc_pairs] [search_pairs] [search_reps]"""
+usage (GPU box): build a probe library first -- tools/build_variants.py probes=-DSICP_DEV_PROBES -- then\n  SICP_LIB=build_dbg/libsicp_probes.so SICP_ACC_INNER_REPEAT=40 corun_probe.py [acc_pairs] [search_pairs] [search_reps]\n(the product library has neither the in-kernel repeat loop nor the environment switch)"""
 import importlib, json, os, sys, threading, time
 import numpy as np
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")

@@ -29,7 +29,11 @@ def prof(args, phase):
     d = f"/tmp/pk_{phase}"
     subprocess.run(["rm", "-rf", d])
     cmd = ["rocprofv3", *args, "--output-format", "csv", "-d", d, "--", "python3", "tools/bench_knn_jobs.py", phase, S, N, REPS]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+    except subprocess.TimeoutExpired as e:   # one hung counter pass must not lose the passes already collected
+        r = subprocess.CompletedProcess(cmd, 124, stdout=(e.stdout or b"").decode(errors="ignore") if isinstance(e.stdout, bytes) else (e.stdout or ""),
+                                        stderr="timed out after 240 s")
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
     info = json.loads(line[-1]) if line else None
     return d, info, r
