@@ -300,7 +300,9 @@ int sicp_stream_submit(sicp_stream s, int64_t source_id, int64_t target_id, cons
  *       exec/scenenet_eval.cc:193-198 calls right after align) is computed when the registration retires -- one more
  *       K = 4 search and one label kernel, queued beside the running registrations -- and kept until
  *       sicp_stream_take_labels(ticket) fetches it (once; n = the source cloud's point count, caller order).  The
- *       registration's result is only handed out by sicp_stream_poll when its labels are there.
+ *       registration's result is only handed out by sicp_stream_poll when its labels are there.  Label sets that are
+ *       never taken do not pile up: the stream keeps the newest 4 x max_in_flight + 64 and drops older ones
+ *       (sicp_stream_take_labels then answers SICP_ERR_NOT_READY).
  *   SICP_SUBMIT_FRESH_FEATURES the normals / label histograms of BOTH clouds are recomputed for this registration,
  *       like every align() of the reference does (em_icp.hpp:28-29, gicp.hpp:33-34), instead of being kept with the
  *       cloud (a stream's default: what setSourceCloud(cloud, kdtree, covs) exists for).  Same values either way. */
@@ -355,6 +357,8 @@ int sicp_accumulate_batch(sicp_handle* handles, int32_t n, const double* qt, dou
  *             (em_icp.hpp:46-65); use_hint = 0 starts every walk from the curve position like the first
  *             search of an align(), 1 from the handle's previous result like the later ones
  *   what = 1 / 2: the k_cov self-search of the source / target cloud (em_icp.hpp:283-296)
+ *   what = 3: what = 0 as an EM-ICP align() launches it after its first flush of features: the search writes the slots' EM
+ *             weights in its epilogue (em_icp.hpp:77-89,108; K = 4, at most 16 classes), or a weight kernel follows once
  * The handles end up as after sicp_correspondences / sicp_covariances. */
 int sicp_search_batch(sicp_handle* handles, int32_t n, const double* qt, int32_t what, int32_t use_hint,
                       int32_t repeat, double* kernel_ms);

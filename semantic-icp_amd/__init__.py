@@ -452,7 +452,8 @@ def accumulate_batch(engines, qts, repeat: int = 1):
 
 def search_batch(engines, qts=None, what: int = 0, use_hint: bool = True, repeat: int = 1):
     """sicp_search_batch: the search kernels of every engine as one job launch (what = 0 the K-correspondence
-    search at poses qts, 1 / 2 the k_cov self-search of the source / target cloud), issued `repeat` times.
+    search at poses qts, 1 / 2 the k_cov self-search of the source / target cloud, 3 the search of 0 with the EM weights
+    in its epilogue as an align() launches it), issued `repeat` times.
     Returns kernel milliseconds per repetition (all engines' searches together)."""
     n = len(engines)
     if qts is None:

@@ -67,7 +67,25 @@ __device__ __forceinline__ void corr_eval(const Pose& P, double one_m_eps, doubl
   }
 }
 
-// 1/d for a normal, finite d: v_rcp_f64 (2^-26) + two Newton steps (~1 ulp; 5 instructions, the
-// correctly rounded division sequence is 14)
+// GICPCostFunction::Probability as the reference uses it (gicp_cost_function.h:75-87 through em_icp.hpp:108):
+// the density det(2 pi A)^-1/2 exp(-r/2), converted to bool (quirk Q1: 1 unless the product underflows to
+// exactly 0; NaN -> 1).  pow() and exp() cost ~300 instructions to answer a question that is decided long
+// before the last digit: with 1e-60 < det A < 1e30 (det of A = C_t + R C_s R^T is at most 8 for real inputs) the
+// power lies in (6e-17, 6e28), so the product cannot be 0 for r < 1300 (exp(-650) = 5e-283: the product is above
+// 3e-299, a normal number) and is exactly 0 for r > 1600 (exp(-800) is 0, below the smallest denormal, times a
+// finite power).  The band between them -- and every determinant outside that range, NaN, Inf, det <= 0 -- takes
+// the literal formula, so the decision is the reference's for every input.
+__device__ __forceinline__ double geometric_gate(const Corr& c, int bool_probability) {
+  const double two_pi = 6.283185307179586;
+  if (bool_probability) {
+    const bool sane = c.detA > 1e-60 && c.detA < 1e30;
+    if (sane && c.r < 1300.0) return 1.0;
+    if (sane && c.r > 1600.0) return 0.0;
+    const double probability = pow(two_pi * two_pi * two_pi * c.detA, -0.5) * exp(-0.5 * c.r);
+    return (probability != 0.0) ? 1.0 : 0.0;  // quirk Q1: double -> bool (NaN -> true)
+  }
+  return pow(two_pi * two_pi * two_pi * c.detA, -0.5) * exp(-0.5 * c.r);
+}
+
 }  // namespace sicp
 #endif

@@ -116,8 +116,26 @@ struct DevArena {
   // A block may be handed out again at once, to any thread and stream: like hipFree, giving one back first waits
   // for the device (launches that still read or write it may be in flight on streams the caller knows nothing of).
   // Releases are rare next to allocations: buffers that grow, handles and clouds (beyond the cloud pool) that go.
+  // An object that gives back MANY blocks at once (a handle: ~40, a cloud beyond the pool's cap: ~26) waits for the
+  // device ONCE: FreeScope does the wait, and the frees of this thread inside it skip theirs -- the blocks are the
+  // dying object's own, nothing can be launched on them any more.
+  static int& scope_device() { static thread_local int d = -1; return d; }
+  struct FreeScope {
+    int prev;
+    explicit FreeScope(int device) : prev(scope_device()) {
+      int cur = -1;
+      const bool ok = hipGetDevice(&cur) == hipSuccess;
+      const bool switched = ok && cur != device && hipSetDevice(device) == hipSuccess;
+      (void)hipDeviceSynchronize();
+      if (switched) (void)hipSetDevice(cur);
+      scope_device() = device;
+    }
+    ~FreeScope() { scope_device() = prev; }
+    FreeScope(const FreeScope&) = delete;
+    FreeScope& operator=(const FreeScope&) = delete;
+  };
   void free(void* p, int device, int slab, size_t cls) {
-    {
+    if (scope_device() != device) {
       int cur = -1;
       const bool ok = hipGetDevice(&cur) == hipSuccess;
       const bool switched = ok && cur != device && hipSetDevice(device) == hipSuccess;
@@ -508,8 +526,17 @@ int reserve_features(sicp_context* h, Cloud& c);
 int set_cloud_common(sicp_handle h, int which, int32_t n, const StridedCloud& in);
 
 // ---- stages.cpp ------------------------------------------------------------------------------------
+// (fold: the EM weights written by the search's epilogue -- KnnArgs::w_* -- or nullptr)
+struct WeightFold {
+  const sicp::PointRec *srec, *trec;
+  const double *sproj, *tproj;
+  double* w;
+  double one_m_eps;
+  int C, bool_probability;
+};
 int run_nn(sicp_context* h, int K, const Cloud& Qc, int q_begin, int q_count, const double* M34, const Cloud& Tc,
-           int tseg, bool self, float gate_sq, int* out_i, float* out_d, int timer_bit, hipStream_t stream, int out_stride = 0);
+           int tseg, bool self, float gate_sq, int* out_i, float* out_d, int timer_bit, hipStream_t stream, int out_stride = 0,
+           const WeightFold* fold = nullptr);
 int ensure_hval(sicp_context* h, int k);
 int ensure_proj(sicp_context* h, Cloud& c);
 int compute_features(sicp_context* h, Cloud& c, bool with_hist, hipStream_t stream = nullptr);

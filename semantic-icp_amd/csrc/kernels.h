@@ -132,6 +132,15 @@ struct KnnArgs {
   int k_out;       // neighbours written per query (<= the list length K the kernel runs with)
   unsigned long long* live_cnt;  // nullable, packet kernel: kLiveCounters partial counters; every wave adds the number of
                                  // neighbours it wrote that passed the gate (statistics: sicp_stats.total_active)
+  // EM weights in the search's epilogue (packet kernel, K = 4, at most 16 classes; w_out == nullptr: not wanted).  The lane
+  // that writes a neighbour's index already holds everything em_weight_rows4_kernel would re-read -- the index, the query's
+  // place -- so it gathers the two records and projection rows and writes the slot's weight beside the index: the same
+  // operations in the same order as that kernel (em_icp.hpp:84-89,108), hence the same bits.  The pose is M (rows [R | t]).
+  const PointRec *w_srec, *w_trec;
+  const double *w_sproj, *w_tproj;  // [n][proj_stride(w_C)]
+  double* w_out;                    // [query][k_out]
+  double w_one_m_eps;
+  int w_C, w_bool_probability;
 };
 constexpr int kLiveCounters = 1024;  // (spread: ~6 of a 100K-query search's 6250 waves per counter)
 

@@ -18,6 +18,7 @@
 
 #define SICP_HD __host__ __device__
 #include "kernels.h"
+#include "device_geometry.hpp"
 
 namespace sicp {
 // ------------------------------------------------------------------------------------------
@@ -981,11 +982,46 @@ __device__ __forceinline__ void knn_packet_body(const KnnArgs& a, int wg, int n_
       const unsigned orig = (unsigned)best;
       const float d = best == KEY_EMPTY ? INFINITY : key_dist(best);
       const bool keep = orig != 0xffffffffu && d < a.gate_sq;  // strict <, float compare (em_icp.hpp:65)
+      int nb = -1;  // device index of the neighbour, -1 = none / gated out
       if (mine) {
-        a.out_i[o + k * ks] = keep ? a.inv[orig] : -1;
+        if (keep) nb = a.inv[orig];
+        a.out_i[o + k * ks] = nb;
         if (a.out_d) a.out_d[o + k * ks] = d;
       }
       if (a.live_cnt) live += (unsigned)__popcll(__ballot(mine && keep));
+      if constexpr (K == 4) {
+        // The slot's EM weight, here rather than in a kernel of its own (em_weight_rows4_kernel: one more launch per
+        // search that re-reads the indices and is bound by its gathers): prob = sum_s (t_dist . CM[:, s]) (s_dist .
+        // CM[:, s]) from the two projection rows, in ascending s with every product rounded on its own
+        // (em_icp.hpp:84-89), times Probability()'s bool (:108) -- operation for operation what that kernel does.
+        // The gathers of this wave wait while the other waves of the SIMD walk.
+        if (a.w_out != nullptr) {
+          double w = 0.0;
+          if (mine && nb >= 0) {
+            const int C = a.w_C, PS = proj_stride(C), NP = PS / 2;
+            typedef double v2d_t __attribute__((ext_vector_type(2)));
+            const v2d_t* __restrict__ psrc = reinterpret_cast<const v2d_t*>(a.w_sproj + (size_t)(a.q_begin + q) * PS);
+            const v2d_t* __restrict__ ptgt = reinterpret_cast<const v2d_t*>(a.w_tproj + (size_t)nb * PS);
+            const PointRec sr = a.w_srec[a.q_begin + q], tr = a.w_trec[nb];
+            double prob = 0.0;
+            for (int kk = 0; kk < NP; ++kk) {
+              const v2d_t tv = ptgt[kk], sv = psrc[kk];
+              { double temp = tv.x; temp *= sv.x; prob += temp; }
+              if (2 * kk + 1 < C) { double temp = tv.y; temp *= sv.y; prob += temp; }
+            }
+            Pose P;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+              P.R[3 * r + 0] = a.M[4 * r + 0]; P.R[3 * r + 1] = a.M[4 * r + 1]; P.R[3 * r + 2] = a.M[4 * r + 2];
+              P.t[r] = a.M[4 * r + 3];
+            }
+            Corr cr;
+            corr_eval<false>(P, a.w_one_m_eps, sr.x, sr.y, sr.z, sr.nx, sr.ny, sr.nz, tr.x, tr.y, tr.z, tr.nx, tr.ny, tr.nz, cr);
+            w = prob * geometric_gate(cr, a.w_bool_probability);
+          }
+          if (mine) a.w_out[o + k * ks] = w;
+        }
+      }
     }
     if (a.live_cnt && lane == 0 && live) atomicAdd(a.live_cnt + (bid & (kLiveCounters - 1)), (unsigned long long)live);
   }

@@ -39,7 +39,10 @@ std::shared_ptr<Cloud> acquire_cloud(int device) {
     // the pool is full: free this one (hipFree synchronises the device -- only beyond the cap)
     int cur = -1;
     const bool switched = hipGetDevice(&cur) == hipSuccess && cur != device && hipSetDevice(device) == hipSuccess;
-    delete dead;
+    {
+      DevArena::FreeScope once(device);  // (one wait for the device, not one per feature buffer)
+      delete dead;
+    }
     if (switched) (void)hipSetDevice(cur);
   });
 }

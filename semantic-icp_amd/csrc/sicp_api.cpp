@@ -146,7 +146,10 @@ int sicp_destroy(sicp_handle h) {
     }
     if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
     if (h->stream) (void)hipStreamDestroy(h->stream);
-    delete h;
+    {
+      DevArena::FreeScope once(h->device);  // one wait for the device, not one per buffer of the handle
+      delete h;
+    }
     return SICP_OK;
   });
 }
@@ -396,7 +399,7 @@ int sicp_accumulate_batch(sicp_handle* hs, int32_t n, const double* qt, double* 
 
 int sicp_search_batch(sicp_handle* hs, int32_t n, const double* qt, int32_t what, int32_t use_hint, int32_t repeat, double* kernel_ms) {
   return abi_guard((hs && n > 0) ? hs[0] : nullptr, [&]() -> int {
-    if (!hs || n < 1 || what < 0 || what > 2 || (what == 0 && !qt)) return SICP_ERR_INVALID_ARGUMENT;
+    if (!hs || n < 1 || what < 0 || what > 3 || ((what == 0 || what == 3) && !qt)) return SICP_ERR_INVALID_ARGUMENT;
     sicp_context* h = hs[0];
     SICPCHECK(set_device(h));
     for (int p = 0; p < n; ++p) {
@@ -407,6 +410,13 @@ int sicp_search_batch(sicp_handle* hs, int32_t n, const double* qt, int32_t what
         SICPCHECK(check_ready(h, false));
         SICPCHECK(prepare_cloud(h, h->cloud(0)));
         SICPCHECK(prepare_cloud(h, h->cloud(1)));
+        if (what == 3) {  // the search as an align() launches it, EM weights included: the features it reads must be there
+          if (h->params.mode != SICP_MODE_EM) return SICP_ERR_INVALID_ARGUMENT;
+          SICPCHECK(check_ready(h, true));
+          for (int c = 0; c < 2; ++c)
+            if (!features_current(h, h->cloud(c), true)) { h->epoch = next_epoch(); SICPCHECK(compute_features(h, h->cloud(c), true)); }
+          if (!weights_from_histograms(h->params, h->params.knn)) { SICPCHECK(ensure_proj(h, h->cloud(0))); SICPCHECK(ensure_proj(h, h->cloud(1))); }
+        }
         HIPCHECK(hipStreamSynchronize(h->stream));
       }
     }
@@ -417,9 +427,9 @@ int sicp_search_batch(sicp_handle* hs, int32_t n, const double* qt, int32_t what
       for (int p = 0; p < n; ++p) {
         sicp_context* g = hs[p];
         jc.slice = 0;
-        if (what == 0) {
+        if (what == 0 || what == 3) {
           if (!use_hint) g->hint_ok = false;
-          const int rc = run_correspondences(g, qt + 7 * p, g->params.knn, false);
+          const int rc = run_correspondences(g, qt + 7 * p, g->params.knn, what == 3);
           if (rc != SICP_OK) return rc;
         } else {
           g->epoch = next_epoch();
@@ -552,6 +562,10 @@ int sicp_correspondences(sicp_handle h, const double qt[7], int32_t* idx, float*
     SICPCHECK(prepare_cloud(h, T));
     if (!features_current(h, S, em)) SICPCHECK(compute_features(h, S, em));
     if (!features_current(h, T, em)) SICPCHECK(compute_features(h, T, em));
+    if (em && !weights_from_histograms(P, P.knn)) {  // as align_begin: the projections belong to the feature phase
+      SICPCHECK(ensure_proj(h, S));
+      SICPCHECK(ensure_proj(h, T));
+    }
     SICPCHECK(run_correspondences(h, qt, P.knn, true));
     const int n = S.n, K = P.knn;
     const size_t slots = (size_t)n * K;

@@ -8,7 +8,8 @@ namespace host {
 // queries: points [q_begin, q_begin+q_count) of cloud Q (device order), optionally transformed
 // by M34; targets: segment `tseg` of cloud T.  Writes device indices of T (or -1) and distances.
 int run_nn(sicp_context* h, int K, const Cloud& Qc, int q_begin, int q_count, const double* M34, const Cloud& Tc,
-           int tseg, bool self, float gate_sq, int* out_i, float* out_d, int timer_bit, hipStream_t stream, int out_stride) {
+           int tseg, bool self, float gate_sq, int* out_i, float* out_d, int timer_bit, hipStream_t stream, int out_stride,
+           const WeightFold* fold) {
   if (q_count <= 0) return SICP_OK;
   // the kernels run with a list of L >= K entries and write the first K (the K nearest neighbours
   // are the first K of any longer exact list): any K in 1..32 works
@@ -37,6 +38,12 @@ int run_nn(sicp_context* h, int K, const Cloud& Qc, int q_begin, int q_count, co
     a.out_stride = out_stride;
     a.k_out = K;
     a.live_cnt = nullptr;
+    a.w_srec = a.w_trec = nullptr; a.w_sproj = a.w_tproj = nullptr; a.w_out = nullptr;
+    a.w_one_m_eps = 0.0; a.w_C = 0; a.w_bool_probability = 0;
+    if (fold && h->params.nn_method == 1) {
+      a.w_srec = fold->srec; a.w_trec = fold->trec; a.w_sproj = fold->sproj; a.w_tproj = fold->tproj; a.w_out = fold->w;
+      a.w_one_m_eps = fold->one_m_eps; a.w_C = fold->C; a.w_bool_probability = fold->bool_probability;
+    }
     // seed hint: what the previous search of the same queries found (same clouds, same K, this align)
     a.seed_hint = (!self && h->hint_ok && out_i == h->idx.p && h->corr_K == K && h->corr_n == Qc.n) ? h->idx.p : nullptr;
     a.hint_K = K;
@@ -262,6 +269,32 @@ int run_correspondences(sicp_context* h, const double* qt, int K, bool weights) 
   matrix34(qt, M);
   const bool sem = P.mode == SICP_MODE_SEMANTIC;
   h->counted_in_search = false;
+  // EM-ICP, K = 4, at most 16 classes, packet search: the weights are written by the search's own epilogue
+  // (knn_kernels.hip: KnnArgs::w_*; the same operations as em_weight_rows4_kernel, which then does not run).  Only when
+  // the projections it reads are already there -- computed by an EARLIER flush, not waiting in this one (a flush launches
+  // its searches first) -- and not for the developer variants that have a weight kernel of their own.
+  // SICP_NO_WEIGHT_FOLD (A/B aid): always the separate kernel.
+  WeightFold fold_args;
+  const WeightFold* fold = nullptr;
+  {
+    static const bool no_fold = std::getenv("SICP_NO_WEIGHT_FOLD") != nullptr;
+    static const bool lane_per_query = std::getenv("SICP_KNN_LANE_PER_QUERY") != nullptr;
+    const unsigned long long want_id = h->cm_id * 1099511628211ull + (unsigned long long)P.k_cov;
+    bool ok = weights && !no_fold && !lane_per_query && P.mode == SICP_MODE_EM && K == 4 && P.nn_method == 1 && P.profile == 0 &&
+              P.num_classes >= 1 && P.num_classes <= 16 && !weights_from_histograms(P, K) && S.n_seg() == 1 &&
+              S.proj_valid && T.proj_valid && S.proj_cm_id == want_id && T.proj_cm_id == want_id;
+    if (ok && h->collect)
+      for (int s = 0; s < kParts; ++s) ok = ok && h->collect->cov[s].empty() && h->collect->proj[s].empty();
+    if (ok) {
+      fold_args.srec = S.rec.p; fold_args.trec = T.rec.p;
+      fold_args.sproj = S.proj.p; fold_args.tproj = T.proj.p;
+      fold_args.w = h->w.p;
+      fold_args.one_m_eps = 1.0 - P.epsilon;
+      fold_args.C = P.num_classes;
+      fold_args.bool_probability = P.quirk_bool_probability;
+      fold = &fold_args;
+    }
+  }
   if (sem) {  // label segments that are skipped keep (idx, d2) = (-1, +inf)
     HIPCHECK(hipMemsetAsync(h->idx.p, 0xFF, sizeof(int) * slots, h->stream));
     HIPCHECK(hipMemsetD32Async((hipDeviceptr_t)h->d2.p, 0x7f800000, slots, h->stream));
@@ -276,7 +309,7 @@ int run_correspondences(sicp_context* h, const double* qt, int K, bool weights) 
         if (ts < 0) continue;                    // semantic_icp.hpp:50
         if (!(sn > P.min_class_pts)) continue;   // semantic_icp.hpp:51
       }
-      SICPCHECK(run_nn(h, K, S, so, sn, M, T, ts, false, (float)P.gate_sq, h->idx.p, h->d2.p, SICP_PROFILE_NN, h->stream));
+      SICPCHECK(run_nn(h, K, S, so, sn, M, T, ts, false, (float)P.gate_sq, h->idx.p, h->d2.p, SICP_PROFILE_NN, h->stream, 0, fold));
       h->st.total_corr += (int64_t)sn * K;
     }
     h->st.t_nn_ms += now_ms() - t0;
@@ -289,7 +322,11 @@ int run_correspondences(sicp_context* h, const double* qt, int K, bool weights) 
   // statistics: the live slots of this search, counted right behind it (same stream / same job flush: no extra
   // host turn between two solves)
   if (h->count_stats && !h->counted_in_search) SICPCHECK(count_active(h));
-  if (weights) SICPCHECK(run_weights(h, qt));
+  if (weights && fold) {
+    h->corr_weighted = true;  // (written by the search itself)
+  } else if (weights) {
+    SICPCHECK(run_weights(h, qt));
+  }
   return SICP_OK;
 }
 

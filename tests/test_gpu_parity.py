@@ -242,6 +242,33 @@ def test_weights_and_accumulate_vs_oracle(pair1, mode, nn, lm):
     assert info["lm_iters"] == oinfo["lm_iters"]  # same trust-region path as the Ceres-style oracle
 
 
+@pytest.mark.parametrize("C,bool_q", [(11, 1), (4, 1), (16, 1), (13, 0)])
+def test_em_weights_from_the_search_epilogue_equal_the_weight_kernel(lidar20k, C, bool_q):
+    """EM-ICP, K = 4, at most 16 classes: the packet search writes the slots' weights in its epilogue (KnnArgs::w_*) instead
+    of em_weight_rows4_kernel running behind it -- the same operations in the same order (em_icp.hpp:84-89,108), so the same
+    bits.  A handle with a profiling mask takes the separate kernel: both, on the same correspondences, compared bit for bit
+    (odd and even class counts: padded projection rows; quirk Q1 on and off: the literal pow / exp path)."""
+    src, sl, tgt, tl, T, _ = lidar20k
+    rng = np.random.default_rng(C)
+    sl2, tl2 = rng.integers(1, C + 1, len(sl)).astype(np.uint32), rng.integers(1, C + 1, len(tl)).astype(np.uint32)
+    cm = synth.confusion_matrix(C)
+    qt = mat_to_qt(T)
+    got = []
+    for profile in (0, 4):     # 0: the epilogue; SICP_PROFILE_WEIGHT: the weight kernel, timed
+        e, p = make_engine(sicp.MODE_EM, C, cm, quirk_bool_probability=bool_q, profile=profile)
+        e.set_source(src, sl2)
+        e.set_target(tgt, tl2)
+        st0 = e.stats()
+        idx, d2, w = e.correspondences(qt)
+        st1 = e.stats()
+        assert (st1["weight_launches"] - st0["weight_launches"]) == (1 if profile else 0)
+        got.append((idx, d2, w))
+        e.close()
+    assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])
+    assert np.array_equal(got[0][2], got[1][2])          # bit for bit
+    assert (got[0][2][got[0][0] >= 0] > 0).all() and (got[0][2][got[0][0] < 0] == 0).all()
+
+
 # ------------------------------------------------------------------------------------------------
 # full align(): the three reference classes
 # ------------------------------------------------------------------------------------------------

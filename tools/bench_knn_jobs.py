@@ -3,6 +3,7 @@
     k4_first   the K = 4 correspondence search from the curve position (first search of an align())
     k4_hinted  the same search seeded by the previous result (every later outer iteration)
     k20        the k = 20 self-search of the covariance neighbourhoods (source clouds)
+    k4_weights k4_hinted as an EM-ICP align() launches it: the EM weights written by the search's epilogue (what = 3)
 usage: bench_knn_jobs.py [phase|all] [pairs] [points] [reps]
 Under rocprofv3 run ONE phase per invocation (tools/pmc_knn.py does); the last line says how many dispatches of
 the phase's kernel belong to the timed repetitions."""
@@ -50,6 +51,9 @@ if phase in ("k4_hinted", "all"):
     run("k4_hinted", 0, poses, True, 1)                             # late outer iterations: the pose barely moves
 if phase in ("k20", "all"):
     run("k20", 1, None, False, 1)
+if phase in ("k4_weights", "all") and not gicp:
+    sicp.search_batch(es, poses, what=3, use_hint=False, repeat=1)
+    run("k4_weights", 3, poses, True, 1)
 for e in es:
     e.close()
 print(json.dumps({"pairs": S, "points": n, "reps": reps, "phases": out}))
