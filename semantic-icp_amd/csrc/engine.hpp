@@ -619,6 +619,7 @@ struct TickGroup {
   TickSet* S = nullptr;
   hipEvent_t side_done = nullptr;
   bool pending = false, side_recorded = false;
+  bool force_wait = false;  // the next tick must wait for what the side stream has been given so far (a stream's ordered feature rewrite)
   int round = 0;
   std::vector<int> act, joining, finished;
 };

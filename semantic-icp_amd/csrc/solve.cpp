@@ -303,6 +303,10 @@ int BatchRun::turn(TickGroup& G, JobCollector& jc) {
     if (promote_started(G, idle) < 0) { h->last_error = "start-up pipeline: event query failed"; return SICP_ERR_HIP; }
   }
   ++G.round;
+  if (G.force_wait) {  // (streams.cpp: a feature rewrite of a cloud that a solving pair reads was queued on the side stream)
+    if (G.side_recorded) HIPCHECK(hipStreamWaitEvent(G.M, G.side_done, 0));
+    G.force_wait = false;
+  }
   const double dbg_t_search0 = now_ms();
   // (1) searches of the pairs between two inner solves -> side stream
   bool any_search = false;

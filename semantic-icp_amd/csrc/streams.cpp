@@ -31,15 +31,21 @@ static void stream_worker_loop(sicp_stream_ctx* S) {
   std::vector<sicp_stream_ctx::Submission> fresh;
   std::vector<int> fresh_slot;
   // Registrations in flight per cloud.  A SICP_SUBMIT_FRESH_FEATURES registration REWRITES the feature buffers of its
-  // two clouds (records, dense records, neighbour lists, histograms, projections) on the side stream, and nothing
-  // orders that stream against the tick of the pairs already solving, whose accumulate kernel reads those very
-  // buffers: such a registration is admitted only while no other live registration -- nor an earlier one of the same
-  // admission round -- refers to either of its clouds.  It waits in the queue meanwhile, later registrations that touch
-  // none of its clouds overtake it (results carry tickets, not positions), and later registrations that DO touch them
-  // stay behind it, so it cannot starve.  A registration that reuses features only reads: it is admitted as before,
-  // its reads follow any rewrite queued earlier on the side stream in stream order.
+  // two clouds (records, dense records, neighbour lists, histograms, projections) on the side stream, while the tick
+  // of the pairs already solving -- stream M -- reads those very buffers when another live registration shares a
+  // cloud.  Nothing used to order the two; now:
+  //   * such a registration is admitted WITH ORDER: the side stream first waits for the tick in flight (an event on
+  //     M), and the next tick waits for the side stream's rewrite (TickGroup::force_wait) -- one tick without the
+  //     overlap, only when a rewritten cloud really is shared with a live registration (the re-submission of a pair
+  //     whose previous registration is still solving);
+  //   * two registrations of ONE admission round never rewrite the same cloud (their feature jobs would land in the
+  //     same launch): the later one waits a round, later registrations that touch its clouds stay behind it, others
+  //     overtake it (results carry tickets, not positions).
+  // A registration that reuses features only reads: its reads follow any rewrite queued earlier on the side stream.
   std::unordered_map<const Cloud*, int> users;
-  std::vector<const Cloud*> held;
+  std::vector<const Cloud*> held, round_clouds;
+  bool round_rewrites = false, order_needed = false;
+  hipEvent_t tick_ev = nullptr;  // recorded on M behind the tick in flight when a rewrite has to wait for it
   auto release_users = [&](const Cloud* a, const Cloud* b) {
     for (const Cloud* c : {a, b}) {
       auto it = users.find(c);
@@ -53,26 +59,34 @@ static void stream_worker_loop(sicp_stream_ctx* S) {
   for (;;) {
     // ---- admit
     fresh.clear(); fresh_slot.clear();
+    round_rewrites = false; order_needed = false;
     {
       std::unique_lock<std::mutex> lock(S->m);
       S->cv_work.wait(lock, [&] { return S->stop || !S->queue.empty() || S->in_flight > 0; });
       if (S->stop) {
+        if (tick_ev) (void)hipEventDestroy(tick_ev);
         for (size_t i = 0; i < dbg_log.size(); i += std::max<size_t>(1, dbg_log.size() / 40))
           std::fprintf(stderr, "[stream] t %.1f ms completed %.0f ticks %.0f waited %.1f ms pairs-per-tick %.1f solo-allowed %.0f | host ms: admit %.1f flush %.1f turn %.1f (of which waited; searches %.1f, tick launch %.1f)\n",
                        dbg_log[i][0], dbg_log[i][1], dbg_log[i][2], dbg_log[i][3], dbg_log[i][4], dbg_log[i][5], dbg_log[i][6], dbg_log[i][7], dbg_log[i][8], dbg_log[i][9], dbg_log[i][10]);
         return;
       }
       held.clear();
+      round_clouds.clear();
       for (auto it = S->queue.begin(); it != S->queue.end() && !free_slots.empty();) {
         const Cloud* a = it->src.get();
         const Cloud* b = it->tgt.get();
         const bool behind = std::find(held.begin(), held.end(), a) != held.end() || std::find(held.begin(), held.end(), b) != held.end();
         const bool rewrites = (it->flags & SICP_SUBMIT_FRESH_FEATURES) != 0;
-        if (behind || (rewrites && (users.count(a) || users.count(b)))) {
+        const bool in_round = std::find(round_clouds.begin(), round_clouds.end(), a) != round_clouds.end() ||
+                              std::find(round_clouds.begin(), round_clouds.end(), b) != round_clouds.end();
+        if (behind || (in_round && (rewrites || round_rewrites))) {
           held.push_back(a); held.push_back(b);
           ++it;
           continue;
         }
+        if (rewrites && (users.count(a) || users.count(b))) order_needed = true;  // shared with a registration admitted earlier
+        if (rewrites) round_rewrites = true;
+        round_clouds.push_back(a); round_clouds.push_back(b);
         ++users[a]; ++users[b];
         slot_clouds[(size_t)free_slots.back()] = {a, b};
         fresh.push_back(std::move(*it));
@@ -139,8 +153,20 @@ static void stream_worker_loop(sicp_stream_ctx* S) {
     const double t_flush0 = now_ms();
     dbg_admit_ms += t_flush0 - t_admit0;
     if (!fresh.empty()) {
+      if (order_needed) {  // the rewrite waits for the tick that may be reading the shared cloud ...
+        hipError_t e = tick_ev ? hipSuccess : hipEventCreateWithFlags(&tick_ev, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventRecord(tick_ev, G.M);
+        if (e == hipSuccess) e = hipStreamWaitEvent(run.side, tick_ev, 0);
+        if (e != hipSuccess) { stream_fail(S, SICP_ERR_HIP, std::string("stream: ordering a feature rewrite: ") + hipGetErrorString(e)); return; }
+      }
       const int rc = flush_jobs(L, jc, run.side);
       if (rc != SICP_OK) { stream_fail(S, rc, L->last_error); return; }
+      if (order_needed) {  // ... and the next tick waits for the rewrite
+        const hipError_t e = hipEventRecord(G.side_done, run.side);
+        if (e != hipSuccess) { stream_fail(S, SICP_ERR_HIP, std::string("stream: ordering a feature rewrite: ") + hipGetErrorString(e)); return; }
+        G.side_recorded = true;
+        G.force_wait = true;
+      }
     }
     const double t_turn0 = now_ms();
     dbg_flush_ms += t_turn0 - t_flush0;

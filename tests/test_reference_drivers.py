@@ -185,14 +185,27 @@ def test_reference_nyu_eval_runs_on_the_engine(tmp_path):
     assert r2.returncode == 0, r2.stderr
     # summary rows `cloud number, label agreement, mean NN distance, pairs within 5 m` (exec/nyu_metrics.h:77-81): the
     # reference's host KdTreeFLANN search against the headless driver's GPU search
+    # (column 0, the "cloud number": exec/nyu_eval.cc:103-107 moves the path's digits to the front with std::remove_if and
+    #  never erases the tail, so std::stoi reads "0001" + the untouched rest "0001.pcd" of "seq/0001.pcd": 10001 for frame 1)
+    def ref_cloud_number(path):
+        digits = "".join(ch for ch in path if ch.isdigit())
+        moved = digits + path[len(digits):]
+        lead = ""
+        for ch in moved:
+            if not ch.isdigit():
+                break
+            lead += ch
+        return int(lead)
     for name in ("SICPnyu.csv", "se3GICPnyu.csv"):
-        same_rows(rows_of(one(str(run_dir / ("[0-9]*" + name)))), rows_of(str(our_dir / ("o_" + name))), time_col=-1)
+        ref_rows, our_rows = rows_of(one(str(run_dir / ("[0-9]*" + name)))), rows_of(str(our_dir / ("o_" + name)))
+        assert [int(r_[0]) for r_ in ref_rows] == [ref_cloud_number(f"seq/{int(r_[0]):04d}.pcd") for r_ in our_rows]
+        same_rows([r_[1:] for r_ in ref_rows], [r_[1:] for r_ in our_rows], time_col=-1)
     # the accumulated 895 x 895 confusion matrix, printed by Eigen's operator<< there and by the headless driver here
     ref_mat = np.loadtxt(one(str(run_dir / "Matrix*SICPnyu.csv")))
     our_mat = np.loadtxt(str(our_dir / "Matrixo_SICPnyu.csv"))
     assert ref_mat.shape == (895, 895) and np.array_equal(ref_mat, our_mat)
     # per-evaluation label pairs
-    ref_lab = np.loadtxt(one(str(run_dir / "Label1-*SICPnyu.csv")), delimiter=",")
+    ref_lab = np.loadtxt(one(str(run_dir / "Label10001-*SICPnyu.csv")), delimiter=",")
     our_lab = np.loadtxt(str(our_dir / "Label1-o_SICPnyu.csv"), delimiter=",")
     assert np.array_equal(ref_lab, our_lab)
 
