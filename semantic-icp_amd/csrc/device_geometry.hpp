@@ -21,9 +21,11 @@ __device__ __forceinline__ void corr_eval(const Pose& P, double one_m_eps, doubl
                                           double psz, double nsx, double nsy, double nsz,
                                           double ptx, double pty, double ptz, double ntx,
                                           double nty, double ntz, Corr& o) {
-  // pure float64 algebra with tolerance-level parity (1e-9): fused multiply-adds are welcome here,
-  // unlike in the float32 distance / transform code whose rounding must match the reference's
-#pragma clang fp contract(fast)
+  // pure float64 algebra with tolerance-level parity (1e-9).  NOT contracted: this function is inlined into several
+  // kernels (the weight kernels, the label kernel, the search's weight epilogue) and whether a multiply-add pair fuses
+  // would be each context's own choice -- the as-double Probability() branch (quirk Q1 off) then differs in the last
+  // bit from kernel to kernel.  Separate multiplies and adds are the same everywhere.
+#pragma clang fp contract(off)
   const double* R = P.R;
   const double mx = R[0] * nsx + R[1] * nsy + R[2] * nsz;
   const double my = R[3] * nsx + R[4] * nsy + R[5] * nsz;

@@ -432,6 +432,7 @@ struct sicp_stream_ctx {
     std::shared_ptr<Cloud> src, tgt;
     double init[7];
     unsigned flags;  // SICP_SUBMIT_*
+    int overtaken = 0;  // admission rounds in which it waited for a live registration to let go of its clouds (worker only)
   };
   std::deque<Submission> queue;
   std::deque<sicp_stream_result> done;

@@ -34,15 +34,16 @@ static void stream_worker_loop(sicp_stream_ctx* S) {
   // two clouds (records, dense records, neighbour lists, histograms, projections) on the side stream, while the tick
   // of the pairs already solving -- stream M -- reads those very buffers when another live registration shares a
   // cloud.  Nothing used to order the two; now:
-  //   * such a registration is admitted WITH ORDER: the side stream first waits for the tick in flight (an event on
+  //   * such a registration first waits in the queue for the live one to retire (others overtake it: free), and after
+  //     kMaxOvertaken worker turns it is admitted WITH ORDER: the side stream waits for the tick in flight (an event on
   //     M), and the next tick waits for the side stream's rewrite (TickGroup::force_wait) -- one tick without the
-  //     overlap, only when a rewritten cloud really is shared with a live registration (the re-submission of a pair
-  //     whose previous registration is still solving);
+  //     overlap, so a pair that is re-submitted faster than it converges does not become a serial chain;
   //   * two registrations of ONE admission round never rewrite the same cloud (their feature jobs would land in the
   //     same launch): the later one waits a round, later registrations that touch its clouds stay behind it, others
   //     overtake it (results carry tickets, not positions).
   // A registration that reuses features only reads: its reads follow any rewrite queued earlier on the side stream.
   std::unordered_map<const Cloud*, int> users;
+  constexpr int kMaxOvertaken = 48;  // worker turns (a turn = one tick of ~4 LM evaluations)
   std::vector<const Cloud*> held, round_clouds;
   bool round_rewrites = false, order_needed = false;
   hipEvent_t tick_ev = nullptr;  // recorded on M behind the tick in flight when a rewrite has to wait for it
@@ -79,12 +80,18 @@ static void stream_worker_loop(sicp_stream_ctx* S) {
         const bool rewrites = (it->flags & SICP_SUBMIT_FRESH_FEATURES) != 0;
         const bool in_round = std::find(round_clouds.begin(), round_clouds.end(), a) != round_clouds.end() ||
                               std::find(round_clouds.begin(), round_clouds.end(), b) != round_clouds.end();
-        if (behind || (in_round && (rewrites || round_rewrites))) {
+        const bool shared_live = rewrites && (users.count(a) || users.count(b)) && !in_round;  // with a registration admitted earlier
+        // a rewrite of a cloud a live registration reads first WAITS for that registration (free: others go ahead); only
+        // when it has waited kMaxOvertaken rounds is it admitted with order (one tick without overlap) -- a pair that is
+        // re-submitted faster than it converges must not become a serial chain
+        const bool wait_for_live = shared_live && it->overtaken < kMaxOvertaken;
+        if (behind || wait_for_live || (in_round && (rewrites || round_rewrites))) {
+          if (wait_for_live) ++it->overtaken;
           held.push_back(a); held.push_back(b);
           ++it;
           continue;
         }
-        if (rewrites && (users.count(a) || users.count(b))) order_needed = true;  // shared with a registration admitted earlier
+        if (shared_live) order_needed = true;
         if (rewrites) round_rewrites = true;
         round_clouds.push_back(a); round_clouds.push_back(b);
         ++users[a]; ++users[b];
