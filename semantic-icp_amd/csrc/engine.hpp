@@ -319,6 +319,11 @@ bool debug_enabled();
 constexpr int kParts = 4;  // slices of a batch whose stage sequences run on their own streams
 
 struct JobCollector {
+  // EM weights written by the search's own epilogue (stages.cpp: run_correspondences) instead of a weight kernel behind it:
+  // set by a batch of at most 4 pairs, where every launch is on the critical path of an align() (one pair alone: -46 us of
+  // 1.98 ms).  Not by larger batches and streams: there the separate weight kernel runs hidden beside the accumulate launches
+  // and the longer search does not (measured, profiles/r05/weights_in_search_epilogue.json: 256-pair step 184.4 against 185.3 ms).
+  bool fold_weights = false;
   int knn_K[kParts] = {};  // list length of a slice's searches (one launch per slice: one length)
   int slice = 0;  // slice of the batch the pair whose stage is running belongs to (set by the driver)
   std::vector<sicp::KnnArgs> knn[kParts];

@@ -422,6 +422,7 @@ int sicp_search_batch(sicp_handle* hs, int32_t n, const double* qt, int32_t what
     }
     // the handles' own stage drivers collect the jobs exactly as sicp_align_batch makes them
     JobCollector jc;
+    jc.fold_weights = what == 3;
     {
       BatchGuard guard(hs, n, &jc, h->stream);
       for (int p = 0; p < n; ++p) {

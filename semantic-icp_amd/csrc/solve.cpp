@@ -413,6 +413,7 @@ int align_batch(sicp_handle* hs, int32_t n, const double* init_qt, double* out_q
     HIPCHECK(hipStreamSynchronize(h->stream));  // earlier work of the handle on its own stream
   }
   JobCollector jc;
+  jc.fold_weights = n <= 4;
   BatchGuard guard(hs, n, one_launch ? &jc : nullptr, L->stream);
   const unsigned long long epoch = next_epoch();
   // A large batch starts PIPELINED: the per-align features (self-searches, covariances, projections) and the first

@@ -270,10 +270,11 @@ int run_correspondences(sicp_context* h, const double* qt, int K, bool weights) 
   const bool sem = P.mode == SICP_MODE_SEMANTIC;
   h->counted_in_search = false;
   // EM-ICP, K = 4, at most 16 classes, packet search: the weights are written by the search's own epilogue
-  // (knn_kernels.hip: KnnArgs::w_*; the same operations as em_weight_rows4_kernel, which then does not run).  Only when
+  // (knn_kernels.hip: KnnArgs::w_*; the same operations as em_weight_rows4_kernel, which then does not run) -- for a handle
+  // on its own and in batches of at most 4 pairs (JobCollector::fold_weights says why not in larger ones).  Only when
   // the projections it reads are already there -- computed by an EARLIER flush, not waiting in this one (a flush launches
   // its searches first) -- and not for the developer variants that have a weight kernel of their own.
-  // SICP_NO_WEIGHT_FOLD (A/B aid): always the separate kernel.
+  // SICP_NO_WEIGHT_FOLD / SICP_WEIGHT_FOLD_ALWAYS (A/B aids): never / also in large batches and streams.
   WeightFold fold_args;
   const WeightFold* fold = nullptr;
   {
@@ -283,8 +284,11 @@ int run_correspondences(sicp_context* h, const double* qt, int K, bool weights) 
     bool ok = weights && !no_fold && !lane_per_query && P.mode == SICP_MODE_EM && K == 4 && P.nn_method == 1 && P.profile == 0 &&
               P.num_classes >= 1 && P.num_classes <= 16 && !weights_from_histograms(P, K) && S.n_seg() == 1 &&
               S.proj_valid && T.proj_valid && S.proj_cm_id == want_id && T.proj_cm_id == want_id;
-    if (ok && h->collect)
+    if (ok && h->collect) {
+      static const bool always = std::getenv("SICP_WEIGHT_FOLD_ALWAYS") != nullptr;  // A/B aid: also in large batches and streams
+      ok = h->collect->fold_weights || always;
       for (int s = 0; s < kParts; ++s) ok = ok && h->collect->cov[s].empty() && h->collect->proj[s].empty();
+    }
     if (ok) {
       fold_args.srec = S.rec.p; fold_args.trec = T.rec.p;
       fold_args.sproj = S.proj.p; fold_args.tproj = T.proj.p;
