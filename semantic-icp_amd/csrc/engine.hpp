@@ -401,6 +401,7 @@ struct sicp_context {
   bool counted_in_search = false;     // ... and the search kernel of the current correspondences did so itself
   DevBuf<double> d_bout28;
   sicp::LmState* h_bstates = nullptr;
+  int* h_solo_flag = nullptr;  // pinned: the persistent solve's master writes its launch number here at a regular end (solve.cpp: solo_wait)
   double* h_bout28 = nullptr;
   int h_batch_cap = 0;  // capacity of the per-pair state mirrors (h_bstates, h_bout28)
   hipStream_t side_stream = nullptr;  // batch leader: searches of the pairs between two inner solves

@@ -296,6 +296,12 @@ struct SoloArgs {
   int init;            // 1: the inner solve starts with this launch (state := lm_init(opt, start)), 0: it continues
   int seq;             // written to the state's pad_ word at a regular end: the host's proof the launch ran to it
   int pad_;
+  // nullable: pinned, device-visible host memory.  At a regular end the master also writes the state THERE (plain stores, a
+  // system-scope fence) and then `seq` into *host_flag: the host polls that word instead of waiting for a read-back copy
+  // behind the kernel (copy kernel + completion signal + wake-up: ~30 us between an inner solve and the next search of a
+  // pair alone, four or five times per align()).
+  LmCore* host_state;
+  int* host_flag;
   double start[7];
   LmOptions opt;
 };

@@ -129,6 +129,7 @@ int sicp_destroy(sicp_handle h) {
       sicp::batch_graph_destroy(S.graph);
     }
     if (h->h_bstates) (void)hipHostFree(h->h_bstates);
+    if (h->h_solo_flag) (void)hipHostFree(h->h_solo_flag);
     if (h->h_bout28) (void)hipHostFree(h->h_bout28);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);

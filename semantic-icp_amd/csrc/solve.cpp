@@ -102,7 +102,7 @@ int batch_reserve(sicp_context* h, int n) {
     if (h->h_bstates) (void)hipHostFree(h->h_bstates);
     if (h->h_bout28) (void)hipHostFree(h->h_bout28);
     h->h_bstates = nullptr; h->h_bout28 = nullptr; h->h_batch_cap = 0;
-    HIPCHECK(hipHostMalloc((void**)&h->h_bstates, sizeof(sicp::LmState) * n, hipHostMallocDefault));
+    HIPCHECK(hipHostMalloc((void**)&h->h_bstates, sizeof(sicp::LmState) * n, hipHostMallocCoherent));  // (also written by the persistent solve's master)
     HIPCHECK(hipHostMalloc((void**)&h->h_bout28, sizeof(double) * 28 * n, hipHostMallocDefault));
     h->h_batch_cap = n;
   }
@@ -157,6 +157,15 @@ int tick_launch(sicp_context* h, TickSet& S, hipStream_t M, sicp_handle* hs, int
     A.seq = h->solo_seq = ++launches;
     if (A.init) std::memcpy(A.start, start[p], sizeof A.start);
     A.opt = lm_options(g->params);
+    // the state also lands in the pinned mirror by the master's own stores, and the launch number in a pinned word the host
+    // polls (solo_wait); the copy queued behind the kernel stays as the fallback (a launch that gave up writes neither)
+    if (!h->h_solo_flag) {
+      HIPCHECK(hipHostMalloc((void**)&h->h_solo_flag, 64, hipHostMallocCoherent));  // fine-grained: visible to the CPU while the kernel runs
+      *h->h_solo_flag = 0;
+    }
+    static const bool no_poll = std::getenv("SICP_SOLO_NO_HOST_POLL") != nullptr;  // A/B aid: wait for the read-back copy as before
+    A.host_state = no_poll ? nullptr : static_cast<sicp::LmCore*>(h->h_bstates + p);
+    A.host_flag = no_poll ? nullptr : h->h_solo_flag;
     h->solo_pair = p;
     h->solo_was_init = A.init != 0;
     S.tick_valid = false;  // (the argument array in HBM was not refreshed)
@@ -216,6 +225,29 @@ int tick_wait(sicp_context* h, hipStream_t M) {
   return SICP_OK;
 }
 
+// Wait for a persistent solve: its master writes the state into the pinned mirror and then the launch number into a pinned
+// word (SoloArgs::host_flag) -- the host polls that word (bounded) instead of waiting for the read-back copy queued behind
+// the kernel; whatever the poll does not see (a launch that gave up, polling switched off) the stream wait catches.
+int solo_wait(sicp_context* h, hipStream_t M) {
+  if (h->h_solo_flag) {
+    volatile int* flag = h->h_solo_flag;
+    for (int spins = 0; *flag != h->solo_seq; ++spins) {
+      // every ~20 us: has everything queued on M ended without the word changing?  Then the launch gave up (or the
+      // word is not coming): stop polling.
+      if ((spins & 1023) == 1023 && hipStreamQuery(M) != hipErrorNotReady) break;
+#if defined(__x86_64__)
+      __builtin_ia32_pause();
+#endif
+    }
+    if (*flag == h->solo_seq) {
+      std::atomic_thread_fence(std::memory_order_acquire);
+      return SICP_OK;
+    }
+  }
+  HIPCHECK(hipStreamSynchronize(M));
+  return SICP_OK;
+}
+
 // after a persistent launch has been waited for: did it run to its regular end?
 int solo_check(sicp_context* h) {
 #if defined(SICP_SOLO_TIMING)  // developer aid: cycles per phase of the master and of worker 0, per evaluation of the launch that just ended
@@ -252,7 +284,7 @@ int solo_check(sicp_context* h) {
 int run_tick(sicp_context* h, hipStream_t M, sicp_handle* hs, int n, const std::vector<int>& act, const std::vector<int>& joining,
              const double (*start)[7], int len, int solo_evals) {
   SICPCHECK(tick_launch(h, h->ts[0], M, hs, 0, n, act, joining, start, len, solo_evals));
-  SICPCHECK(tick_wait(h, M));
+  if (solo_evals > 0) SICPCHECK(solo_wait(h, M)); else SICPCHECK(tick_wait(h, M));
   if (solo_evals > 0) SICPCHECK(solo_check(h));
   return SICP_OK;
 }
@@ -263,7 +295,7 @@ int BatchRun::turn(TickGroup& G, JobCollector& jc) {
   sicp_context* h = L;
   if (G.pending) {
     const double tw0 = now_ms();
-    SICPCHECK(tick_wait(h, G.M));
+    if (solo_now) SICPCHECK(solo_wait(h, G.M)); else SICPCHECK(tick_wait(h, G.M));
     dbg_wait_ms += now_ms() - tw0; ++dbg_ticks; dbg_act += (long long)G.act.size();
     G.pending = false;
     G.finished.clear();

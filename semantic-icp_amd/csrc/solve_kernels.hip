@@ -925,6 +925,11 @@ __global__ __launch_bounds__(BS, 1) void solve_one_kernel(const SoloArgs A) {
       st.pad_ = A.seq;  // the launch ran to its regular end (after a timed-out wait the state in HBM is left as it was)
       *static_cast<LmCore*>(lm) = st;
       if (A.init) lm->opt = A.opt;
+      if (A.host_state) {  // the host's copy, then the word it polls (system scope: the CPU sees the state before the flag)
+        *A.host_state = st;
+        __threadfence_system();
+        __hip_atomic_store(A.host_flag, A.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
 #if defined(SICP_SOLO_TIMING)
       for (int i = 0; i < 4; ++i) { sync[kSoloSyncWords + 2 * i] = (unsigned)tm[i]; sync[kSoloSyncWords + 1 + 2 * i] = (unsigned)(tm[i] >> 32); }
 #endif
