@@ -585,6 +585,7 @@ int align_batch(sicp_handle* hs, int32_t n, const double* init_qt, double* out_q
     if (n_groups == 2) HIPCHECK(hipStreamWaitEvent(grp[1].M, h->main_done, 0));
   }
   JobCollector gjc[2];
+  gjc[0].fold_weights = gjc[1].fold_weights = jc.fold_weights;
   if (one_launch) {
     guard.retarget(side);
     for (int g = 0; g < n_groups; ++g)  // from here on a pair's stages collect into its group's job lists

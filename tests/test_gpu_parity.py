@@ -266,6 +266,24 @@ def test_em_weights_from_the_search_epilogue_equal_the_weight_kernel(lidar20k, C
         e.close()
     assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])
     assert np.array_equal(got[0][2], got[1][2])          # bit for bit
+    if C == 11:
+        # a pair alone: only its first search -- queued beside the feature kernels, before the projections exist -- is
+        # followed by the weight kernel, every later outer iteration's weights come from the search itself; a batch of more
+        # than 4 pairs keeps the kernel (it hides beside the accumulate launches there).  Same poses either way.
+        ident = np.array([0, 0, 0, 1, 0, 0, 0.0])
+        es = []
+        for k in range(5):
+            e, p = make_engine(sicp.MODE_EM, C, cm)
+            e.set_source(src, sl2)
+            e.set_target(tgt, tl2)
+            es.append(e)
+        q1, s1 = es[0].align(ident)
+        assert s1["outer_iters"] >= 2 and s1["weight_launches"] == 1
+        res = sicp.align_batch(es)
+        for q, st in res:
+            assert np.array_equal(q, q1) and st["weight_launches"] == st["outer_iters"]
+        for e in es:
+            e.close()
     assert (got[0][2][got[0][0] >= 0] > 0).all() and (got[0][2][got[0][0] < 0] == 0).all()
 
 
