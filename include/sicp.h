@@ -300,9 +300,9 @@ int sicp_stream_submit(sicp_stream s, int64_t source_id, int64_t target_id, cons
  *       exec/scenenet_eval.cc:193-198 calls right after align) is computed when the registration retires -- one more
  *       K = 4 search and one label kernel, queued beside the running registrations -- and kept until
  *       sicp_stream_take_labels(ticket) fetches it (once; n = the source cloud's point count, caller order).  The
- *       registration's result is only handed out by sicp_stream_poll when its labels are there.  Label sets that are
- *       never taken do not pile up: the stream keeps the newest 4 x max_in_flight + 64 and drops older ones
- *       (sicp_stream_take_labels then answers SICP_ERR_NOT_READY).
+ *       registration's result is only handed out by sicp_stream_poll when its labels are there.  Taking them is
+ *       the caller's side of the contract: a label set (4 bytes per source point) stays in host memory until it is taken or
+ *       the stream is destroyed -- a caller may take them long after the poll that returned the registration.
  *   SICP_SUBMIT_FRESH_FEATURES the normals / label histograms of BOTH clouds are recomputed for this registration,
  *       like every align() of the reference does (em_icp.hpp:28-29, gicp.hpp:33-34), instead of being kept with the
  *       cloud (a stream's default: what setSourceCloud(cloud, kdtree, covs) exists for).  Same values either way. */

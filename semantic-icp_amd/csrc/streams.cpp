@@ -233,14 +233,7 @@ static void stream_worker_loop(sicp_stream_ctx* S) {
         for (int d = 0; d < C0.n; ++d) lab[(size_t)C0.caller_index(d)] = h->h_labels[d];
         {
           std::lock_guard<std::mutex> lock(S->m);
-          S->labels[S->slot_ticket[p]] = std::move(lab);
-          // label sets nobody takes must not pile up: beyond 4 x the slots + 64 kept sets the oldest is dropped
-          while (S->labels.size() > 4 * (size_t)S->cap + 64) {
-            auto oldest = S->labels.begin();
-            for (auto it = S->labels.begin(); it != S->labels.end(); ++it)
-              if (it->first < oldest->first) oldest = it;
-            S->labels.erase(oldest);
-          }
+          S->labels[S->slot_ticket[p]] = std::move(lab);  // kept until sicp_stream_take_labels(ticket) (or the stream's end)
         }
         run.phase[p] = PAIR_DONE;
         S->slot_flags[p] &= ~(unsigned)SICP_SUBMIT_FUSED_LABELS;
