@@ -219,6 +219,15 @@ def test_reference_test_icp_and_roc_eval_run_to_the_end(tmp_path):
     r = subprocess.run([exe, "-s", str(tmp_path / "a.pcd"), "-t", str(tmp_path / "b.pcd")], cwd=tmp_path, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     assert "Time Multiclass" in r.stdout and "Time Single Class" in r.stdout and "GICP transform" in r.stdout
+    # exec/make_semantic.cc: reads ./cloudB.pcd, zeroes the labels, splits it with pcl_2_semantic (covariances on the GPU) and
+    # prints the covariances that are NaN -- none for a cloud without degenerate neighbourhoods
+    ms = driver("make_semantic")
+    ms_dir = tmp_path / "ms"
+    ms_dir.mkdir()
+    pcd_files.write_pcd(str(ms_dir / "cloudB.pcd"), tgt, tl, "binary_compressed")
+    r = subprocess.run([ms], cwd=ms_dir, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert f"Loaded {len(tgt)} data points" in r.stdout and "Labels:" in r.stdout and "nan" not in r.stdout.lower()
     # exec/roc_eval.cc: label pairs of registered clouds against separately labelled ground-truth clouds
     roc = driver("roc_eval")
     for sub in ("pred", "gt"):
