@@ -492,19 +492,6 @@ __global__ __launch_bounds__(64) void bvh_knn_kernel(KnnArgs a) {
 // shrinks and there are enough waves to hide memory latency.  The four lists are merged through
 // LDS at the end; keys make the result independent of visiting order, so it is bit-identical to
 // the other engines.
-__device__ __forceinline__ float quad_min(float v) {
-  float o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));  // quad_perm [1,0,3,2]
-  v = fminf(v, o);
-  o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));  // quad_perm [2,3,0,1]
-  return fminf(v, o);
-}
-__device__ __forceinline__ float quad_max(float v) {
-  float o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));
-  v = fmaxf(v, o);
-  o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));
-  return fmaxf(v, o);
-}
-
 // Pruning bound of a quad: an upper bound of the query's true K-th smallest distance from the four
 // partial lists (each the K best of a quarter of the candidates seen so far).
 //   (1) any lane's own K-th distance: its K candidates are among all candidates;
@@ -764,6 +751,12 @@ __device__ __forceinline__ int locate_leaf(const u64* __restrict__ codes, int to
   return lo;
 }
 
+// (Round 5, built and measured, not kept: a walk that PREFETCHES below a level-2 node -- the leaf boxes and leaf groups of all
+// level-1 children that pass, requested in one round trip, their bounds parked in LDS -- to shorten the chain of dependent
+// loads of a search that runs alone.  Same decisions, bit-identical results, and slower everywhere: one search alone 66 -> 89 us
+// (first search 70 -> 97), 24 -> 39 us per search in a 16-job launch: 102 VGPRs / 31 KB of LDS per workgroup halve the waves in
+// flight, and the loads for children that are pruned before their turn cost more than the round trips saved.
+// profiles/r05/prefetching_walk.json.)
 constexpr int kWalkLevels = kMaxLevels - 1;  // levels that carry sibling bounds (every level but the root)
 
 // The four leaves below a level-1 node are 64 consecutive points = 1 KB: ONE LDS-DMA instruction (global_load_lds,
