@@ -1045,8 +1045,14 @@ __global__ __launch_bounds__(64 * WPB) void bvh_knn_packet_kernel(KnnArgs a) {
 // Several searches in one launch (lock-step batch: all pairs' searches of a phase): blockIdx.y picks
 // the job from an array passed BY VALUE -- kernel arguments keep their pointers typed as HBM and
 // are read with scalar loads.  The jobs' long tails overlap inside the one launch.
+// (SICP_KNN20_WAVES, build-time experiment: waves per SIMD the long-list kernels are compiled for.  Their 122 VGPRs give 4;
+// forced to 5 (96 VGPRs, 72 bytes of spills) a k = 20 self-search takes 39.7 instead of 40.4 us in a 16-job launch, forced to 6
+// (80 VGPRs, 136 bytes) 41.3 us: not worth the spills.)
+#ifndef SICP_KNN20_WAVES
+#define SICP_KNN20_WAVES 1
+#endif
 template <int K, int WPB>
-__global__ __launch_bounds__(64 * WPB) void bvh_knn_packet_jobs_kernel(KnnJobs jobs) {
+__global__ __launch_bounds__(64 * WPB, (K >= 16 ? SICP_KNN20_WAVES : 1)) void bvh_knn_packet_jobs_kernel(KnnJobs jobs) {
   const KnnArgs& a = jobs.job[blockIdx.y];
   const int n_wg = ((a.q_count + 15) / 16 + WPB - 1) / WPB;
   if ((int)blockIdx.x >= n_wg) return;
