@@ -144,7 +144,9 @@ typedef struct sicp_stats {
   int32_t outer_iters;      /* what getOuterIter() returns (em_icp.h:88-91)          */
   int32_t total_lm_iters;
   int32_t total_evals;      /* accumulate passes ("E" of SURVEY.md 8d), all outer    */
-  int32_t reserved0;
+  int32_t weights_in_search; /* correspondence searches of this align() that wrote the EM weights themselves
+                               (a handle alone, batches of <= 4 pairs): these have no weight launch of their own,
+                               so weight_launches + weights_in_search = searches with weights            */
   int64_t total_corr;       /* sum over outer passes of N_s*K candidate slots        */
   int64_t total_active;     /* slots that passed the distance gate                   */
   double final_cost;

@@ -73,7 +73,7 @@ class SicpStats(C.Structure):
         ("outer_iters", C.c_int32),
         ("total_lm_iters", C.c_int32),
         ("total_evals", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("weights_in_search", C.c_int32),
         ("total_corr", C.c_int64),
         ("total_active", C.c_int64),
         ("final_cost", C.c_double),
@@ -95,7 +95,7 @@ class SicpStats(C.Structure):
     ]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved0"}
+        return {k: getattr(self, k) for k, _ in self._fields_}
 
 
 class SicpStreamResult(C.Structure):

@@ -5,6 +5,8 @@
 namespace sicp {
 namespace host {
 
+constexpr size_t kSoloFallbackOffset = 64;  // bytes between the persistent solve's polled word and its fallback copy's landing area (one cache line)
+
 sicp::LmOptions lm_options(const sicp_params& P) {
   sicp::LmOptions o;
   o.max_iterations = P.max_lm_iterations;
@@ -160,7 +162,8 @@ int tick_launch(sicp_context* h, TickSet& S, hipStream_t M, sicp_handle* hs, int
     // the state also lands in the pinned mirror by the master's own stores, and the launch number in a pinned word the host
     // polls (solo_wait); the copy queued behind the kernel stays as the fallback (a launch that gave up writes neither)
     if (!h->h_solo_flag) {
-      HIPCHECK(hipHostMalloc((void**)&h->h_solo_flag, 64, hipHostMallocCoherent));  // fine-grained: visible to the CPU while the kernel runs
+      // fine-grained: visible to the CPU while the kernel runs.  Behind the word: the landing area of the fallback copy
+      HIPCHECK(hipHostMalloc((void**)&h->h_solo_flag, kSoloFallbackOffset + sizeof(sicp::LmState), hipHostMallocCoherent));
       *h->h_solo_flag = 0;
     }
     static const bool no_poll = std::getenv("SICP_SOLO_NO_HOST_POLL") != nullptr;  // A/B aid: wait for the read-back copy as before
@@ -170,7 +173,10 @@ int tick_launch(sicp_context* h, TickSet& S, hipStream_t M, sicp_handle* hs, int
     h->solo_was_init = A.init != 0;
     S.tick_valid = false;  // (the argument array in HBM was not refreshed)
     HIPCHECK(sicp::launch_solve_one(g->corr_K, h->params.use_sqloss, A, nb, M));
-    HIPCHECK(hipMemcpyAsync(h->h_bstates + p, h->d_bstates.p + p, sizeof(sicp::LmState), hipMemcpyDeviceToHost, M));
+    // The fallback read-back lands in an area of its OWN: the host reads h_bstates[p] as soon as the polled word has changed,
+    // while this copy may still be in flight behind the kernel -- it must not rewrite what the host is reading (solo_wait
+    // moves it over when the poll did not see the word: a launch that gave up, polling switched off).
+    HIPCHECK(hipMemcpyAsync(reinterpret_cast<char*>(h->h_solo_flag) + kSoloFallbackOffset, h->d_bstates.p + p, sizeof(sicp::LmState), hipMemcpyDeviceToHost, M));
     return SICP_OK;
   }
   // the argument array in HBM only changes when the set of pairs inside a solve does
@@ -235,16 +241,21 @@ int solo_wait(sicp_context* h, hipStream_t M) {
       // every ~20 us: has everything queued on M ended without the word changing?  Then the launch gave up (or the
       // word is not coming): stop polling.
       if ((spins & 1023) == 1023 && hipStreamQuery(M) != hipErrorNotReady) break;
+      // a solve of a few hundred evaluations lasts milliseconds: after ~0.2 ms of pure spinning the poll gives its core
+      // to whoever else wants it between looks (a stream's worker shares the host with the submitting threads)
+      if (spins > 16384 && (spins & 255) == 255) std::this_thread::yield();
 #if defined(__x86_64__)
       __builtin_ia32_pause();
 #endif
     }
     if (*flag == h->solo_seq) {
       std::atomic_thread_fence(std::memory_order_acquire);
-      return SICP_OK;
+      return SICP_OK;  // (h_bstates[solo_pair] holds the LmCore the master wrote; the options behind it never change)
     }
   }
   HIPCHECK(hipStreamSynchronize(M));
+  if (h->h_solo_flag && h->solo_pair >= 0)
+    std::memcpy(static_cast<void*>(h->h_bstates + h->solo_pair), reinterpret_cast<const char*>(h->h_solo_flag) + kSoloFallbackOffset, sizeof(sicp::LmState));
   return SICP_OK;
 }
 

@@ -192,6 +192,15 @@ int compute_features(sicp_context* h, Cloud& c, bool with_hist, hipStream_t stre
                      SICP_PROFILE_COV, stream, nn_stride));
   }
   c.nn_stride = nn_stride;
+  {
+    // Test aid (needs SICP_DEBUG): the N-th call of this routine in the process fails HERE -- its self-search jobs are
+    // queued, its covariance job is not -- with the status an exhausted arena gives.  A failure at this point cannot be
+    // provoked from outside (a cloud's feature buffers are reserved when it is set), and it is the one that used to leave
+    // the registration's OTHER cloud marked current with nothing computed (tests/test_gpu_stream.py).
+    static const int fail_at = (debug_enabled() && std::getenv("SICP_FAULT_FEATURES_CALL")) ? std::atoi(std::getenv("SICP_FAULT_FEATURES_CALL")) : 0;
+    static std::atomic<int> calls{0};
+    if (fail_at > 0 && ++calls == fail_at) return SICP_ERR_OUT_OF_MEMORY;
+  }
   sicp::CovArgs a;
   a.n = n; a.k = k; a.C = with_hist ? P.num_classes : 0;
   a.x = c.x.p; a.y = c.y.p; a.z = c.z.p;
@@ -328,6 +337,7 @@ int run_correspondences(sicp_context* h, const double* qt, int K, bool weights) 
   if (h->count_stats && !h->counted_in_search) SICPCHECK(count_active(h));
   if (weights && fold) {
     h->corr_weighted = true;  // (written by the search itself)
+    ++h->st.weights_in_search;
   } else if (weights) {
     SICPCHECK(run_weights(h, qt));
   }

@@ -11,6 +11,25 @@ void stream_fail(sicp_stream_ctx* S, int rc, const std::string& msg) {
   S->cv_space.notify_all();
 }
 
+// What compute_features / ensure_proj record about a cloud's feature buffers at the moment they queue the kernels.
+struct FeatureMarks {
+  bool feat_valid = false, proj_valid = false, feat_hist = false;
+  int rec_dense_n = 0, feat_k = 0, feat_C = 0, feat_float_products = 0, nn_stride = 0;
+  unsigned long long feat_epoch = 0, proj_cm_id = 0;
+  explicit FeatureMarks(const Cloud* c) {
+    if (!c) return;
+    feat_valid = c->feat_valid; proj_valid = c->proj_valid; feat_hist = c->feat_hist; rec_dense_n = c->rec_dense_n;
+    feat_k = c->feat_k; feat_C = c->feat_C; feat_float_products = c->feat_float_products; nn_stride = c->nn_stride;
+    feat_epoch = c->feat_epoch; proj_cm_id = c->proj_cm_id;
+  }
+  void restore(Cloud* c) const {
+    if (!c) return;
+    c->feat_valid = feat_valid; c->proj_valid = proj_valid; c->feat_hist = feat_hist; c->rec_dense_n = rec_dense_n;
+    c->feat_k = feat_k; c->feat_C = feat_C; c->feat_float_products = feat_float_products; c->nn_stride = nn_stride;
+    c->feat_epoch = feat_epoch; c->proj_cm_id = proj_cm_id;
+  }
+};
+
 // The worker: admit queued registrations into free slots, one turn of the continuous batching
 // (BatchRun::turn: finish the tick in flight, queue the searches of the pairs between two solves, launch
 // the next tick), retire the pairs that have converged.  One iteration per tick.
@@ -44,7 +63,7 @@ static void stream_worker_loop(sicp_stream_ctx* S) {
   // A registration that reuses features only reads: its reads follow any rewrite queued earlier on the side stream.
   std::unordered_map<const Cloud*, int> users;
   constexpr int kMaxOvertaken = 48;  // worker turns (a turn = one tick of ~4 LM evaluations)
-  std::vector<const Cloud*> held, round_clouds;
+  std::unordered_set<const Cloud*> held, round_clouds;  // (hash sets: the scan below runs under S->m once per worker turn)
   bool round_rewrites = false, order_needed = false;
   hipEvent_t tick_ev = nullptr;  // recorded on M behind the tick in flight when a rewrite has to wait for it
   auto release_users = [&](const Cloud* a, const Cloud* b) {
@@ -76,10 +95,9 @@ static void stream_worker_loop(sicp_stream_ctx* S) {
       for (auto it = S->queue.begin(); it != S->queue.end() && !free_slots.empty();) {
         const Cloud* a = it->src.get();
         const Cloud* b = it->tgt.get();
-        const bool behind = std::find(held.begin(), held.end(), a) != held.end() || std::find(held.begin(), held.end(), b) != held.end();
+        const bool behind = held.count(a) || held.count(b);
         const bool rewrites = (it->flags & SICP_SUBMIT_FRESH_FEATURES) != 0;
-        const bool in_round = std::find(round_clouds.begin(), round_clouds.end(), a) != round_clouds.end() ||
-                              std::find(round_clouds.begin(), round_clouds.end(), b) != round_clouds.end();
+        const bool in_round = round_clouds.count(a) || round_clouds.count(b);
         const bool shared_live = rewrites && (users.count(a) || users.count(b)) && !in_round;  // with a registration admitted earlier
         // a rewrite of a cloud a live registration reads first WAITS for that registration (free: others go ahead); only
         // when it has waited kMaxOvertaken rounds is it admitted with order (one tick without overlap) -- a pair that is
@@ -87,13 +105,13 @@ static void stream_worker_loop(sicp_stream_ctx* S) {
         const bool wait_for_live = shared_live && it->overtaken < kMaxOvertaken;
         if (behind || wait_for_live || (in_round && (rewrites || round_rewrites))) {
           if (wait_for_live) ++it->overtaken;
-          held.push_back(a); held.push_back(b);
+          held.insert(a); held.insert(b);
           ++it;
           continue;
         }
         if (shared_live) order_needed = true;
         if (rewrites) round_rewrites = true;
-        round_clouds.push_back(a); round_clouds.push_back(b);
+        round_clouds.insert(a); round_clouds.insert(b);
         ++users[a]; ++users[b];
         slot_clouds[(size_t)free_slots.back()] = {a, b};
         fresh.push_back(std::move(*it));
@@ -127,6 +145,7 @@ static void stream_worker_loop(sicp_stream_ctx* S) {
         mark[0][q] = jc.knn[q].size(); mark[1][q] = jc.cov[q].size(); mark[2][q] = jc.proj[q].size();
         mark[3][q] = jc.weight[q].size(); mark[4][q] = jc.count[q].size();
       }
+      FeatureMarks before[2] = {FeatureMarks(h->cl[0].get()), FeatureMarks(h->cl[1].get())};
       int rc = check_ready(h, false);
       // SICP_SUBMIT_FRESH_FEATURES: this registration recomputes the features of both its clouds, like an align() of
       // the reference (the slot's epoch is new, so align_begin finds them stale)
@@ -147,6 +166,13 @@ static void stream_worker_loop(sicp_stream_ctx* S) {
           jc.knn[q].resize(mark[0][q]); jc.cov[q].resize(mark[1][q]); jc.proj[q].resize(mark[2][q]);
           jc.weight[q].resize(mark[3][q]); jc.count[q].resize(mark[4][q]);
         }
+        // ... and with the jobs goes what they would have written: compute_features / ensure_proj mark a cloud's records,
+        // histograms and projections current when they QUEUE the kernels, so a registration that failed on its second cloud
+        // (an arena that is full: SICP_ERR_OUT_OF_MEMORY) would leave its first cloud marked current with nothing computed,
+        // and every later registration sharing it would solve on stale or uninitialised features.  The clouds get back the
+        // marks they had before this registration queued anything (what an earlier registration of this round queued for
+        // them is still in the collector and still runs).
+        for (int c = 0; c < 2; ++c) before[c].restore(h->cl[c].get());
         release_users(slot_clouds[(size_t)p].first, slot_clouds[(size_t)p].second);
         slot_clouds[(size_t)p] = {nullptr, nullptr};
         h->cl[0] = acquire_cloud(S->device);

@@ -279,9 +279,10 @@ def test_em_weights_from_the_search_epilogue_equal_the_weight_kernel(lidar20k, C
             es.append(e)
         q1, s1 = es[0].align(ident)
         assert s1["outer_iters"] >= 2 and s1["weight_launches"] == 1
+        assert s1["weights_in_search"] == s1["outer_iters"] - 1   # the counters say where the weights were computed
         res = sicp.align_batch(es)
         for q, st in res:
-            assert np.array_equal(q, q1) and st["weight_launches"] == st["outer_iters"]
+            assert np.array_equal(q, q1) and st["weight_launches"] == st["outer_iters"] and st["weights_in_search"] == 0
         for e in es:
             e.close()
     assert (got[0][2][got[0][0] >= 0] > 0).all() and (got[0][2][got[0][0] < 0] == 0).all()

@@ -23,7 +23,7 @@ for gi, g in enumerate(groups):
     subprocess.run(["rm", "-rf", d])
     try:
       r = subprocess.run(["rocprofv3", "--pmc", *g.split(), "--output-format", "csv", "-d", d, "--", "python3", "tools/bench_acc_batch.py", S],
-                         capture_output=True, text=True, timeout=180, env=env)
+                         capture_output=True, text=True, timeout=360, env=env)
     except subprocess.TimeoutExpired:
         errors[g] = "timed out"
         json.dump({"pairs_per_launch": int(S), "env": sys.argv[3:], "counters": res, "failed_passes": errors}, open(out_path, "w"), indent=1)
