@@ -347,6 +347,7 @@ struct TickSet {
   sicp::BatchGraph graph;
   std::vector<int> tick_act;  // the pairs whose arguments d_batch currently holds
   bool tick_valid = false;
+  unsigned epoch_host = 0;    // mirror of d_bhdr->epoch_base: tick_prepare_kernel adds kMaxBatchLen per tick, and so does the host
 };
 
 }  // namespace host
@@ -393,6 +394,7 @@ struct sicp_context {
   // state per pair, pinned mirrors, and the captured [accumulate_batch, lm_step_batch] x lm_batch graph
   TickSet ts[2];  // two sets: the halves of a batch alternate, one's tick runs while the host turns the other around
   DevBuf<sicp::LmState> d_bstates;
+  DevBuf<sicp::EvalIn> d_ein;         // [2 per pair]: what an evaluation reads of its pair when the accumulate launch steps the machine itself
   DevBuf<unsigned> d_solo_sync;       // the last pair still iterating: hand-off words of the persistent solve (solve_one_kernel)
   unsigned solo_tag = 0;              // its tags so far (a launch uses solo_tag + 1 ...: the words are never zeroed in between)
   int solo_seq = 0, solo_pair = 0;    // launch counter (the state's pad_ word echoes it at a regular end) and the pair's state slot
@@ -580,6 +582,7 @@ struct SolveResult {
 };
 
 bool solo_allowed(sicp_context* h);
+bool lm_step_in_launch();
 int run_solve(sicp_context* h, const double* init_qt, double* out_qt, SolveResult* res);
 bool same_solver(const sicp_params& a, const sicp_params& b);
 int tickset_reserve(sicp_context* h, TickSet& S, int n);

@@ -193,6 +193,19 @@ struct WeightArgs {
   double* w;
 };
 
+// What one evaluation of a device-resident solve reads about its pair -- pose and status -- when the LM step runs INSIDE the
+// accumulate launch (the last workgroup to finish a pair's chunks steps its machine: accumulate_staged_kernel).  Two entries
+// per pair, picked by the parity of the evaluation's EPOCH (BatchHeader::epoch_base + the launch's index in its tick): launch
+// e reads entry e & 1 and its LM step writes entry (e + 1) & 1, so a workgroup that is dispatched late -- beside a flood of
+// search workgroups they are -- still sees what every other workgroup of the launch saw.  An entry counts only when its
+// epoch is the launch's: a pair that finished at e is not running at e + 2.
+struct alignas(16) EvalIn {
+  double pose[7];
+  int status;       // LM_*
+  unsigned epoch;
+};
+static_assert(sizeof(EvalIn) == 64, "one cache line half");
+
 struct AccArgs {
   int n_s, K;
   const int* idx;
@@ -202,6 +215,7 @@ struct AccArgs {
   Pose pose;            // used when lm == nullptr
   const LmState* lm;    // device-resident solve: evaluate at lm->pose, skip when it has finished
   LmState* lm_step;     // batched solve: the state lm_step_batch_kernel advances (== lm)
+  EvalIn* ein;          // nullable: [2]; with it the accumulate launch steps the machine itself (no lm_step_batch_kernel)
   double one_m_eps;
   LossArgs loss;
   double* partials;  // [28][accumulate_blocks]
@@ -229,7 +243,8 @@ struct BatchArgs {
 // array, so the instantiated graph never changes
 struct BatchHeader {
   int n_pairs;   // entries of the BatchArgs array (pairs whose solve has ended are skipped on the device)
-  int pad_[3];
+  unsigned epoch_base;  // epoch of the current tick's first evaluation (advanced on the device by tick_prepare_kernel)
+  int pad_[2];
 };
 
 // [accumulate, lm_step_batch] x len of a lock-step batch as an instantiated graph with explicit
@@ -238,13 +253,14 @@ constexpr int kMaxBatchLen = 32;
 struct BatchGraph {
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
-  int len = 0, K = 0, sqloss = 0, capacity = 0;
+  int len = 0, K = 0, sqloss = 0, capacity = 0, fold = 0;
   const BatchArgs* batch = nullptr;
   const BatchHeader* hdr = nullptr;
 };
 // *built is set to 1 when the graph had to be (re)instantiated
+// fold != 0: [tick_prepare, accumulate x len] (the accumulate launches step the LM machines: AccArgs::ein is set)
 hipError_t batch_graph_prepare(BatchGraph& g, int K, int use_sqloss, const BatchHeader* hdr, const BatchArgs* batch, int capacity, int len,
-                               int* built);
+                               int* built, int fold = 0);
 void batch_graph_destroy(BatchGraph& g);
 
 // neighbour-list length the search kernels run with for a request of k neighbours (the k nearest
@@ -268,8 +284,12 @@ hipError_t launch_em_weight_jobs(const WeightArgs* jobs, int n, hipStream_t st);
 hipError_t launch_count_active_jobs(const CountJob* jobs, int n, hipStream_t st);
 int accumulate_blocks(int total, int K);  // chunks of a pair with `total` slots, K correspondences per source point
 // every pair of the batch in one launch: hdr / batch in HBM, capacity = slots of the batch buffers
-hipError_t launch_accumulate_batch(int K, int use_sqloss, const BatchHeader* hdr, const BatchArgs* batch, int capacity, hipStream_t st);
+// node = index of the launch inside its tick (its epoch is hdr->epoch_base + node; only read by pairs with AccArgs::ein)
+hipError_t launch_accumulate_batch(int K, int use_sqloss, const BatchHeader* hdr, const BatchArgs* batch, int capacity, hipStream_t st, int node = 0);
 hipError_t launch_lm_step_batch(const BatchHeader* hdr, const BatchArgs* batch, int capacity, hipStream_t st);
+// first kernel of a tick whose accumulate launches step the LM machines themselves: advances hdr->epoch_base and
+// publishes every pair's pose / status (from its LmState) as the first evaluation's EvalIn
+hipError_t launch_tick_prepare(BatchHeader* hdr, const BatchArgs* batch, hipStream_t st);
 // one pair alone: the whole inner solve of batch[0] in one persistent launch (one workgroup per chunk); its partials
 // buffer holds TWO sets of columns, sync = max_evals + 1 words (word 0 is raised when a device-wide wait timed out)
 bool solve_one_fits(int total_slots, int K);

@@ -376,7 +376,7 @@ int sicp_accumulate_batch(sicp_handle* hs, int32_t n, const double* qt, double* 
 #else
     const int inner = 0;
 #endif
-    *h->ts[0].h_bhdr = sicp::BatchHeader{n, {inner, 0, 0}};
+    *h->ts[0].h_bhdr = sicp::BatchHeader{n, h->ts[0].epoch_host, {inner, 0}};
     HIPCHECK(hipMemcpyAsync(h->ts[0].d_bhdr.p, h->ts[0].h_bhdr, sizeof(sicp::BatchHeader), hipMemcpyHostToDevice, h->stream));
     HIPCHECK(hipMemcpyAsync(h->ts[0].d_batch.p, h->ts[0].h_batch, sizeof(sicp::BatchArgs) * n, hipMemcpyHostToDevice, h->stream));
     if (repeat < 1) repeat = 1;

@@ -99,6 +99,11 @@ int batch_reserve(sicp_context* h, int n) {
   SICPCHECK(tickset_reserve(h, h->ts[0], n));
   n = std::max(32, (n + 31) / 32 * 32);
   HIPCHECK(h->d_bstates.reserve(n));
+  if (h->d_ein.cap < (size_t)2 * n) {  // (zeroed: epoch 0 never is a launch's epoch)
+    HIPCHECK(h->d_ein.reserve((size_t)2 * n));
+    HIPCHECK(hipMemsetAsync(h->d_ein.p, 0, sizeof(sicp::EvalIn) * h->d_ein.cap, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+  }
   HIPCHECK(h->d_bout28.reserve((size_t)28 * n));
   if (h->h_batch_cap < n) {
     if (h->h_bstates) (void)hipHostFree(h->h_bstates);
@@ -109,6 +114,17 @@ int batch_reserve(sicp_context* h, int n) {
     h->h_batch_cap = n;
   }
   return SICP_OK;
+}
+
+// Build-time experiment of round 6 (-DSICP_LM_STEP_IN_LAUNCH, then SICP_LM_STEP_IN_LAUNCH=1): the LM step of a tick inside its
+// accumulate launches (solve_kernels.hip says what it measured: slower).  The product's tick is [accumulate, lm_step_batch] x len.
+bool lm_step_in_launch() {
+#if defined(SICP_LM_STEP_IN_LAUNCH)
+  static const bool on = std::getenv("SICP_LM_STEP_IN_LAUNCH") != nullptr;
+  return on;
+#else
+  return false;
+#endif
 }
 
 // One TICK of a batch: `len` LM evaluations of every pair in `act` (pair indices), in one graph launch:
@@ -191,10 +207,11 @@ int tick_launch(sicp_context* h, TickSet& S, hipStream_t M, sicp_handle* hs, int
     if (g->partials.reserve((size_t)nb * 28) != hipSuccess) return SICP_ERR_OUT_OF_MEMORY;
     fill_acc(g, B.a);
     B.a.lm = B.a.lm_step = h->d_bstates.p + p;
+    B.a.ein = lm_step_in_launch() ? h->d_ein.p + 2 * (size_t)p : nullptr;
     B.nb = nb;
   }
   if (!same_set) {
-    *S.h_bhdr = sicp::BatchHeader{(int)act.size(), {0, 0, 0}};
+    *S.h_bhdr = sicp::BatchHeader{(int)act.size(), S.epoch_host, {0, 0}};
     HIPCHECK(hipMemcpyAsync(S.d_bhdr.p, S.h_bhdr, sizeof(sicp::BatchHeader), hipMemcpyHostToDevice, M));
     HIPCHECK(hipMemcpyAsync(S.d_batch.p, S.h_batch, sizeof(sicp::BatchArgs) * act.size(), hipMemcpyHostToDevice, M));
     S.tick_act = act;
@@ -207,19 +224,22 @@ int tick_launch(sicp_context* h, TickSet& S, hipStream_t M, sicp_handle* hs, int
   // fault when a thread other than the main one launches graphs while it traces kernels (tools/r04/two_thread_dispatch.hip
   // reproduces it without this library), and a stream's ticks are launched by its worker thread.  Same kernels, same bits.
   static const bool no_graph = std::getenv("SICP_NO_GRAPH") != nullptr;
+  const bool fold = lm_step_in_launch();
   if (no_graph) {
     const int cap = std::min(S.cap, kMaxActivePairs);
+    if (fold) HIPCHECK(sicp::launch_tick_prepare(S.d_bhdr.p, S.d_batch.p, M));
     for (int b = 0; b < len; ++b) {
-      HIPCHECK(sicp::launch_accumulate_batch(hs[act[0]]->corr_K, h->params.use_sqloss, S.d_bhdr.p, S.d_batch.p, cap, M));
-      HIPCHECK(sicp::launch_lm_step_batch(S.d_bhdr.p, S.d_batch.p, cap, M));
+      HIPCHECK(sicp::launch_accumulate_batch(hs[act[0]]->corr_K, h->params.use_sqloss, S.d_bhdr.p, S.d_batch.p, cap, M, b));
+      if (!fold) HIPCHECK(sicp::launch_lm_step_batch(S.d_bhdr.p, S.d_batch.p, cap, M));
     }
   } else {
     int built = 0;
     HIPCHECK(sicp::batch_graph_prepare(S.graph, hs[act[0]]->corr_K, h->params.use_sqloss, S.d_bhdr.p, S.d_batch.p, std::min(S.cap, kMaxActivePairs),
-                                       len, &built));
+                                       len, &built, fold ? 1 : 0));
     h->st.graph_builds += built;
     HIPCHECK(hipGraphLaunch(S.graph.exec, M));
   }
+  if (fold) S.epoch_host += (unsigned)sicp::kMaxBatchLen;  // (what tick_prepare_kernel has just been queued to do)
   HIPCHECK(hipMemcpyAsync(h->h_bstates + lo, h->d_bstates.p + lo, sizeof(sicp::LmState) * (hi - lo), hipMemcpyDeviceToHost, M));
   return SICP_OK;
 }

@@ -162,6 +162,17 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 #define SICP_GLOBAL __attribute__((address_space(1)))
 
+// Hand-offs between workgroups of one launch (the persistent solve; the LM step inside the accumulate launch): write-through stores and agent-scope loads of
+// at most 8 bytes -- visible across CUs and XCDs without a release / acquire fence (cdna_hip_programming.md
+// guideline 16, recipe R1: payload sc1 -> the storing wave drains -> one lane stores the flag).
+typedef unsigned long long u64;
+__device__ __forceinline__ void coherent_store_f64(SICP_GLOBAL double* p, double v) {
+  __hip_atomic_store((SICP_GLOBAL u64*)p, (u64)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double coherent_load_f64(const SICP_GLOBAL double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load((const SICP_GLOBAL u64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
 // a value every lane holds identically -> scalar registers (it costs no VGPRs and feeds the scalar
 // operand of the vector instructions that use it)
 __device__ __forceinline__ double uniform_f64(double v) {
@@ -487,7 +498,11 @@ __device__ __forceinline__ void accumulate_segment(const LoadCtx& L, const MathC
     __builtin_amdgcn_s_barrier();
     for (int e = threadIdx.x; e < parked * 28; e += BS) {
       const int c = e / 28, k = e - 28 * c;
+#if defined(SICP_LM_STEP_IN_LAUNCH)  // (write-through: the workgroup that finishes a pair LAST sums the columns of all of them inside this launch)
+      coherent_store_f64(partials + (size_t)k * n_chunks + (chunk - parked + c), (comb[c][0][k] + comb[c][1][k]) + (comb[c][2][k] + comb[c][3][k]));
+#else
       partials[(size_t)k * n_chunks + (chunk - parked + c)] = (comb[c][0][k] + comb[c][1][k]) + (comb[c][2][k] + comb[c][3][k]);
+#endif
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -582,21 +597,115 @@ __device__ __forceinline__ void accumulate_segment(const LoadCtx& L, const MathC
   }
 }
 
+// Fixed-order sum of the partial columns (layout [28][n]) by one workgroup of
+// REDUCE_THREADS / 64 waves: wave (cq = wave / 4, rg = wave % 4) sums the rows rg, rg + 4, ... (7 of
+// them) over the column part cq (all columns with 256 threads) -- lane l takes the columns l, l + 64,
+// ... in ascending order, four columns' loads in flight before the first add -- and reduces across
+// its lanes with wave_sum; with more than one part the parts of a row are joined in a fixed order.
+// Everyone who needs the 28 sums of a pair (the LM step, sicp_accumulate, the host-loop solve) goes
+// through this one routine, so they see the same bits.  Must be called by all REDUCE_THREADS threads
+// of the block; the result is valid for thread 0 after the call (s_part is block-shared scratch).
+#ifndef SICP_REDUCE_THREADS
+#define SICP_REDUCE_THREADS 256  // more threads leave lm_feed (312 VGPRs) too few registers: 512 -> spills
+#endif
+constexpr int REDUCE_THREADS = SICP_REDUCE_THREADS, REDUCE_PARTS = REDUCE_THREADS / 256;
+static_assert(REDUCE_PARTS == 1, "the column count need not divide");
+// COHERENT: the columns were written by other workgroups of the SAME launch with write-through (sc1) stores and are
+// read with agent-scope loads, which no cache of this CU / XCD can serve stale (the persistent solve's master).
+template <bool COHERENT = false>
+__device__ __forceinline__ void reduce_partials_block(const double* __restrict__ partials, int n, double (&s_part)[4][28], double (&o)[28]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, rg = wave & 3, cq = wave >> 2;
+  const int nq = n / REDUCE_PARTS, c0 = cq * nq, c1 = c0 + nq;
+  const double* __restrict__ base = partials + (size_t)rg * n;  // row rg + 4 r lives at base + 4 r n
+  double s[7];
+#pragma unroll
+  for (int r = 0; r < 7; ++r) s[r] = 0.0;
+  constexpr int DEEP = 4;  // column blocks in flight per trip (clamped loads past the end are issued too: keep it near n / 64)
+  for (int b0 = c0 + lane; b0 < c1; b0 += 64 * DEEP) {
+    double v[DEEP][7];
+#pragma unroll
+    for (int t = 0; t < DEEP; ++t) {
+      const int b = min(b0 + 64 * t, c1 - 1);  // clamped: loaded unconditionally, added only when in range
+#pragma unroll
+      for (int r = 0; r < 7; ++r)
+        v[t][r] = COHERENT ? coherent_load_f64((const SICP_GLOBAL double*)(base + (size_t)(4 * r) * n + b)) : __builtin_nontemporal_load(base + (size_t)(4 * r) * n + b);
+    }
+#pragma unroll
+    for (int t = 0; t < DEEP; ++t)
+      if (b0 + 64 * t < c1) {
+#pragma unroll
+        for (int r = 0; r < 7; ++r) s[r] += v[t][r];
+      }
+  }
+#pragma unroll
+  for (int r = 0; r < 7; ++r) {
+    const double sum = wave_sum(s[r]);
+    if (lane == 0) s_part[cq][rg + 4 * r] = sum;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < 28; ++k)
+      o[k] = REDUCE_PARTS == 4 ? (s_part[0][k] + s_part[1][k]) + (s_part[2][k] + s_part[3][k])
+           : REDUCE_PARTS == 2 ? s_part[0][k] + s_part[1][k] : s_part[0][k];
+  }
+}
+
+// ---- build-time experiment of round 6 (-DSICP_LM_STEP_IN_LAUNCH + SICP_LM_STEP_IN_LAUNCH=1 in the environment): the LM step
+// INSIDE the accumulate launch -- the workgroup that delivers a pair's last columns sums them all and advances the pair's
+// trust-region machine, the tick is [tick_prepare, accumulate x len] instead of [accumulate, lm_step_batch] x len.  Built,
+// bit-identical to the product (all GPU tests), and SLOWER everywhere: 256-pair stream step 184.2 against 183.1 ms, 16 full-size
+// pairs 59.5 against 48.9 ms per step, SE3-GICP 144 against 129 (profiles/r06/lm_step_in_launch_ab.json).  Every workgroup's range
+// is about half a pair, so every pair completes at the END of the launch and its step (reduce 44 KB + ~9 us of one lane) extends
+// the launch by what the separate kernel took; the drain + two barriers + one agent-scope add per segment and the 532 bytes of
+// scratch lm_feed's 310 registers cost the kernel come on top.  The step's kernel was never the loss it looked like in the
+// trace (55 us "present" per launch): while it waits for a SIMD the searches that share the chip make progress.
+// Not part of the product build.
+#if defined(SICP_LM_STEP_IN_LAUNCH)
+// One LM step of a pair from inside the accumulate launch (one lane).  Not inlined: lm_feed wants ~310 registers, the
+// accumulate kernel is compiled for two waves per SIMD (256), and this runs once per pair and evaluation -- whatever it
+// spills must stay out of the kernel's hot loop.
+__device__ __attribute__((noinline)) void lm_step_in_launch(LmState* lm, EvalIn* next, unsigned next_epoch, const double (&o)[28]) {
+  LmCore st = *lm;
+  lm_feed(st, lm->opt, o);
+  st.pending = 0;  // the arrival counter of the NEXT launch starts from zero
+  *static_cast<LmCore*>(lm) = st;
+#pragma unroll
+  for (int k = 0; k < 7; ++k) next->pose[k] = st.pose[k];
+  next->status = st.status;
+  next->epoch = next_epoch;
+}
+
+#endif
+
 template <int K, bool SQLOSS, int BS>
-__global__ __launch_bounds__(BS, SICP_ACC_OCC) void accumulate_staged_kernel(const BatchHeader* __restrict__ hdr, const BatchArgs* __restrict__ batch) {
+__global__ __launch_bounds__(BS, SICP_ACC_OCC) void accumulate_staged_kernel(const BatchHeader* __restrict__ hdr, const BatchArgs* __restrict__ batch, int node) {
   constexpr int SG = GroupShape<K>::SG, NS = GroupShape<K>::NS, NW = BS / 64;
   extern __shared__ __attribute__((aligned(16))) double smem[];  // ONE shared object: [reduction tiles | staging | logarithm table | per-pair walk state]
   __shared__ int total_running;
+#if defined(SICP_LM_STEP_IN_LAUNCH)
+  __shared__ int s_last;
+#endif
   __shared__ double comb[COMB_CHUNKS][NW][28];
+  static_assert(COMB_CHUNKS * NW >= 4 && BS == REDUCE_THREADS, "comb[] doubles as reduce_partials_block's scratch; the workgroup is its block");
   char* stage_all = reinterpret_cast<char*>(smem + NW * RED_ROWS * RED_STRIDE);
   char* log_tab = stage_all + NW * SG * STAGE_SLOT_BYTES;
   PairSlot* ctx = reinterpret_cast<PairSlot*>(log_tab + LOG_TABLE_BYTES);
   const int n_pairs = hdr->n_pairs;
   if (n_pairs <= 0) return;
+  // this launch's epoch (pairs whose LM machine is stepped inside the launch: AccArgs::ein, see EvalIn in kernels.h)
+  const unsigned epoch = (unsigned)uniform_i32((int)(hdr->epoch_base + (unsigned)node));
+  (void)epoch;
   for (int k = threadIdx.x; k < kLogTableEntries; k += BS) reinterpret_cast<v2d*>(log_tab)[k] = reinterpret_cast<const v2d*>(kLogTable)[k];
   for (int p = threadIdx.x; p < n_pairs; p += BS) {
     const AccArgs& a = batch[p].a;
     PairSlot c;
+#if defined(SICP_LM_STEP_IN_LAUNCH)
+    if (a.ein) {  // (never the state itself: another workgroup of this launch may already have stepped it)
+      const EvalIn& in = a.ein[epoch & 1u];
+      c.running = in.epoch == epoch && in.status == LM_RUNNING;
+    } else
+#endif
     c.running = a.lm ? a.lm->status == LM_RUNNING : 1;
     c.n_chunks = acc_geometry(a.n_s * a.K, SG).n_chunks;
     c.item_begin = 0;
@@ -669,6 +778,13 @@ __global__ __launch_bounds__(BS, SICP_ACC_OCC) void accumulate_staged_kernel(con
     MathCtx M;
     {
       Pose P;
+#if defined(SICP_LM_STEP_IN_LAUNCH)
+      if (a.ein) {
+        const double* q = a.ein[epoch & 1u].pose;
+        se3::rotation(q, P.R);
+        P.t[0] = q[4]; P.t[1] = q[5]; P.t[2] = q[6];
+      } else
+#endif
       if (a.lm) {
         se3::rotation(a.lm->pose, P.R);
         P.t[0] = a.lm->pose[4]; P.t[1] = a.lm->pose[5]; P.t[2] = a.lm->pose[6];
@@ -687,75 +803,38 @@ __global__ __launch_bounds__(BS, SICP_ACC_OCC) void accumulate_staged_kernel(con
 
     accumulate_segment<K, SQLOSS, BS>(L, M, chunk_lo, n_here, n_chunks, steps, uniform_i32(geo.chunk_groups), partials, stage, tile, comb, lane, wave);
     item += n_here;
+#if defined(SICP_LM_STEP_IN_LAUNCH)
+    // ---- the LM step, inside this launch: the workgroup that delivers a pair's LAST columns sums them all and advances the
+    // pair's trust-region machine (csrc/lm.hpp: the code lm_step_batch_kernel runs, in the order it runs it: the same bits)
+    // while the other workgroups are still evaluating other pairs -- no second launch per evaluation, and nothing waits for
+    // a 312-register block to find a SIMD between the search waves that share the chip with a tick.
+    // Hand-off (cdna_hip_programming.md recipe R1): the columns were stored write-through, every wave drains its stores,
+    // ONE agent-scope add on the pair's arrival counter (LmCore::pending) tells who is last; the last one reads the
+    // columns with agent-scope loads.  The stepped state goes to the pair's LmState (what the host reads back after the tick)
+    // and, as pose + status + epoch, to the OTHER EvalIn entry: the next launch's input, never this one's.
+    EvalIn* const ein = uniform_ptr(a.ein);
+    if (ein != nullptr) {
+      LmState* const lm = uniform_ptr(a.lm_step);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (threadIdx.x == 0) {
+        const int before = __hip_atomic_fetch_add(&lm->pending, n_here, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = before + n_here == n_chunks;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (s_last) {
+        double o[28];
+        reduce_partials_block<true>((const double*)partials, n_chunks, *reinterpret_cast<double (*)[4][28]>(&comb[0][0][0]), o);
+        if (threadIdx.x == 0) lm_step_in_launch(lm, ein + ((epoch + 1u) & 1u), epoch + 1u, o);
+        __syncthreads();  // (comb[] is the next segment's again)
+      }
+    }
+#endif
   }
 #ifdef SICP_DEV_PROBES
   }
 #endif
-}
-
-// Hand-offs between workgroups of one launch (the persistent solve): write-through stores and agent-scope loads of
-// at most 8 bytes -- visible across CUs and XCDs without a release / acquire fence (cdna_hip_programming.md
-// guideline 16, recipe R1: payload sc1 -> the storing wave drains -> one lane stores the flag).
-typedef unsigned long long u64;
-__device__ __forceinline__ void coherent_store_f64(SICP_GLOBAL double* p, double v) {
-  __hip_atomic_store((SICP_GLOBAL u64*)p, (u64)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ double coherent_load_f64(const SICP_GLOBAL double* p) {
-  return __longlong_as_double((long long)__hip_atomic_load((const SICP_GLOBAL u64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-
-// Fixed-order sum of the partial columns (layout [28][n]) by one workgroup of
-// REDUCE_THREADS / 64 waves: wave (cq = wave / 4, rg = wave % 4) sums the rows rg, rg + 4, ... (7 of
-// them) over the column part cq (all columns with 256 threads) -- lane l takes the columns l, l + 64,
-// ... in ascending order, four columns' loads in flight before the first add -- and reduces across
-// its lanes with wave_sum; with more than one part the parts of a row are joined in a fixed order.
-// Everyone who needs the 28 sums of a pair (the LM step, sicp_accumulate, the host-loop solve) goes
-// through this one routine, so they see the same bits.  Must be called by all REDUCE_THREADS threads
-// of the block; the result is valid for thread 0 after the call (s_part is block-shared scratch).
-#ifndef SICP_REDUCE_THREADS
-#define SICP_REDUCE_THREADS 256  // more threads leave lm_feed (312 VGPRs) too few registers: 512 -> spills
-#endif
-constexpr int REDUCE_THREADS = SICP_REDUCE_THREADS, REDUCE_PARTS = REDUCE_THREADS / 256;
-static_assert(REDUCE_PARTS == 1, "the column count need not divide");
-// COHERENT: the columns were written by other workgroups of the SAME launch with write-through (sc1) stores and are
-// read with agent-scope loads, which no cache of this CU / XCD can serve stale (the persistent solve's master).
-template <bool COHERENT = false>
-__device__ __forceinline__ void reduce_partials_block(const double* __restrict__ partials, int n, double (&s_part)[4][28], double (&o)[28]) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, rg = wave & 3, cq = wave >> 2;
-  const int nq = n / REDUCE_PARTS, c0 = cq * nq, c1 = c0 + nq;
-  const double* __restrict__ base = partials + (size_t)rg * n;  // row rg + 4 r lives at base + 4 r n
-  double s[7];
-#pragma unroll
-  for (int r = 0; r < 7; ++r) s[r] = 0.0;
-  constexpr int DEEP = 4;  // column blocks in flight per trip (clamped loads past the end are issued too: keep it near n / 64)
-  for (int b0 = c0 + lane; b0 < c1; b0 += 64 * DEEP) {
-    double v[DEEP][7];
-#pragma unroll
-    for (int t = 0; t < DEEP; ++t) {
-      const int b = min(b0 + 64 * t, c1 - 1);  // clamped: loaded unconditionally, added only when in range
-#pragma unroll
-      for (int r = 0; r < 7; ++r)
-        v[t][r] = COHERENT ? coherent_load_f64((const SICP_GLOBAL double*)(base + (size_t)(4 * r) * n + b)) : __builtin_nontemporal_load(base + (size_t)(4 * r) * n + b);
-    }
-#pragma unroll
-    for (int t = 0; t < DEEP; ++t)
-      if (b0 + 64 * t < c1) {
-#pragma unroll
-        for (int r = 0; r < 7; ++r) s[r] += v[t][r];
-      }
-  }
-#pragma unroll
-  for (int r = 0; r < 7; ++r) {
-    const double sum = wave_sum(s[r]);
-    if (lane == 0) s_part[cq][rg + 4 * r] = sum;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int k = 0; k < 28; ++k)
-      o[k] = REDUCE_PARTS == 4 ? (s_part[0][k] + s_part[1][k]) + (s_part[2][k] + s_part[3][k])
-           : REDUCE_PARTS == 2 ? s_part[0][k] + s_part[1][k] : s_part[0][k];
-  }
 }
 
 // device-resident solve: reduce the partial columns and advance the LM machine by one evaluation
@@ -1106,10 +1185,10 @@ static size_t stream_smem_bytes(int capacity, int K) {
   return sizeof(double) * 4 * RED_ROWS * RED_STRIDE + staging + LOG_TABLE_BYTES + sizeof(PairSlot) * (size_t)capacity;
 }
 
-hipError_t launch_accumulate_batch(int K, int use_sqloss, const BatchHeader* hdr, const BatchArgs* batch, int capacity, hipStream_t st) {
+hipError_t launch_accumulate_batch(int K, int use_sqloss, const BatchHeader* hdr, const BatchArgs* batch, int capacity, hipStream_t st, int node) {
   void* fn = accumulate_fn(K, use_sqloss);
   if (!fn) return hipErrorInvalidValue;
-  void* args[] = {(void*)&hdr, (void*)&batch};
+  void* args[] = {(void*)&hdr, (void*)&batch, (void*)&node};
   return hipLaunchKernel(fn, dim3(accumulate_grid()), dim3(256), args, stream_smem_bytes(capacity, K), st);
 }
 
@@ -1154,6 +1233,35 @@ hipError_t launch_lm_step_batch(const BatchHeader* hdr, const BatchArgs* batch, 
   return hipGetLastError();
 }
 
+// First kernel of a tick whose accumulate launches step the LM machines themselves: a new epoch range for the tick, and every
+// pair's pose / status -- from its LmState, whoever wrote it last: lm_init_kernel for a pair that joins, the previous tick's
+// last step, a persistent solve that gave up -- as the input of the tick's first evaluation.  ONE workgroup (it owns the
+// header word it advances).
+__global__ __launch_bounds__(256) void tick_prepare_kernel(BatchHeader* __restrict__ hdr, const BatchArgs* __restrict__ batch) {
+  __shared__ unsigned s_epoch;
+  if (threadIdx.x == 0) {
+    s_epoch = hdr->epoch_base + (unsigned)kMaxBatchLen;  // (an even stride: a tick's first evaluation always has the same parity)
+    hdr->epoch_base = s_epoch;
+  }
+  __syncthreads();
+  const unsigned e0 = s_epoch;
+  for (int p = threadIdx.x; p < hdr->n_pairs; p += blockDim.x) {
+    const AccArgs& a = batch[p].a;
+    if (!a.ein || !a.lm_step) continue;
+    EvalIn& in = a.ein[e0 & 1u];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) in.pose[k] = a.lm_step->pose[k];
+    in.status = a.lm_step->status;
+    in.epoch = e0;
+    a.lm_step->pending = 0;
+  }
+}
+
+hipError_t launch_tick_prepare(BatchHeader* hdr, const BatchArgs* batch, hipStream_t st) {
+  hipLaunchKernelGGL(tick_prepare_kernel, dim3(1), dim3(256), 0, st, hdr, batch);
+  return hipGetLastError();
+}
+
 __global__ __launch_bounds__(64) void lm_init_kernel(const LmJoin* __restrict__ joins, int n, LmState* __restrict__ states) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
@@ -1186,13 +1294,15 @@ void batch_graph_destroy(BatchGraph& g) {
 }
 
 hipError_t batch_graph_prepare(BatchGraph& g, int K, int use_sqloss, const BatchHeader* hdr, const BatchArgs* batch, int capacity, int len,
-                               int* built) {
+                               int* built, int fold) {
   *built = 0;
   void* fn = accumulate_fn(K, use_sqloss);
   if (capacity <= 0 || len < 1 || len > kMaxBatchLen || !fn) return hipErrorInvalidValue;
-  if (g.exec && g.K == K && g.sqloss == use_sqloss && g.len == len && g.batch == batch && g.hdr == hdr && g.capacity == capacity) return hipSuccess;
+  if (g.exec && g.K == K && g.sqloss == use_sqloss && g.len == len && g.batch == batch && g.hdr == hdr && g.capacity == capacity && g.fold == fold)
+    return hipSuccess;
   batch_graph_destroy(g);
-  void* args[] = {(void*)&hdr, (void*)&batch};
+  int node = 0;
+  void* args[] = {(void*)&hdr, (void*)&batch, (void*)&node};  // (kernel parameters are copied when a node is added)
   hipKernelNodeParams pa, ps;
   memset(&pa, 0, sizeof pa);
   pa.func = fn;
@@ -1201,23 +1311,32 @@ hipError_t batch_graph_prepare(BatchGraph& g, int K, int use_sqloss, const Batch
   pa.sharedMemBytes = (unsigned)stream_smem_bytes(capacity, K);
   pa.kernelParams = args;
   memset(&ps, 0, sizeof ps);
-  ps.func = (void*)lm_step_batch_kernel;
-  ps.gridDim = dim3(capacity);
-  ps.blockDim = dim3(REDUCE_THREADS);
+  ps.func = fold ? (void*)tick_prepare_kernel : (void*)lm_step_batch_kernel;
+  ps.gridDim = dim3(fold ? 1 : capacity);
+  ps.blockDim = dim3(fold ? 256 : REDUCE_THREADS);
   ps.kernelParams = args;
   hipError_t e = hipGraphCreate(&g.graph, 0);
   if (e != hipSuccess) return e;
   hipGraphNode_t prev = nullptr, acc = nullptr, step = nullptr;
-  for (int b = 0; b < len; ++b) {
-    e = hipGraphAddKernelNode(&acc, g.graph, prev ? &prev : nullptr, prev ? 1 : 0, &pa);
-    if (e != hipSuccess) return e;
-    e = hipGraphAddKernelNode(&step, g.graph, &acc, 1, &ps);
+  if (fold) {  // [tick_prepare, accumulate x len]: the accumulate launches step the machines themselves
+    e = hipGraphAddKernelNode(&step, g.graph, nullptr, 0, &ps);
     if (e != hipSuccess) return e;
     prev = step;
   }
+  for (int b = 0; b < len; ++b) {
+    node = b;
+    e = hipGraphAddKernelNode(&acc, g.graph, prev ? &prev : nullptr, prev ? 1 : 0, &pa);
+    if (e != hipSuccess) return e;
+    prev = acc;
+    if (!fold) {
+      e = hipGraphAddKernelNode(&step, g.graph, &acc, 1, &ps);
+      if (e != hipSuccess) return e;
+      prev = step;
+    }
+  }
   e = hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0);
   if (e != hipSuccess) return e;
-  g.K = K; g.sqloss = use_sqloss; g.len = len; g.batch = batch; g.hdr = hdr; g.capacity = capacity;
+  g.K = K; g.sqloss = use_sqloss; g.len = len; g.batch = batch; g.hdr = hdr; g.capacity = capacity; g.fold = fold;
   *built = 1;
   return hipSuccess;
 }

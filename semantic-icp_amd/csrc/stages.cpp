@@ -422,7 +422,7 @@ int eval28(sicp_context* h, const double* qt, double* out28) {
   fill_acc(h, B.a);
   fill_pose(qt, B.a.pose);
   B.nb = nb;
-  *h->ts[0].h_bhdr = sicp::BatchHeader{1, {0, 0, 0}};
+  *h->ts[0].h_bhdr = sicp::BatchHeader{1, h->ts[0].epoch_host, {0, 0}};
   HIPCHECK(hipMemcpyAsync(h->ts[0].d_bhdr.p, h->ts[0].h_bhdr, sizeof(sicp::BatchHeader), hipMemcpyHostToDevice, h->stream));
   HIPCHECK(hipMemcpyAsync(h->ts[0].d_batch.p, h->ts[0].h_batch, sizeof(sicp::BatchArgs), hipMemcpyHostToDevice, h->stream));
   {
