@@ -81,6 +81,43 @@ int sicp_default_params(int mode, sicp_params* p) {
   });
 }
 
+// Handles are recycled like clouds: sicp_destroy parks a handle -- streams, events, pinned mirrors, device buffers, tick
+// graphs and all -- in a per-device pool and sicp_create hands it out again, reset to what a new handle is.  The
+// reference's drivers construct their registration objects PER PAIR (exec/kitti_eval.cc:176,198, exec/nyu_eval.cc:140,183), and a
+// handle made from nothing costs ~4 ms to create, ~5 ms of first-use allocations inside its first align() and ~9 ms to
+// destroy (every device buffer given back waits for the device): 49.6 ms per KITTI pair through the class shims against
+// ~2 ms of align() (profiles/r06/dropin_calls_before.json).  sicp_release_pool frees the parked handles too.
+namespace {
+struct HandlePool {
+  std::mutex m;
+  std::vector<sicp_context*> parked[sicp::host::kPoolDevices];
+};
+HandlePool& handle_pool() {
+  static HandlePool* p = new HandlePool;  // never destroyed: it may outlive the HIP runtime at process exit
+  return *p;
+}
+constexpr size_t kHandlePoolCap = 32;  // per device (a parked handle keeps its buffers: ~12 MB at 100K x 4 slots)
+
+// what a new handle is, for one that has been used
+void reset_handle(sicp_context* h) {
+  h->collect = nullptr;
+  sicp_default_params(SICP_MODE_GICP, &h->params);
+  h->epoch = 0;
+  h->C = 0; h->cm.clear(); h->cm_id = 0;
+  h->corr_n = h->corr_K = 0;
+  h->corr_valid = h->corr_weighted = h->hint_ok = false;
+  for (TickSet& S : h->ts) { S.tick_valid = false; S.tick_act.clear(); }
+  h->solo_skip = h->solo_penalty = 0;
+  h->solo_was_init = h->solo_failed = false;
+  h->count_stats = h->counted_in_search = false;
+  h->wait_on_device = false;
+  h->last_error.clear();
+  std::memset(&h->st, 0, sizeof h->st);
+}
+
+int destroy_for_real(sicp_context* h);
+}  // namespace
+
 int sicp_create(int device_id, sicp_handle* out) {
   return abi_guard([&]() -> int {
     if (!out) return SICP_ERR_INVALID_ARGUMENT;
@@ -88,6 +125,22 @@ int sicp_create(int device_id, sicp_handle* out) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return SICP_ERR_NO_DEVICE;
     if (device_id < 0 || device_id >= n) return SICP_ERR_INVALID_ARGUMENT;
+    {
+      HandlePool& pool = handle_pool();
+      sicp_context* h = nullptr;
+      {
+        std::lock_guard<std::mutex> lock(pool.m);
+        auto& v = pool.parked[device_id % kPoolDevices];
+        for (size_t i = v.size(); i-- > 0;)
+          if (v[i]->device == device_id) { h = v[i]; v.erase(v.begin() + (long)i); break; }
+      }
+      if (h) {
+        h->cl[0] = acquire_cloud(device_id);
+        h->cl[1] = acquire_cloud(device_id);
+        *out = h;
+        return SICP_OK;
+      }
+    }
     sicp_context* h = new (std::nothrow) sicp_context();
     if (!h) return SICP_ERR_OUT_OF_MEMORY;
     h->device = device_id;
@@ -104,7 +157,7 @@ int sicp_create(int device_id, sicp_handle* out) {
               hipHostMalloc((void**)&h->h_count, sizeof(long long) * sicp::kLiveCounters, hipHostMallocDefault) == hipSuccess &&
               hipHostMalloc((void**)&h->h_lm, sizeof(sicp::LmState), hipHostMallocDefault) == hipSuccess;
     if (!ok) {
-      sicp_destroy(h);
+      destroy_for_real(h);
       return SICP_ERR_NO_DEVICE;
     }
     *out = h;
@@ -115,6 +168,31 @@ int sicp_create(int device_id, sicp_handle* out) {
 int sicp_destroy(sicp_handle h) {
   return abi_guard(h, [&]() -> int {
     if (!h) return SICP_OK;
+    // park it: everything it queued has ended, its clouds go back to their pool (or stay with whoever shares them), and
+    // what remains is a handle as sicp_create makes them -- with its streams, mirrors, buffers and graphs in place
+    static const bool no_pool = std::getenv("SICP_NO_HANDLE_POOL") != nullptr;  // A/B aid
+    bool clean = !no_pool && h->stream && h->stream2 && hipSetDevice(h->device) == hipSuccess && hipStreamSynchronize(h->stream) == hipSuccess &&
+                 hipStreamSynchronize(h->stream2) == hipSuccess;
+    if (clean && h->side_stream) clean = hipStreamSynchronize(h->side_stream) == hipSuccess;
+    if (clean && h->feat_stream) clean = hipStreamSynchronize(h->feat_stream) == hipSuccess;
+    for (int s2 = 1; clean && s2 < kParts; ++s2)
+      if (h->part_stream[s2]) clean = hipStreamSynchronize(h->part_stream[s2]) == hipSuccess;
+    if (clean) {
+      for (auto& c : h->cl)
+        if (c) { settle_cloud(*c); c.reset(); }
+      reset_handle(h);
+      HandlePool& pool = handle_pool();
+      std::lock_guard<std::mutex> lock(pool.m);
+      auto& v = pool.parked[h->device % kPoolDevices];
+      if (v.size() < kHandlePoolCap) { v.push_back(h); return SICP_OK; }
+    }
+    return destroy_for_real(h);
+  });
+}
+
+namespace {
+int destroy_for_real(sicp_context* h) {
+  {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto& c : h->cl)
@@ -152,8 +230,9 @@ int sicp_destroy(sicp_handle h) {
       delete h;
     }
     return SICP_OK;
-  });
+  }
 }
+}  // namespace
 
 int sicp_release_pool(int device_id) {
   return abi_guard([&]() -> int {
@@ -167,6 +246,17 @@ int sicp_release_pool(int device_id) {
       dead.swap(pool.free_list[device_id % kPoolDevices]);
     }
     if (hipSetDevice(device_id) != hipSuccess) return SICP_ERR_NO_DEVICE;
+    {  // the parked handles of this device (their buffers are part of what the pool holds)
+      std::vector<sicp_context*> idle;
+      {
+        HandlePool& hp = handle_pool();
+        std::lock_guard<std::mutex> lock(hp.m);
+        auto& v = hp.parked[device_id % kPoolDevices];
+        for (size_t i = v.size(); i-- > 0;)
+          if (v[i]->device == device_id) { idle.push_back(v[i]); v.erase(v.begin() + (long)i); }
+      }
+      for (sicp_context* g : idle) (void)destroy_for_real(g);
+    }
     for (Cloud* c : dead) delete c;
     (void)hipDeviceSynchronize();   // nothing may still be running out of a block that goes back to the driver
     dev_arena().release(device_id);  // the slabs no live buffer is carved from

@@ -34,16 +34,20 @@ class SemanticIterativeClosestPoint {
     align(finalCloud, init);
   }
 
-  void align(SemanticCloudPtr finalCloud, Sophus::SE3d& initTransform) {  // impl/semantic_icp.hpp:27-166
+  // impl/semantic_icp.hpp:27-166.  The two clouds are registered where they already are: each SemanticPointCloud keeps its
+  // label clouds on the GPU (uploaded at its first use) and this handle refers to them (sicp_share_cloud) -- nothing is
+  // flattened, uploaded or indexed again per align(), and the per-label covariances are the ones computed once per cloud
+  // (reuse_features; impl/semantic_icp.hpp:73,77 read them out of the cloud objects the same way).
+  void align(SemanticCloudPtr finalCloud, Sophus::SE3d& initTransform) {
     sicp_handle h = engine_.get();
     sicp_params p;
     detail::check(sicp_default_params(SICP_MODE_SEMANTIC, &p), h, "sicp_default_params");
     p.k_cov = sourceCloud_->getK();
     p.epsilon = sourceCloud_->getEpsilon();
+    p.reuse_features = 1;
     detail::check(sicp_set_params(h, &p), h, "sicp_set_params");
-    detail::FlatCloud s = flatten(*sourceCloud_), t = flatten(*targetCloud_);
-    detail::check(sicp_set_cloud(h, SICP_SOURCE, s.size(), s.x.data(), s.y.data(), s.z.data(), s.label.data()), h, "sicp_set_cloud");
-    detail::check(sicp_set_cloud(h, SICP_TARGET, t.size(), t.x.data(), t.y.data(), t.z.data(), t.label.data()), h, "sicp_set_cloud");
+    detail::check(sicp_share_cloud(h, SICP_SOURCE, sourceCloud_->device(), SICP_SOURCE), h, "sicp_share_cloud");
+    detail::check(sicp_share_cloud(h, SICP_TARGET, targetCloud_->device(), SICP_SOURCE), h, "sicp_share_cloud");
     double out[7];
     detail::check(sicp_align(h, initTransform.data(), out, nullptr, nullptr), h, "sicp_align");
     finalTransformation_ = detail::to_se3(out);
@@ -54,14 +58,6 @@ class SemanticIterativeClosestPoint {
   Sophus::SE3d getFinalTransFormation() { return finalTransformation_; }  // (sic) semantic_icp.h:58-62
 
  protected:
-  // label clouds concatenated in semanticLabels order == the order the reference iterates them
-  static detail::FlatCloud flatten(SemanticCloud& c) {
-    detail::FlatCloud f;
-    for (SemanticT s : c.semanticLabels)
-      for (const PointT& p : *(c.labeledPointClouds[s])) f.push(p.x, p.y, p.z, (uint32_t)s);
-    return f;
-  }
-
   Sophus::SE3d finalTransformation_;
   SemanticCloudPtr sourceCloud_, targetCloud_;
   detail::Engine engine_;
