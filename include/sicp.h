@@ -321,6 +321,20 @@ int sicp_stream_counters(sicp_stream s, int64_t* submitted, int64_t* completed, 
                          int64_t* slot_evals);
 const char* sicp_stream_last_error(sicp_stream s);
 
+/* Caller-supplied per-point covariances, where the reference reads them instead of computing them:
+ * SemanticIterativeClosestPoint::align takes whatever sits in the public `labeledCovariances` of its two clouds
+ * (impl/semantic_icp.hpp:73,77; semantic_point_cloud.h:36-42: addSemanticCloud(..., computeKd, computeCov = false) leaves
+ * them to the caller), and GICP::setSourceCloud(cloud, tree, covs) / setTargetCloud(cloud, tree, covs) (gicp.h:50-55, 65-70)
+ * accept arbitrary vectors (GICP::align and EmIterativeClosestPoint::align then overwrite them, impl/gicp.hpp:33-34,
+ * impl/em_icp.hpp:28-29 -- which is what this engine does too unless reuse_features is set).
+ * cov9: n_points x 9 row-major 3x3 matrices in the caller's point order.  The engine evaluates covariances of the form the
+ * reference's own routine produces, C = I - (1 - epsilon) n n^T (a unit normal n; epsilon = params.epsilon), and keeps the
+ * normal: a matrix that is not of that form (to 1e-8) is REFUSED -- SICP_ERR_INVALID_ARGUMENT, sicp_last_error names the
+ * first offending point -- never silently replaced.  Accepted covariances count as the cloud's current features for
+ * SICP_MODE_SEMANTIC, and for SICP_MODE_GICP with reuse_features = 1; SICP_MODE_EM also needs the label histograms of
+ * the neighbourhoods and recomputes.  Entries of non-finite points (which never reach the device) are ignored. */
+int sicp_set_covariances(sicp_handle h, int which, const double* cov9);
+
 /* the final_cloud output of align (em_icp.hpp:192-198): source transformed by
  * float(matrix(qt)); ox/oy/oz are host buffers of n_source floats */
 int sicp_transform_source(sicp_handle h, const double qt[7], float* ox, float* oy, float* oz);

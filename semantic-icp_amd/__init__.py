@@ -176,6 +176,7 @@ def lib():
             "sicp_transform_source": [C.c_void_p, _dp, _fp, _fp, _fp],
             "sicp_fused_labels": [C.c_void_p, _dp, _up],
             "sicp_covariances": [C.c_void_p, C.c_int, _dp, _dp, _bp, _ip],
+            "sicp_set_covariances": [C.c_void_p, C.c_int, _dp],
             "sicp_correspondences": [C.c_void_p, _dp, _ip, _fp, _dp],
             "sicp_accumulate": [C.c_void_p, _dp, _dp],
             "sicp_solve": [C.c_void_p, _dp, _dp, _ip, _ip, _dp],
@@ -375,6 +376,11 @@ class Engine:
         nn = np.empty((n, p.k_cov), dtype=np.int32) if want_nn else None
         self._check(lib().sicp_covariances(self._h, which, _ptr(cov, _dp), _ptr(nrm, _dp), _ptr(hist, _bp), _ptr(nn, _ip)), "sicp_covariances")
         return cov, nrm, hist, nn
+
+    def set_covariances(self, which: int, cov9):
+        """caller-supplied covariances (n x 3 x 3 or n x 9, the caller's point order); SicpError when one is not I - (1-eps) n n^T"""
+        c = np.ascontiguousarray(np.asarray(cov9, dtype=np.float64).reshape(-1, 9))
+        self._check(lib().sicp_set_covariances(self._h, which, _ptr(c, _dp)), "sicp_set_covariances")
 
     def correspondences(self, qt):
         qt = np.ascontiguousarray(qt, dtype=np.float64)

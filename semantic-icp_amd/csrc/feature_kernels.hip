@@ -451,6 +451,34 @@ hipError_t launch_cov(const CovArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 
+// sicp_set_covariances: the records of a cloud whose normals the caller supplied (device order), written like cov_body's
+__global__ __launch_bounds__(256) void set_normals_kernel(int n, const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
+                                                          const double* __restrict__ normal3, PointRec* __restrict__ rec, char* __restrict__ rec_dense,
+                                                          int rec_dense_n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  PointRec r;
+  r.x = x[i]; r.y = y[i]; r.z = z[i];
+  r.nx = normal3[3 * (size_t)i]; r.ny = normal3[3 * (size_t)i + 1]; r.nz = normal3[3 * (size_t)i + 2];
+  r.pad_[0] = r.pad_[1] = r.pad_[2] = 0u;
+  rec[i] = r;
+  if (rec_dense) {
+    typedef double dense_v2d __attribute__((ext_vector_type(2)));
+    const size_t m = (size_t)rec_dense_n;
+    const char* src = reinterpret_cast<const char*>(&r);
+    *reinterpret_cast<dense_v2d*>(rec_dense + 16 * (size_t)i) = *reinterpret_cast<const dense_v2d*>(src);
+    *reinterpret_cast<dense_v2d*>(rec_dense + 16 * m + 16 * (size_t)i) = *reinterpret_cast<const dense_v2d*>(src + 16);
+    *reinterpret_cast<float*>(rec_dense + 32 * m + 4 * (size_t)i) = r.z;
+  }
+}
+
+hipError_t launch_set_normals(int n, const float* x, const float* y, const float* z, const double* normal3, PointRec* rec, char* rec_dense,
+                              int rec_dense_n, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(set_normals_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, x, y, z, normal3, rec, rec_dense, rec_dense_n);
+  return hipGetLastError();
+}
+
 hipError_t launch_proj(const ProjArgs& a, hipStream_t st) {
   const int total = a.n * a.C;
   if (total <= 0) return hipSuccess;

@@ -275,6 +275,9 @@ hipError_t launch_bvh_knn_quad(int K, const KnnArgs& a, hipStream_t st);
 hipError_t launch_bvh_knn_packet(int K, const KnnArgs& a, hipStream_t st);
 hipError_t launch_cov(const CovArgs& a, hipStream_t st);
 hipError_t launch_proj(const ProjArgs& a, hipStream_t st);
+// caller-supplied normals (sicp_set_covariances): the point records and their dense copy, as cov_kernel writes them
+hipError_t launch_set_normals(int n, const float* x, const float* y, const float* z, const double* normal3, PointRec* rec, char* rec_dense,
+                              int rec_dense_n, hipStream_t st);
 hipError_t launch_em_weight(const WeightArgs& a, hipStream_t st);
 hipError_t launch_fused_labels(const WeightArgs& a, uint32_t* out, hipStream_t st);
 hipError_t launch_bvh_knn_packet_jobs(int K, const KnnArgs* jobs, int n, hipStream_t st);

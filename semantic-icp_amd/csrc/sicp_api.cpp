@@ -588,6 +588,77 @@ int sicp_transform_source(sicp_handle h, const double qt[7], float* ox, float* o
   });
 }
 
+int sicp_set_covariances(sicp_handle h, int which, const double* cov9) {
+  return abi_guard(h, [&]() -> int {
+    if (!h || !cov9 || (which != SICP_SOURCE && which != SICP_TARGET)) return SICP_ERR_INVALID_ARGUMENT;
+    SICPCHECK(set_device(h));
+    const sicp_params& P = h->params;
+    Cloud& c = h->cloud(which);
+    if (!c.is_set) return SICP_ERR_NOT_READY;
+    SICPCHECK(prepare_cloud(h, c));
+    SICPCHECK(cloud_wait(h, c));  // (perm is read below)
+    const double kappa = 1.0 - P.epsilon;
+    if (!(kappa > 0.0)) { h->last_error = "sicp_set_covariances: params.epsilon must be below 1"; return SICP_ERR_INVALID_ARGUMENT; }
+    const int n = c.n;
+    std::vector<double> nrm((size_t)(n > 0 ? n : 1) * 3);
+    // C = I - kappa n n^T  <=>  (I - C) / kappa = n n^T: symmetric, rank one, trace one.  The normal is the column with the
+    // largest diagonal entry, scaled; what is left after taking n n^T away is the distance from the form.
+    constexpr double tol = 1e-8;
+    for (int d = 0; d < n; ++d) {
+      const int ci = c.caller_index(d);
+      const double* C9 = cov9 + (size_t)ci * 9;
+      double M[3][3];
+      bool ok = true;
+      for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) {
+          M[a][b] = ((a == b ? 1.0 : 0.0) - C9[3 * a + b]) / kappa;
+          ok = ok && std::isfinite(M[a][b]);
+        }
+      int col = 0;
+      if (M[1][1] > M[col][col]) col = 1;
+      if (M[2][2] > M[col][col]) col = 2;
+      double nv[3] = {0, 0, 0};
+      if (ok && M[col][col] > 0.0) {
+        const double s = 1.0 / std::sqrt(M[col][col]);
+        for (int a = 0; a < 3; ++a) nv[a] = M[a][col] * s;
+        const double len = std::sqrt(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]);
+        ok = std::fabs(len - 1.0) <= tol;
+        for (int a = 0; a < 3 && ok; ++a)
+          for (int b = 0; b < 3; ++b) ok = ok && std::fabs(M[a][b] - nv[a] * nv[b]) <= tol && std::fabs(C9[3 * a + b] - C9[3 * b + a]) <= tol;
+        if (ok) for (int a = 0; a < 3; ++a) nv[a] /= len;
+      } else {
+        ok = false;
+      }
+      if (!ok) {
+        char msg[256];
+        std::snprintf(msg, sizeof msg, "sicp_set_covariances: the covariance of point %d is not I - (1 - epsilon) n n^T with a unit n and epsilon = %g "
+                                       "(the form impl/semantic_point_cloud.hpp:25-84 produces and this engine evaluates); nothing was changed", ci, P.epsilon);
+        h->last_error = msg;
+        return SICP_ERR_INVALID_ARGUMENT;
+      }
+      nrm[3 * (size_t)d] = nv[0]; nrm[3 * (size_t)d + 1] = nv[1]; nrm[3 * (size_t)d + 2] = nv[2];
+    }
+    const size_t m = (size_t)(n > 0 ? n : 1);
+    HIPCHECK(c.rec.reserve(m));
+    HIPCHECK(c.rec_dense.reserve(sicp::dense_rec_bytes(n)));
+    DevBuf<double> d_nrm;
+    HIPCHECK(d_nrm.reserve(m * 3));
+    if (n == 0) HIPCHECK(hipMemsetAsync(c.rec.p, 0, sizeof(sicp::PointRec), h->stream));  // (compute_features: the record dead slots are evaluated on)
+    if (n > 0) HIPCHECK(hipMemcpyAsync(d_nrm.p, nrm.data(), sizeof(double) * 3 * n, hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(sicp::launch_set_normals(n, c.x.p, c.y.p, c.z.p, d_nrm.p, c.rec.p, c.rec_dense.p, n, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));  // (nrm / d_nrm go out of scope)
+    c.rec_dense_n = n;
+    c.feat_valid = true;
+    c.proj_valid = false;
+    c.feat_k = P.k_cov; c.feat_C = 0;
+    c.feat_float_products = P.quirk_float_products;
+    c.feat_hist = false;
+    c.feat_epoch = h->epoch;
+    h->corr_valid = false;
+    return SICP_OK;
+  });
+}
+
 int sicp_covariances(sicp_handle h, int which, double* cov9, double* normal3, uint8_t* hist, int32_t* nn_idx) {
   return abi_guard(h, [&]() -> int {
     if (!h || (which != SICP_SOURCE && which != SICP_TARGET)) return SICP_ERR_INVALID_ARGUMENT;

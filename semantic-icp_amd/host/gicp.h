@@ -35,6 +35,7 @@ class GICP {
   // the next align() the getters hand back exactly what the reference would (a fresh empty vector, or
   // the caller's own), never the previous cloud's values.
   inline void setSourceCloud(const PointCloudPtr& cloud) {
+    source_cov_supplied_ = false;
     sourceCloud_ = cloud;
     sourceKdTree_ = KdTreePtr(new KdTree());
     sourceKdTree_->setInputCloud(sourceCloud_);
@@ -44,8 +45,10 @@ class GICP {
   inline void setSourceCloud(const PointCloudPtr& cloud, const KdTreePtr& tree, const MatricesVectorPtr& covs) {
     sourceCloud_ = cloud; sourceKdTree_ = tree; sourceCovariances_ = covs;
     source_cov_stale_ = false;
+    source_cov_supplied_ = covs && cloud && !covs->empty() && covs->size() == cloud->size();
   }
   inline void setTargetCloud(const PointCloudPtr& cloud) {
+    target_cov_supplied_ = false;
     shared_target_from_ = nullptr;
     targetCloud_ = cloud;
     targetKdTree_ = KdTreePtr(new KdTree());
@@ -57,6 +60,7 @@ class GICP {
     shared_target_from_ = nullptr;
     targetCloud_ = cloud; targetKdTree_ = tree; targetCovariances_ = covs;
     target_cov_stale_ = false;
+    target_cov_supplied_ = covs && cloud && !covs->empty() && covs->size() == cloud->size();
   }
   // Engine extensions for scan sequences: the target of this registration is the source cloud of
   // `other` as it lives on the GPU after other's align() (one upload, tree and covariance set per scan;
@@ -150,6 +154,18 @@ class GICP {
       detail::check(sicp_share_cloud(h, SICP_TARGET, shared_target_from_->engine_.get(), SICP_SOURCE), h, "sicp_share_cloud");
     detail::check(detail::set_cloud(h, SICP_SOURCE, *sourceCloud_, false), h, "sicp_set_cloud_strided");
     if (!shared_target_from_) detail::check(detail::set_cloud(h, SICP_TARGET, *targetCloud_, false), h, "sicp_set_cloud_strided");
+    // The covariances of the 3-argument setters.  The reference's align() overwrites them (impl/gicp.hpp:33-34), and so does
+    // this engine -- unless keepFeatures(true) asked for a cloud's covariances to be kept across align() calls: then the
+    // caller's are the ones kept, and a matrix the engine cannot take (not I - (1 - epsilon) n n^T) is refused loudly.
+    if (reuse_features_ && source_cov_supplied_) push_covariances(h, SICP_SOURCE, *sourceCovariances_);
+    if (reuse_features_ && target_cov_supplied_ && !shared_target_from_) push_covariances(h, SICP_TARGET, *targetCovariances_);
+  }
+  static void push_covariances(sicp_handle h, int which, const MatricesVector& v) {
+    std::vector<double> c9(v.size() * 9);
+    for (size_t i = 0; i < v.size(); ++i)
+      for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) c9[i * 9 + 3 * a + b] = v[i](a, b);
+    detail::check(sicp_set_covariances(h, which, c9.data()), h, "sicp_set_covariances");
   }
 
   // what align() computed on the GPU (normals -> C = I - (1-eps) n n^T), copied out once per align
@@ -175,6 +191,7 @@ class GICP {
   double epsilon_;
   int outer_iter;
   bool source_cov_stale_ = false, target_cov_stale_ = false;
+  bool source_cov_supplied_ = false, target_cov_supplied_ = false;  // the 3-argument setters handed over one matrix per point
   bool reuse_features_ = false;
   GICP* shared_target_from_ = nullptr;
   Sophus::SE3d finalTransformation_;

@@ -76,7 +76,9 @@ class SemanticPointCloud {
     tree->setInputCloud(cloud_ptr);
     labeledKdTrees[label] = tree;
     if (!computeCov) return;
-    static_cast<std::map<SemanticT, MatricesVectorPtr>&>(labeledCovariances)[label] = MatricesVectorPtr(new MatricesVector());
+    MatricesVectorPtr mine(new MatricesVector());
+    static_cast<std::map<SemanticT, MatricesVectorPtr>&>(labeledCovariances)[label] = mine;
+    ours_[label] = mine.get();
     owed_.insert(label);
   }
 
@@ -90,6 +92,7 @@ class SemanticPointCloud {
       labeledCovariances.erase(label);
       labeledKdTrees.erase(label);
       owed_.erase(label);
+      ours_.erase(label);
       device_ = NONE;
     }
   }
@@ -125,6 +128,10 @@ class SemanticPointCloud {
     if (device_ != CURRENT) {
       if (device_ == PRE_TRANSFORM) materialise_covariances();
       upload();
+    } else {
+      int32_t n = 0;
+      detail::check(sicp_cloud_size(engine_.get(), SICP_SOURCE, &n, nullptr), engine_.get(), "sicp_cloud_size");
+      push_supplied_covariances(engine_.get(), n);  // (a vector the caller assigned since the upload)
     }
     return engine_.get();
   }
@@ -146,6 +153,46 @@ class SemanticPointCloud {
       for (const PointT& q : *(labeledPointClouds[s])) f.push(q.x, q.y, q.z, (uint32_t)s);
     detail::check(sicp_set_cloud(h, SICP_SOURCE, f.size(), f.x.data(), f.y.data(), f.z.data(), f.label.data()), h, "sicp_set_cloud");
     device_ = CURRENT;
+    pushed_.clear();
+    push_supplied_covariances(h, f.size());
+  }
+
+  // impl/semantic_icp.hpp:73,77 registers with whatever sits in labeledCovariances.  A vector that is not the one this class
+  // made for its label -- the caller assigned its own, or filled the entry of a label added with computeCov = false -- is
+  // handed to the engine (sicp_set_covariances), which takes covariances of the form I - (1 - epsilon) n n^T and REFUSES
+  // anything else: check() throws, nothing is silently replaced.  (Matrices edited in place inside a vector this class made
+  // are not seen: assign a vector.)
+  void push_supplied_covariances(sicp_handle h, int n) {
+    std::map<SemanticT, MatricesVectorPtr>& plain = labeledCovariances;
+    bool any = false;
+    for (SemanticT s : semanticLabels) {
+      auto it = plain.find(s);
+      if (it == plain.end() || !it->second || owed_.count(s)) continue;
+      auto mine = ours_.find(s);
+      const bool foreign = mine == ours_.end() || mine->second != it->second.get();
+      auto sent = pushed_.find(s);
+      if (foreign && (sent == pushed_.end() || sent->second != it->second.get())) any = true;  // not handed over yet
+    }
+    if (!any || n == 0) return;
+    std::vector<double> c9((size_t)n * 9);
+    std::vector<std::pair<SemanticT, const MatricesVector*>> sent_now;
+    detail::check(sicp_covariances(h, SICP_SOURCE, c9.data(), nullptr, nullptr, nullptr), h, "sicp_covariances");  // the labels that are the engine's own
+    size_t at = 0;
+    for (SemanticT s : semanticLabels) {
+      const size_t m = labeledPointClouds[s]->size();
+      auto it = plain.find(s);
+      auto mine = ours_.find(s);
+      if (it != plain.end() && it->second && !owed_.count(s) && (mine == ours_.end() || mine->second != it->second.get())) {
+        if (it->second->size() != m) throw std::runtime_error("SemanticPointCloud: labeledCovariances of a label does not have one matrix per point");
+        for (size_t i = 0; i < m; ++i)
+          for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) c9[(at + i) * 9 + 3 * a + b] = (*it->second)[i](a, b);
+        sent_now.push_back(std::make_pair(s, (const MatricesVector*)it->second.get()));
+      }
+      at += m;
+    }
+    detail::check(sicp_set_covariances(h, SICP_SOURCE, c9.data()), h, "sicp_set_covariances");  // (throws: a refused vector is offered again next time)
+    for (const auto& e : sent_now) pushed_[e.first] = e.second;
   }
 
   // labeledCovariances[label] for every label that still owes them: one read-back of what the GPU computed per segment
@@ -179,6 +226,8 @@ class SemanticPointCloud {
   enum DeviceCopy { NONE, CURRENT, PRE_TRANSFORM };  // what the engine's copy of this cloud is
   DeviceCopy device_ = NONE;
   std::set<SemanticT> owed_;  // labels whose covariance vector has not been fetched yet
+  std::map<SemanticT, const MatricesVector*> pushed_;  // the caller's vector of a label the engine's copy of the cloud holds
+  std::map<SemanticT, const MatricesVector*> ours_;  // the vector this class made for a label (anything else there is the caller's)
   detail::Engine engine_;
 };
 

@@ -538,3 +538,67 @@ def test_developer_switches_do_not_change_a_bit():
     for env in ({"SICP_NO_GRAPH": "1"}, {"SICP_WEIGHTS_FROM_HIST": "1"}, {"SICP_TICK_FIRST": "1"}):
         got = _poses_in_a_subprocess(env)
         assert got == base, env
+
+
+def test_caller_supplied_covariances_are_taken_or_refused():
+    """sicp_set_covariances (gicp.h:50-55 setSourceCloud(cloud, tree, covs); impl/semantic_icp.hpp:73,77 reads whatever the
+    caller left in labeledCovariances): covariances of the engine's form I - (1 - eps) n n^T -- here with normals of the
+    caller's own choosing, not the PCA ones -- are what the evaluation sweep and the inner solve then run on (checked
+    against the oracle's literal Evaluate on the very same 3x3 matrices); any other matrix is refused with the offending
+    point named and nothing changed; and with reuse_features = 0 an align() recomputes them, as impl/gicp.hpp:33-34 does."""
+    src, sl, tgt, tl, T, cm = synth.lidar_pair(seed=9, n_points=8000)
+    rng = np.random.default_rng(5)
+
+    def covs(n):
+        v = rng.normal(size=(n, 3))
+        v /= np.linalg.norm(v, axis=1, keepdims=True)
+        return np.eye(3)[None] - (1 - 1e-3) * v[:, :, None] * v[:, None, :], v
+
+    cs, ns = covs(len(src))
+    ct, nt = covs(len(tgt))
+    qt = mat_to_qt(T)
+    with make_engine(sicp.MODE_GICP, reuse_features=1) as e:
+        e.set_source(src); e.set_target(tgt)
+        e.set_covariances(sicp.SOURCE, cs); e.set_covariances(sicp.TARGET, ct.reshape(-1, 9))
+        got, gn, _, _ = e.covariances(sicp.SOURCE)          # "what is there" comes back: the caller's
+        assert np.allclose(got, cs, atol=1e-12, rtol=0) and (1 - np.abs(np.einsum("ni,ni->n", gn, ns))).max() < 1e-12
+        idx, d2, w = e.correspondences(IDENT)
+        out = e.accumulate(qt)
+        op = oracle_params(O.MODE_GICP)
+        ref = O.accumulate(op, qt, src, cs, tgt, ct, idx, w)
+        assert np.allclose(out, ref, rtol=1e-9, atol=1e-9 * np.abs(ref).max())
+        sol, info = e.solve(IDENT)
+        osol, oinfo = O.solve(op, src, cs, tgt, ct, idx, w, IDENT)
+        rot, trn = pose_delta(osol, sol)
+        assert info["lm_iters"] == oinfo["lm_iters"] and rot < 1e-7 and trn < 1e-7
+        # a matrix of another form: refused, named, nothing changed
+        bad = cs.copy()
+        bad[17] = np.diag([1.0, 2.0, 3.0])                  # (the shape of exec/test_gradient.cc:32-50's fixture)
+        with pytest.raises(sicp.SicpError) as err:
+            e.set_covariances(sicp.SOURCE, bad)
+        assert err.value.status == sicp.ERR_INVALID_ARGUMENT and "point 17" in str(err.value)
+        unsym = cs.copy()
+        unsym[5, 0, 1] += 1e-3
+        with pytest.raises(sicp.SicpError):
+            e.set_covariances(sicp.SOURCE, unsym)
+        assert np.array_equal(e.accumulate(qt), out)
+        kept, _ = e.align(IDENT)                            # reuse_features = 1: align() keeps the caller's
+    with make_engine(sicp.MODE_GICP) as e0:                 # the reference's align(): covariances recomputed from the cloud
+        e0.set_source(src); e0.set_target(tgt)
+        plain, _ = e0.align(IDENT)
+        e0.set_covariances(sicp.SOURCE, cs); e0.set_covariances(sicp.TARGET, ct)
+        again, _ = e0.align(IDENT)
+        assert np.array_equal(again, plain) and not np.array_equal(kept, plain)
+    # SICP_MODE_SEMANTIC reads the clouds' covariances (never recomputes per align): the caller's are used
+    s2, l2, t2, tl2, T2 = synth.config1_pair(seed=1, n_per_label=600)
+    with make_engine(sicp.MODE_SEMANTIC) as es:
+        es.set_source(s2, l2); es.set_target(t2, tl2)
+        base, _ = es.align(IDENT)
+        c_own, _, _, _ = es.covariances(sicp.SOURCE)
+        es.set_covariances(sicp.SOURCE, c_own)              # the engine's own matrices handed back: the same registration
+        same, _ = es.align(IDENT)
+        assert np.abs(same - base).max() < 1e-9
+        c_other, _ = covs(len(s2))
+        es.set_covariances(sicp.SOURCE, c_other)
+        other, _ = es.align(IDENT)
+        assert np.abs(other - base).max() > 1e-9            # and different covariances give a different answer: they are read

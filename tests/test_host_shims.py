@@ -394,3 +394,26 @@ def test_nyu_eval_headless_poses_and_label_agreement(tmp_path):
         assert len(rows_s) == len(summary[name])
         for ra, rb in zip(summary[name], rows_s):
             assert ra[0] == rb[0] and abs(ra[3] - rb[3]) <= 2 and abs(ra[1] - rb[1]) < 2e-3
+
+
+@pytest.mark.gpu
+def test_semantic_point_cloud_lives_on_the_device_and_handles_are_pooled(tmp_path):
+    """tests/cpp/semantic_cloud_check.cc: the SemanticPointCloud of the class shims owns one device-resident cloud that
+    SemanticIterativeClosestPoint::align shares (no flatten / upload / covariance pass per align), labeledCovariances is
+    fetched on first read and equals what addSemanticCloud computes per label cloud (also when read after transform()),
+    align() equals the flat C-ABI path bit for bit, and sicp_destroy / sicp_create recycle handles."""
+    sicp.build()
+    src, sl, tgt, tl, T_gt = synth.config1_pair(seed=1, n_per_label=700)
+    write_pcd(str(tmp_path / "a.pcd"), src, sl, binary=True)
+    write_pcd(str(tmp_path / "b.pcd"), tgt, tl, binary=True)
+    exe = str(tmp_path / "semantic_cloud_check")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"), "-I", HOST, os.path.join(ROOT, "tests", "cpp", "semantic_cloud_check.cc"),
+                    "-L", os.path.join(ROOT, "semantic-icp_amd"), "-lsicp", "-Wl,-rpath," + os.path.join(ROOT, "semantic-icp_amd"),
+                    "-Wl,-rpath,/opt/rocm/lib", "-pthread", "-o", exe], check=True, capture_output=True)
+    r = subprocess.run([exe, str(tmp_path / "a.pcd"), str(tmp_path / "b.pcd")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = {line.split()[0]: int(line.split()[1]) for line in r.stdout.splitlines() if line.strip()}
+    assert got == {"lazy_covariances_equal_per_label_clouds": 1, "covariances_after_transform_are_those_of_the_added_cloud": 1,
+                   "align_on_shared_device_clouds_equals_flat_c_abi": 1, "destroyed_handle_is_reused_and_fresh": 1,
+                   "supplied_covariances_of_the_engines_form_are_taken": 1, "supplied_covariances_of_another_form_are_refused_loudly": 1,
+                   "release_pool_frees_parked_handles": 1}, r.stdout
