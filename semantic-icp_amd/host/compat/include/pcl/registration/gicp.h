@@ -2,12 +2,16 @@
 // the reference's drivers run beside semanticicp::GICP as a comparison column (exec/test_icp.cc:107-113,
 // exec/kitti_eval.cc:229-247, nyu_eval.cc:193-210, scenenet_eval.cc:229-247, roc_eval.cc:160-176).  It is NOT
 // part of the path this engine replaces (out of scope).  So that those drivers still RUN
-// end to end without PCL, the stand-in does no registration at all: align() hands back the initial guess
-// (identity when none is given), reports hasConverged() == false and says so once on stderr.  Build against
-// real PCL to get PCL's numbers in that column.
+// end to end without PCL, the stand-in does no registration at all -- and what it reports cannot be mistaken for one:
+// getFinalTransformation() is all NaN (so every number a driver derives from it, the error columns of its PCL-GICP
+// result file included, is NaN), hasConverged() is false, and align() says so once on stderr.  The output cloud is the
+// source moved by the initial guess.  (SICP_PCL_GICP_RETURNS_GUESS=1 in the environment: the guess instead of NaN, the
+// behaviour of round 5, for scripts that need a finite matrix there.)  Build against real PCL to get PCL's numbers.
 #ifndef SICP_COMPAT_INCLUDE_PCL_REGISTRATION_GICP_H_
 #define SICP_COMPAT_INCLUDE_PCL_REGISTRATION_GICP_H_
 #include <cstdio>
+#include <cstdlib>
+#include <limits>
 
 #include "pcl/point_types.h"
 
@@ -28,9 +32,14 @@ class GeneralizedIterativeClosestPoint {
     if (!told) {
       told = true;
       std::fprintf(stderr, "[sicp compat] pcl::GeneralizedIterativeClosestPoint is third-party PCL code outside the MI355X engine: "
-                           "the stand-in returns the initial guess (build against real PCL for PCL's own GICP column)\n");
+                           "the stand-in registers nothing and reports an all-NaN transformation (build against real PCL for PCL's own GICP column)\n");
     }
-    final_ = guess;
+    if (std::getenv("SICP_PCL_GICP_RETURNS_GUESS")) {
+      final_ = guess;
+    } else {
+      for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) final_(r, c) = std::numeric_limits<float>::quiet_NaN();
+    }
     if (source_) transformPointCloud(*source_, out, guess);
   }
   bool hasConverged() const { return false; }

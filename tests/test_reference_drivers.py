@@ -123,7 +123,8 @@ def test_reference_kitti_eval_runs_on_the_engine(tmp_path):
         assert [(int(x[0]), int(x[1])) for x in ref_rows] == [(0, 3), (3, 6), (6, 9)]
         same_rows(ref_rows, rows_of(prefix + name))
         assert all(row[2] < 1e-4 for row in ref_rows)   # the reference's own error column: the pairs are registered
-    # the bootstrap column is the identity guess, PCL's GICP column is the stand-in (returns the guess): both equal GT error
+    # the bootstrap column is the identity guess (= the ground-truth motion as its error); PCL's GICP column is the stand-in,
+    # which registers nothing and says so in a way no reader of the file can miss: NaN in every derived number
     init = rows_of(one(str(run_dir / "*initkitti.csv")))
     pcl_files = [f for f in glob.glob(str(run_dir / "*GICPkitti.csv")) if not f.endswith("se3GICPkitti.csv")]
     assert len(pcl_files) == 1
@@ -131,7 +132,7 @@ def test_reference_kitti_eval_runs_on_the_engine(tmp_path):
     for a, b in zip(init, pclg):
         T_gt = np.linalg.inv(poses[int(a[0])]) @ poses[int(a[1])]
         assert np.allclose(np.array(a[6:22]).reshape(4, 4), T_gt, atol=1e-4)
-        assert np.allclose(a[2:5], b[2:5], rtol=1e-4)
+        assert np.all(np.isnan(b[2:5]))
 
 
 @pytest.mark.gpu
@@ -236,7 +237,10 @@ def test_reference_test_icp_and_roc_eval_run_to_the_end(tmp_path):
         write_pcd(str(tmp_path / sub / "0001.pcd"), src, sl, binary=True)
     run_dir = tmp_path / "roc_run"
     run_dir.mkdir()
-    r = subprocess.run([roc, "-s", str(tmp_path / "pred"), "-t", str(tmp_path / "gt")], cwd=run_dir, capture_output=True, text=True, timeout=600)
+    # (exec/roc_eval.cc:170-176 moves a cloud by PCL-GICP's matrix and looks its points up in a kd-tree: with the stand-in's
+    #  all-NaN matrix its own metrics code indexes out of range, so this run asks the stand-in for the finite guess)
+    r = subprocess.run([roc, "-s", str(tmp_path / "pred"), "-t", str(tmp_path / "gt")], cwd=run_dir, capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, SICP_PCL_GICP_RETURNS_GUESS="1"))
     assert r.returncode == 0, r.stderr[-3000:]
     pairs = np.loadtxt(one(str(run_dir / "*SICProc.csv")), delimiter=",")
     assert len(pairs) == len(src) and np.mean(pairs[:, 0] == pairs[:, 1]) > 0.9   # registered: nearest neighbours share labels
