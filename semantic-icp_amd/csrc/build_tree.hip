@@ -83,6 +83,35 @@ __global__ __launch_bounds__(256) void level_box_kernel(int n_nodes, int child_c
   box_hi[node_off + j] = make_float4(hx, hy, hz, 0.f);
 }
 
+// The upper levels of a segment's tree from level `first` on, by ONE workgroup: level after level, a barrier in between (a
+// level has a quarter of the nodes of the one below: from 4096 nodes down the whole rest is a few rounds of one workgroup).
+// One launch instead of one per level -- an upload of a 100K-point scan queued seven level launches of 4096 ... 1 nodes, and
+// a SICP_MODE_SEMANTIC cloud that many per label segment.
+constexpr int kUpperThreads = 1024, kUpperMaxNodes = 4096;
+__global__ __launch_bounds__(kUpperThreads) void upper_levels_kernel(TreeLevels lv, int first, int node_begin, float4* __restrict__ box_lo,
+                                                                     float4* __restrict__ box_hi) {
+  for (int k = first; k < lv.n_levels; ++k) {
+    const int n_nodes = lv.cnt[k], child_cnt = lv.cnt[k - 1], node_off = node_begin + lv.off[k], child_off = node_begin + lv.off[k - 1];
+    for (int j = threadIdx.x; j < n_nodes; j += kUpperThreads) {
+      float lx = INFINITY, ly = INFINITY, lz = INFINITY, hx = -INFINITY, hy = -INFINITY, hz = -INFINITY;
+      const int c0 = kFan * j, c1 = min(child_cnt, c0 + kFan);
+      for (int c = c0; c < c1; ++c) {
+        const float4 lo = box_lo[child_off + c], hi = box_hi[child_off + c];
+        lx = fminf(lx, lo.x); ly = fminf(ly, lo.y); lz = fminf(lz, lo.z);
+        hx = fmaxf(hx, hi.x); hy = fmaxf(hy, hi.y); hz = fmaxf(hz, hi.z);
+      }
+      box_lo[node_off + j] = make_float4(lx, ly, lz, 0.f);
+      box_hi[node_off + j] = make_float4(hx, hy, hz, 0.f);
+    }
+    // The level just written is the next one's input, and the levels lie back to back in memory: a cache line that holds the
+    // last boxes of the level below may have been pulled into this CU's L1 while the first boxes of this level -- in the same
+    // line -- were not written yet.  Release the writes, meet, then drop the L1 (the acquire half of the fence) before reading.
+    __threadfence();
+    __syncthreads();
+    __threadfence();
+  }
+}
+
 }  // namespace
 
 size_t build_sort_temp_bytes(int max_segment_points) {
@@ -116,9 +145,12 @@ hipError_t build_tree_device(const BuildBuffers& b, const BuildSegment* segs, in
                        b.rz, b.rl, b.x, b.y, b.z, b.label, b.perm, b.inv, b.pts4);
     hipLaunchKernelGGL(leaf_box_kernel, dim3((g.lv.cnt[0] + 255) / 256), dim3(256), 0, st, g.lv.cnt[0], g.cnt, g.pt_begin, g.node_begin,
                        g.code_begin, b.pts4, b.keys_out, b.box_lo, b.box_hi, b.leaf_code);
-    for (int k = 1; k < g.lv.n_levels; ++k)
+    int k = 1;
+    for (; k < g.lv.n_levels && g.lv.cnt[k] > kUpperMaxNodes; ++k)  // the wide levels: a launch of their own
       hipLaunchKernelGGL(level_box_kernel, dim3((g.lv.cnt[k] + 255) / 256), dim3(256), 0, st, g.lv.cnt[k], g.lv.cnt[k - 1],
                          g.node_begin + g.lv.off[k], g.node_begin + g.lv.off[k - 1], b.box_lo, b.box_hi);
+    if (k < g.lv.n_levels)  // everything above them: one workgroup
+      hipLaunchKernelGGL(upper_levels_kernel, dim3(1), dim3(kUpperThreads), 0, st, g.lv, k, g.node_begin, b.box_lo, b.box_hi);
   }
   return hipGetLastError();
 }

@@ -110,13 +110,18 @@ int prepare_cloud(sicp_context* h, Cloud& c) {
     counts.push_back(n);
   } else {
     // pcl_2_semantic.h:24-39: one sub-cloud per label, labels in order of first appearance
+    // (the previous point's segment first: a cloud that arrives label by label -- SemanticPointCloud's -- or in image
+    //  order, where runs of one label are long, then costs one compare per point instead of one per label seen so far)
+    int last = -1;
     for (int i = 0; i < n; ++i) {
-      int sidx = -1;
-      for (size_t k = 0; k < c.seg_label.size(); ++k)
-        if (c.seg_label[k] == c.hl[i]) { sidx = (int)k; break; }
-      if (sidx < 0) { sidx = (int)c.seg_label.size(); c.seg_label.push_back(c.hl[i]); counts.push_back(0); }
+      const uint32_t l = c.hl[i];
+      int sidx = (last >= 0 && c.seg_label[(size_t)last] == l) ? last : -1;
+      for (size_t k = 0; sidx < 0 && k < c.seg_label.size(); ++k)
+        if (c.seg_label[k] == l) sidx = (int)k;
+      if (sidx < 0) { sidx = (int)c.seg_label.size(); c.seg_label.push_back(l); counts.push_back(0); }
       which[i] = sidx;
       counts[sidx]++;
+      last = sidx;
     }
   }
   const int n_seg = (int)c.seg_label.size();
