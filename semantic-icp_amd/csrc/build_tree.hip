@@ -83,11 +83,22 @@ __global__ __launch_bounds__(256) void level_box_kernel(int n_nodes, int child_c
   box_hi[node_off + j] = make_float4(hx, hy, hz, 0.f);
 }
 
-// The upper levels of a segment's tree from level `first` on, by ONE workgroup: level after level, a barrier in between (a
-// level has a quarter of the nodes of the one below: from 4096 nodes down the whole rest is a few rounds of one workgroup).
-// One launch instead of one per level -- an upload of a 100K-point scan queued seven level launches of 4096 ... 1 nodes, and
-// a SICP_MODE_SEMANTIC cloud that many per label segment.
-constexpr int kUpperThreads = 1024, kUpperMaxNodes = 4096;
+// The narrow upper levels of a segment's tree, from level `first` on, by ONE workgroup: level after level with a barrier in
+// between (a level has a quarter of the nodes of the one below: from 1024 nodes down the whole rest is one round of the
+// workgroup per level).  One launch instead of six at 100K points -- and per label segment of a SICP_MODE_SEMANTIC cloud.
+// The level just written is the next one's input, and the levels lie back to back in memory: a cache line that holds the last
+// boxes of the level below may have been pulled into this CU's L1 while the first boxes of this level -- the same line -- were
+// not written yet.  So the children are read PAST the L1 (agent-scope loads; the stores are write-through and drained by the
+// barrier's s_waitcnt, the workgroup sits on one CU of one XCD: its L2 is the meeting point).  (A first version that kept plain
+// loads and put release / acquire fences around the barrier took 85 us per call: the fences write back and invalidate whole
+// caches, seven times.)
+constexpr int kUpperThreads = 1024, kUpperMaxNodes = 1024;
+__device__ __forceinline__ float4 load_box_past_l1(const float4* p) {
+  const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+  const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return make_float4(__uint_as_float((unsigned)a), __uint_as_float((unsigned)(a >> 32)), __uint_as_float((unsigned)b), __uint_as_float((unsigned)(b >> 32)));
+}
 __global__ __launch_bounds__(kUpperThreads) void upper_levels_kernel(TreeLevels lv, int first, int node_begin, float4* __restrict__ box_lo,
                                                                      float4* __restrict__ box_hi) {
   for (int k = first; k < lv.n_levels; ++k) {
@@ -96,19 +107,15 @@ __global__ __launch_bounds__(kUpperThreads) void upper_levels_kernel(TreeLevels 
       float lx = INFINITY, ly = INFINITY, lz = INFINITY, hx = -INFINITY, hy = -INFINITY, hz = -INFINITY;
       const int c0 = kFan * j, c1 = min(child_cnt, c0 + kFan);
       for (int c = c0; c < c1; ++c) {
-        const float4 lo = box_lo[child_off + c], hi = box_hi[child_off + c];
+        const float4 lo = load_box_past_l1(box_lo + child_off + c), hi = load_box_past_l1(box_hi + child_off + c);
         lx = fminf(lx, lo.x); ly = fminf(ly, lo.y); lz = fminf(lz, lo.z);
         hx = fmaxf(hx, hi.x); hy = fmaxf(hy, hi.y); hz = fmaxf(hz, hi.z);
       }
       box_lo[node_off + j] = make_float4(lx, ly, lz, 0.f);
       box_hi[node_off + j] = make_float4(hx, hy, hz, 0.f);
     }
-    // The level just written is the next one's input, and the levels lie back to back in memory: a cache line that holds the
-    // last boxes of the level below may have been pulled into this CU's L1 while the first boxes of this level -- in the same
-    // line -- were not written yet.  Release the writes, meet, then drop the L1 (the acquire half of the fence) before reading.
-    __threadfence();
-    __syncthreads();
-    __threadfence();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's (write-through) stores have reached L2 ...
+    __syncthreads();                                   // ... before any wave reads them past the L1
   }
 }
 

@@ -13,7 +13,7 @@ pre=$1
 export SICP_NO_GRAPH=1
 for attempt in 1 2; do
   rm -rf /tmp/pb_prof
-  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb_prof -- python3 bench.py --no-cpu-baseline \
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb_prof -- python3 bench.py --no-cpu-baseline --no-dropin \
     > gpurun_out/${pre}_bench_under_rocprof.json 2> /tmp/pb_prof.err
   [ -n "$(find /tmp/pb_prof -name '*kernel_trace.csv' 2>/dev/null | head -1)" ] && break
   echo "attempt $attempt: no kernel trace (rocprofv3 crashed?)"
