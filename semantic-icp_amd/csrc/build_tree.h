@@ -20,6 +20,13 @@ struct BuildSegment {
   TreeLevels lv;
 };
 
+// the same, as the device reads it (several segments are built by launches over ALL of them: the kernels find an element's
+// segment by binary search of the begin offsets)
+struct BuildSegmentDev {
+  int off, cnt, padded, pt_begin, node_begin, code_begin, n_leaf, top;
+  float lox, loy, loz, scale;
+};
+
 struct BuildBuffers {
   // in: the cloud in caller order, and (several segments only) caller indices grouped by segment
   const float *rx, *ry, *rz;
@@ -30,6 +37,11 @@ struct BuildBuffers {
   int *vals_in, *vals_out;
   void* sort_temp;
   size_t sort_temp_bytes;
+  // several segments only: their descriptions on the device (uploaded from `h_segs`, pinned); the offset arrays are spare
+  BuildSegmentDev* d_segs;
+  BuildSegmentDev* h_segs;
+  int *d_seg_begin, *d_seg_end;
+  int *h_seg_begin, *h_seg_end;
   // out
   float *x, *y, *z;
   uint32_t* label;
@@ -38,6 +50,8 @@ struct BuildBuffers {
   unsigned long long* leaf_code;
 };
 
+// keys_in / keys_out / vals_in / vals_out hold `max_segment_points` entries for a one-segment cloud and ALL points for a
+// cloud of several segments (every segment sorts its own range)
 size_t build_sort_temp_bytes(int max_segment_points);
 hipError_t build_tree_device(const BuildBuffers& b, const BuildSegment* segs, int n_seg, hipStream_t st);
 

@@ -119,6 +119,99 @@ __global__ __launch_bounds__(kUpperThreads) void upper_levels_kernel(TreeLevels 
   }
 }
 
+// ---- several segments (SICP_MODE_SEMANTIC: one per label): every stage ONE launch over all segments.  Round 6: a 13-label
+// frame of 307 200 points took 3.2 ms of host time per upload as one sort + six launches PER SEGMENT.
+// segment of element e of a concatenation whose parts begin at begins[0 .. n_seg): the last part that begins at or before e
+template <class F>
+__device__ __forceinline__ int find_segment(const BuildSegmentDev* __restrict__ segs, int n_seg, int e, F begin_of) {
+  int lo = 0, hi = n_seg - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (begin_of(segs[mid]) <= e) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(256) void codes_all_kernel(int n, int n_seg, const BuildSegmentDev* __restrict__ segs, const int* __restrict__ ids,
+                                                        const float* __restrict__ rx, const float* __restrict__ ry, const float* __restrict__ rz,
+                                                        unsigned long long* __restrict__ keys, int* __restrict__ vals) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const BuildSegmentDev g = segs[find_segment(segs, n_seg, e, [](const BuildSegmentDev& s) { return s.off; })];
+  const int i = ids[e];
+  keys[e] = curve_code(rx[i], ry[i], rz[i], g.lox, g.loy, g.loz, g.scale);
+  vals[e] = i;
+}
+
+__global__ __launch_bounds__(256) void gather_all_kernel(int pt_total, int n_seg, const BuildSegmentDev* __restrict__ segs, const int* __restrict__ sorted,
+                                                         const float* __restrict__ rx, const float* __restrict__ ry, const float* __restrict__ rz,
+                                                         const uint32_t* __restrict__ rl, float* __restrict__ x, float* __restrict__ y,
+                                                         float* __restrict__ z, uint32_t* __restrict__ label, int* __restrict__ perm,
+                                                         int* __restrict__ inv, float4* __restrict__ pts4) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= pt_total) return;
+  const BuildSegmentDev g = segs[find_segment(segs, n_seg, p, [](const BuildSegmentDev& s) { return s.pt_begin; })];
+  const int e = p - g.pt_begin;
+  if (e < g.cnt) {
+    const int i = sorted[g.off + e];
+    const float px = rx[i], py = ry[i], pz = rz[i];
+    const int d = g.off + e;
+    x[d] = px; y[d] = py; z[d] = pz;
+    if (rl) label[d] = rl[i];
+    perm[d] = i;
+    inv[i] = d;
+    pts4[p] = make_float4(px, py, pz, __uint_as_float((unsigned)i));
+  } else {
+    pts4[p] = make_float4(INFINITY, INFINITY, INFINITY, __uint_as_float(0xffffffffu));
+  }
+}
+
+__global__ __launch_bounds__(256) void leaf_box_all_kernel(int leaf_total, int n_seg, const BuildSegmentDev* __restrict__ segs,
+                                                           const float4* __restrict__ pts4, const unsigned long long* __restrict__ sorted_keys,
+                                                           float4* __restrict__ box_lo, float4* __restrict__ box_hi,
+                                                           unsigned long long* __restrict__ leaf_code) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= leaf_total) return;
+  const BuildSegmentDev g = segs[find_segment(segs, n_seg, q, [](const BuildSegmentDev& s) { return s.code_begin; })];
+  const int j = q - g.code_begin;
+  float lx = INFINITY, ly = INFINITY, lz = INFINITY, hx = -INFINITY, hy = -INFINITY, hz = -INFINITY;
+  const int e0 = j * kLeaf, e1 = min(g.cnt, e0 + kLeaf);
+  for (int e = e0; e < e1; ++e) {
+    const float4 p = pts4[g.pt_begin + e];
+    lx = fminf(lx, p.x); ly = fminf(ly, p.y); lz = fminf(lz, p.z);
+    hx = fmaxf(hx, p.x); hy = fmaxf(hy, p.y); hz = fmaxf(hz, p.z);
+  }
+  box_lo[g.node_begin + j] = make_float4(lx, ly, lz, 0.f);
+  box_hi[g.node_begin + j] = make_float4(hx, hy, hz, 0.f);
+  leaf_code[q] = e0 < g.cnt ? sorted_keys[g.off + e0] : ~0ull;
+}
+
+// the narrow upper levels of EVERY segment: workgroup s builds those of segment s (upper_levels_kernel's loop; a complete
+// 4-ary tree: level L has 4^(top - L) nodes at level_offset(top, L))
+__global__ __launch_bounds__(kUpperThreads) void upper_levels_all_kernel(const BuildSegmentDev* __restrict__ segs, float4* __restrict__ box_lo,
+                                                                         float4* __restrict__ box_hi) {
+  const BuildSegmentDev g = segs[blockIdx.x];
+  int first = 1;
+  while (first <= g.top && (1 << (2 * (g.top - first))) > kUpperMaxNodes) ++first;
+  for (int k = first; k <= g.top; ++k) {
+    const int n_nodes = 1 << (2 * (g.top - k)), child_cnt = 1 << (2 * (g.top - k + 1));
+    const int node_off = g.node_begin + level_offset(g.top, k), child_off = g.node_begin + level_offset(g.top, k - 1);
+    for (int j = threadIdx.x; j < n_nodes; j += kUpperThreads) {
+      float lx = INFINITY, ly = INFINITY, lz = INFINITY, hx = -INFINITY, hy = -INFINITY, hz = -INFINITY;
+      const int c0 = kFan * j, c1 = min(child_cnt, c0 + kFan);
+      for (int c = c0; c < c1; ++c) {
+        const float4 lo = load_box_past_l1(box_lo + child_off + c), hi = load_box_past_l1(box_hi + child_off + c);
+        lx = fminf(lx, lo.x); ly = fminf(ly, lo.y); lz = fminf(lz, lo.z);
+        hx = fmaxf(hx, hi.x); hy = fmaxf(hy, hi.y); hz = fmaxf(hz, hi.z);
+      }
+      box_lo[node_off + j] = make_float4(lx, ly, lz, 0.f);
+      box_hi[node_off + j] = make_float4(hx, hy, hz, 0.f);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+}
+
 }  // namespace
 
 size_t build_sort_temp_bytes(int max_segment_points) {
@@ -130,7 +223,48 @@ size_t build_sort_temp_bytes(int max_segment_points) {
   return bytes;
 }
 
+// several segments: one launch per stage over all of them, the sorts one per segment
+static hipError_t build_segments_together(const BuildBuffers& b, const BuildSegment* segs, int n_seg, hipStream_t st) {
+  int n = 0, pt_total = 0, leaf_total = 0;
+  for (int s = 0; s < n_seg; ++s) {
+    const BuildSegment& g = segs[s];
+    BuildSegmentDev& d = b.h_segs[s];
+    d.off = g.off; d.cnt = g.cnt; d.padded = g.padded; d.pt_begin = g.pt_begin; d.node_begin = g.node_begin; d.code_begin = g.code_begin;
+    d.n_leaf = g.lv.cnt[0]; d.top = g.lv.n_levels - 1;
+    d.lox = g.lo[0]; d.loy = g.lo[1]; d.loz = g.lo[2]; d.scale = g.scale;
+    n += g.cnt; pt_total += g.padded; leaf_total += g.lv.cnt[0];
+  }
+  hipError_t e = hipMemcpyAsync(b.d_segs, b.h_segs, sizeof(BuildSegmentDev) * n_seg, hipMemcpyHostToDevice, st);
+  if (e != hipSuccess) return e;
+  if (n > 0) {
+    hipLaunchKernelGGL(codes_all_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, n_seg, b.d_segs, b.ids, b.rx, b.ry, b.rz, b.keys_in, b.vals_in);
+    // one plain radix sort per segment, each on its own range of the shared key / value buffers.  (rocPRIM's SEGMENTED radix
+    // sort was tried first: it gives every segment to ONE workgroup, and a 13-label frame whose largest label has ~100K points
+    // then sorts for 4 ms instead of 0.4.)
+    for (int s2 = 0; s2 < n_seg; ++s2) {
+      const BuildSegment& g = segs[s2];
+      if (g.cnt <= 0) continue;
+      size_t tmp = b.sort_temp_bytes;
+      e = rocprim::radix_sort_pairs(b.sort_temp, tmp, b.keys_in + g.off, b.keys_out + g.off, b.vals_in + g.off, b.vals_out + g.off, (size_t)g.cnt, 0, 63, st);
+      if (e != hipSuccess) return e;
+    }
+  }
+  hipLaunchKernelGGL(gather_all_kernel, dim3((pt_total + 255) / 256), dim3(256), 0, st, pt_total, n_seg, b.d_segs, b.vals_out, b.rx, b.ry, b.rz, b.rl, b.x,
+                     b.y, b.z, b.label, b.perm, b.inv, b.pts4);
+  hipLaunchKernelGGL(leaf_box_all_kernel, dim3((leaf_total + 255) / 256), dim3(256), 0, st, leaf_total, n_seg, b.d_segs, b.pts4, b.keys_out, b.box_lo, b.box_hi,
+                     b.leaf_code);
+  for (int s = 0; s < n_seg; ++s) {  // the wide levels of the big segments: a launch of their own each
+    const BuildSegment& g = segs[s];
+    for (int k = 1; k < g.lv.n_levels && g.lv.cnt[k] > kUpperMaxNodes; ++k)
+      hipLaunchKernelGGL(level_box_kernel, dim3((g.lv.cnt[k] + 255) / 256), dim3(256), 0, st, g.lv.cnt[k], g.lv.cnt[k - 1], g.node_begin + g.lv.off[k],
+                         g.node_begin + g.lv.off[k - 1], b.box_lo, b.box_hi);
+  }
+  hipLaunchKernelGGL(upper_levels_all_kernel, dim3(n_seg), dim3(kUpperThreads), 0, st, b.d_segs, b.box_lo, b.box_hi);
+  return hipGetLastError();
+}
+
 hipError_t build_tree_device(const BuildBuffers& b, const BuildSegment* segs, int n_seg, hipStream_t st) {
+  if (n_seg > 1 && b.ids && b.d_segs) return build_segments_together(b, segs, n_seg, st);
   for (int s = 0; s < n_seg; ++s) {
     const BuildSegment& g = segs[s];
     if (g.cnt <= 0) {

@@ -168,10 +168,18 @@ int prepare_cloud(sicp_context* h, Cloud& c) {
   const size_t m = (size_t)(n > 0 ? n : 1);
   HIPCHECK(c.rx.reserve(m)); HIPCHECK(c.ry.reserve(m)); HIPCHECK(c.rz.reserve(m)); HIPCHECK(c.rl.reserve(m));
   HIPCHECK(c.ids.reserve(m)); HIPCHECK(c.d_perm.reserve(m));
-  HIPCHECK(c.keys_in.reserve((size_t)max_cnt)); HIPCHECK(c.keys_out.reserve((size_t)max_cnt));
-  HIPCHECK(c.vals_in.reserve((size_t)max_cnt)); HIPCHECK(c.vals_out.reserve((size_t)max_cnt));
+  // one segment: sort buffers of its size; several: every segment sorts its own range of buffers that hold all points (and the
+  // segments' descriptions go to the device: the other stages are ONE launch over all segments)
+  const bool together = want && n_seg > 1;
+  const size_t sort_n = together ? m : (size_t)max_cnt;
+  HIPCHECK(c.keys_in.reserve(sort_n)); HIPCHECK(c.keys_out.reserve(sort_n));
+  HIPCHECK(c.vals_in.reserve(sort_n)); HIPCHECK(c.vals_out.reserve(sort_n));
   const size_t temp_bytes = sicp::build_sort_temp_bytes(max_cnt);
   HIPCHECK(c.sort_temp.reserve(temp_bytes + 256));
+  if (together) {
+    HIPCHECK(c.d_segs.reserve((size_t)n_seg)); HIPCHECK(c.d_seg_begin.reserve((size_t)n_seg)); HIPCHECK(c.d_seg_end.reserve((size_t)n_seg));
+    HIPCHECK(c.h_segs.resize((size_t)n_seg)); HIPCHECK(c.h_seg_begin.resize((size_t)n_seg)); HIPCHECK(c.h_seg_end.resize((size_t)n_seg));
+  }
   HIPCHECK(c.x.reserve(m)); HIPCHECK(c.y.reserve(m)); HIPCHECK(c.z.reserve(m));
   HIPCHECK(c.label.reserve(m)); HIPCHECK(c.inv.reserve(m));
   HIPCHECK(c.pts4.reserve((size_t)pt_total + 1)); HIPCHECK(c.box_lo.reserve((size_t)node_total + 1));
@@ -188,6 +196,9 @@ int prepare_cloud(sicp_context* h, Cloud& c) {
   b.rx = c.rx.p; b.ry = c.ry.p; b.rz = c.rz.p; b.rl = c.has_label ? c.rl.p : nullptr; b.ids = want ? c.ids.p : nullptr;
   b.keys_in = c.keys_in.p; b.keys_out = c.keys_out.p; b.vals_in = c.vals_in.p; b.vals_out = c.vals_out.p;
   b.sort_temp = c.sort_temp.p; b.sort_temp_bytes = temp_bytes;
+  b.d_segs = together ? c.d_segs.p : nullptr; b.h_segs = together ? c.h_segs.data() : nullptr;
+  b.d_seg_begin = together ? c.d_seg_begin.p : nullptr; b.d_seg_end = together ? c.d_seg_end.p : nullptr;
+  b.h_seg_begin = together ? c.h_seg_begin.data() : nullptr; b.h_seg_end = together ? c.h_seg_end.data() : nullptr;
   b.x = c.x.p; b.y = c.y.p; b.z = c.z.p; b.label = c.label.p; b.perm = c.d_perm.p; b.inv = c.inv.p;
   b.pts4 = c.pts4.p; b.box_lo = c.box_lo.p; b.box_hi = c.box_hi.p; b.leaf_code = c.leaf_code.p;
   HIPCHECK(sicp::build_tree_device(b, segs.data(), n_seg, h->stream));

@@ -269,6 +269,11 @@ struct Cloud {
   HostBuf<int> h_ids;
   DevBuf<unsigned long long> keys_in, keys_out;
   DevBuf<unsigned char> sort_temp;
+  // several label segments: their descriptions and sort offsets for the one-launch-per-stage build (build_tree.hip)
+  DevBuf<sicp::BuildSegmentDev> d_segs;
+  HostBuf<sicp::BuildSegmentDev> h_segs;
+  DevBuf<int> d_seg_begin, d_seg_end;
+  HostBuf<int> h_seg_begin, h_seg_end;
   DevBuf<sicp::PointRec> rec;  // position + normal of every point (what the weight / accumulate kernels gather)
   DevBuf<char> rec_dense;      // the same as three dense arrays (what the accumulate kernel streams for the source points)
   int rec_dense_n = 0;         // the cloud size they were written for (0: not written)
