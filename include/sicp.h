@@ -38,7 +38,7 @@ extern "C" {
 #endif
 
 #define SICP_VERSION_MAJOR 0
-#define SICP_VERSION_MINOR 5
+#define SICP_VERSION_MINOR 6
 #define SICP_MAX_K_COV 32  /* largest covariance neighbourhood (ctor argument k) */
 
 /* ---- status codes ------------------------------------------------------- */

@@ -189,7 +189,7 @@ def test_one_point_clouds():
 
 
 def test_version_string_and_pool_arguments():
-    assert sicp.version().startswith("semantic-icp_amd 0.5")
+    assert sicp.version().startswith("semantic-icp_amd 0.6")
     assert sicp.lib().sicp_release_pool(-1) == sicp.ERR_INVALID_ARGUMENT
     assert sicp.lib().sicp_release_pool(10_000) == sicp.ERR_INVALID_ARGUMENT
     assert sicp.lib().sicp_release_pool(0) == sicp.OK
