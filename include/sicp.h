@@ -327,12 +327,20 @@ const char* sicp_stream_last_error(sicp_stream s);
  * them to the caller), and GICP::setSourceCloud(cloud, tree, covs) / setTargetCloud(cloud, tree, covs) (gicp.h:50-55, 65-70)
  * accept arbitrary vectors (GICP::align and EmIterativeClosestPoint::align then overwrite them, impl/gicp.hpp:33-34,
  * impl/em_icp.hpp:28-29 -- which is what this engine does too unless reuse_features is set).
- * cov9: n_points x 9 row-major 3x3 matrices in the caller's point order.  The engine evaluates covariances of the form the
- * reference's own routine produces, C = I - (1 - epsilon) n n^T (a unit normal n; epsilon = params.epsilon), and keeps the
- * normal: a matrix that is not of that form (to 1e-8) is REFUSED -- SICP_ERR_INVALID_ARGUMENT, sicp_last_error names the
- * first offending point -- never silently replaced.  Accepted covariances count as the cloud's current features for
- * SICP_MODE_SEMANTIC, and for SICP_MODE_GICP with reuse_features = 1; SICP_MODE_EM also needs the label histograms of
- * the neighbourhoods and recomputes.  Entries of non-finite points (which never reach the device) are ignored. */
+ * cov9: n_points x 9 row-major 3x3 matrices in the caller's point order.
+ *   - every matrix of the form the reference's own routine produces, C = I - (1 - epsilon) n n^T (a unit normal n; epsilon =
+ *     params.epsilon; to 1e-8): the engine keeps the normals and registers with its product kernels, batches and streams included;
+ *   - otherwise, every matrix symmetric and finite (SICP_MODE_GICP / SICP_MODE_SEMANTIC): kept as they are, and the cloud's
+ *     registrations evaluate gicp_cost_function.h:27-73 on the full 3x3 matrices (its closed form for symmetric covariances),
+ *     with the trust-region loop on the host: correct to the same tolerances, ONE PAIR AT A TIME (sicp_align, sicp_solve,
+ *     sicp_accumulate; sicp_align_batch of more than one pair and streams answer SICP_ERR_INVALID_ARGUMENT) and far from the
+ *     product path's speed -- the path of an exotic input, e.g. exec/test_gradient.cc:32-50's fixture;
+ *   - anything else (a non-symmetric or non-finite matrix; a general matrix in SICP_MODE_EM, whose align() recomputes
+ *     covariances and label histograms together) is REFUSED: SICP_ERR_INVALID_ARGUMENT, sicp_last_error names the first
+ *     offending point, nothing is changed -- never a silent replacement.
+ * Accepted covariances count as the cloud's current features for SICP_MODE_SEMANTIC, and for SICP_MODE_GICP with
+ * reuse_features = 1 (without it align() recomputes them, as impl/gicp.hpp:33-34 does).  Entries of non-finite points (which
+ * never reach the device) are ignored.  sicp_covariances hands back what is there. */
 int sicp_set_covariances(sicp_handle h, int which, const double* cov9);
 
 /* the final_cloud output of align (em_icp.hpp:192-198): source transformed by

@@ -87,6 +87,7 @@ int stage_cloud(sicp_context* h, Cloud& c, int32_t n, const StridedCloud& in) {
   c.is_set = true;
   c.layout = -1;
   c.feat_valid = false;
+  c.cov_general = false;
   c.proj_valid = false;
   return SICP_OK;
 }
@@ -212,6 +213,7 @@ int prepare_cloud(sicp_context* h, Cloud& c) {
   c.pending = true;
   c.layout = want;
   c.feat_valid = false;
+  c.cov_general = false;
   h->corr_valid = false;
   h->hint_ok = false;
   return SICP_OK;
@@ -246,6 +248,7 @@ int set_cloud_common(sicp_handle h, int which, int32_t n, const StridedCloud& in
   c.is_set = true;
   c.layout = -1;
   c.feat_valid = false;
+  c.cov_general = false;
   h->corr_valid = false;
   h->hint_ok = false;
   // upload now for the current mode, so that align() starts with the cloud resident in HBM;

@@ -277,6 +277,11 @@ struct Cloud {
   DevBuf<sicp::PointRec> rec;  // position + normal of every point (what the weight / accumulate kernels gather)
   DevBuf<char> rec_dense;      // the same as three dense arrays (what the accumulate kernel streams for the source points)
   int rec_dense_n = 0;         // the cloud size they were written for (0: not written)
+  // Caller-supplied covariances that are NOT of the form I - (1-eps) n n^T (sicp_set_covariances): the six entries xx xy xz yy
+  // yz zz of every point's symmetric matrix, device order.  A handle with such a cloud evaluates through
+  // accumulate_general_kernel (the literal gicp_cost_function.h:27-73 with full 3x3 matrices), one pair at a time.
+  DevBuf<double> cov6;
+  bool cov_general = false;
   DevBuf<uint8_t> hist;
   DevBuf<double> proj;  // [n][proj_stride(C)] label distribution x confusion matrix
   bool proj_valid = false;
@@ -587,6 +592,8 @@ struct SolveResult {
 };
 
 bool solo_allowed(sicp_context* h);
+bool general_covariances(const sicp_context* h);  // either cloud carries caller covariances of general form
+int align_host_loop(sicp_context* h, const double* init_qt, double* out_qt, int32_t* outer_iters, sicp_stats* stats);
 bool lm_step_in_launch();
 int run_solve(sicp_context* h, const double* init_qt, double* out_qt, SolveResult* res);
 bool same_solver(const sicp_params& a, const sicp_params& b);

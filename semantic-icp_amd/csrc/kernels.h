@@ -221,6 +221,16 @@ struct AccArgs {
   double* partials;  // [28][accumulate_blocks]
 };
 
+// One evaluation of ONE pair whose covariances are (partly) the caller's own, of general form: full symmetric 3x3 matrices
+// (six doubles per point, device order; nullptr: that cloud's are I - (1-eps) n n^T from its records).  Same columns of
+// partials[28][n_chunks] as the product kernel writes, summed by the same finalize_batch_kernel.
+struct GenAccArgs {
+  AccArgs a;
+  const double *scov6, *tcov6;
+  int n_chunks, pad_;
+};
+hipError_t launch_accumulate_general(const GenAccArgs& g, hipStream_t st);
+
 // job arrays passed by value to one launch (lock-step batch); sized to stay inside the 4 KB of
 // kernel arguments
 constexpr int kMaxKnnJobs = 8;

@@ -30,7 +30,7 @@ std::shared_ptr<Cloud> acquire_cloud(int device) {
     dead->pending = false;
     dead->n = 0; dead->n_caller = 0; dead->is_set = false; dead->has_label = false; dead->layout = -1;
     dead->keep.clear(); dead->drop_i.clear(); dead->drop_xyz.clear();
-    dead->feat_valid = false; dead->proj_valid = false; dead->feat_epoch = 0; dead->proj_cm_id = 0;
+    dead->feat_valid = false; dead->cov_general = false; dead->proj_valid = false; dead->feat_epoch = 0; dead->proj_cm_id = 0;
     CloudPool& pl = cloud_pool();
     {
       std::lock_guard<std::mutex> lock(pl.m);

@@ -5,6 +5,33 @@
 
 using namespace sicp::host;
 
+// align() with the outer AND the inner loop on the host (lm_on_device = 0; a pair with caller covariances of general form)
+int sicp::host::align_host_loop(sicp_context* h, const double* init_qt, double* out_qt, int32_t* outer_iters, sicp_stats* stats) {
+  const sicp_params& P = h->params;
+  const double t_begin = now_ms();
+  h->epoch = next_epoch();
+  SICPCHECK(align_begin(h, stats != nullptr));
+  OuterState o;
+  std::memcpy(o.cur, init_qt, sizeof o.cur);
+  while (!o.converged) {
+    std::memcpy(o.est, o.cur, sizeof o.est);
+    if (P.mode == SICP_MODE_SEMANTIC) o.count++;  // semantic_icp.hpp:47
+    SICPCHECK(run_correspondences(h, o.cur, P.knn, true));
+    {
+      const double t0 = now_ms();
+      SolveResult r;
+      SICPCHECK(run_solve(h, o.est, o.est, &r));
+      h->st.total_lm_iters += r.iterations;
+      h->st.final_cost = r.cost;
+      h->st.t_solve_ms += now_ms() - t0;
+    }
+    outer_finish(P, o);
+  }
+  std::memcpy(out_qt, o.cur, sizeof o.cur);
+  SICPCHECK(align_end(h, o, t_begin, outer_iters, stats));
+  return SICP_OK;
+}
+
 // =================================================================================================
 // C ABI
 // =================================================================================================
@@ -408,29 +435,8 @@ int sicp_align(sicp_handle h, const double init_qt[7], double out_qt[7], int32_t
     SICPCHECK(check_ready(h, false));
     const sicp_params& P = h->params;
     // device-resident solve: a lock-step batch of one (the same kernels, hence the same bits, as any batch)
-    if (P.lm_on_device) return sicp_align_batch(&h, 1, init_qt, out_qt, outer_iters, stats);
-    const double t_begin = now_ms();
-    h->epoch = next_epoch();
-    SICPCHECK(align_begin(h, stats != nullptr));
-    OuterState o;
-    std::memcpy(o.cur, init_qt, sizeof o.cur);
-    while (!o.converged) {
-      std::memcpy(o.est, o.cur, sizeof o.est);
-      if (P.mode == SICP_MODE_SEMANTIC) o.count++;  // semantic_icp.hpp:47
-      SICPCHECK(run_correspondences(h, o.cur, P.knn, true));
-      {
-        const double t0 = now_ms();
-        SolveResult r;
-        SICPCHECK(run_solve(h, o.est, o.est, &r));
-        h->st.total_lm_iters += r.iterations;
-        h->st.final_cost = r.cost;
-        h->st.t_solve_ms += now_ms() - t0;
-      }
-      outer_finish(P, o);
-    }
-    std::memcpy(out_qt, o.cur, sizeof o.cur);
-    SICPCHECK(align_end(h, o, t_begin, outer_iters, stats));
-    return SICP_OK;
+    if (P.lm_on_device && !general_covariances(h)) return sicp_align_batch(&h, 1, init_qt, out_qt, outer_iters, stats);
+    return align_host_loop(h, init_qt, out_qt, outer_iters, stats);
   });
 }
 
@@ -443,6 +449,11 @@ int sicp_align_batch(sicp_handle* hs, int32_t n, const double* init_qt, double* 
 int sicp_accumulate_batch(sicp_handle* hs, int32_t n, const double* qt, double* out28, int32_t repeat, double* kernel_ms) {
   return abi_guard((hs && n > 0) ? hs[0] : nullptr, [&]() -> int {
     if (!hs || n < 1 || !qt || !out28) return SICP_ERR_INVALID_ARGUMENT;
+    for (int p = 0; p < n; ++p)
+      if (hs[p] && general_covariances(hs[p])) {
+        hs[p]->last_error = "sicp_accumulate_batch: a handle with caller covariances of general form evaluates one pair at a time (sicp_accumulate)";
+        return SICP_ERR_INVALID_ARGUMENT;
+      }
     for (int p = 0; p < n; ++p)
       if (!hs[p] || !hs[p]->corr_valid || hs[p]->device != hs[0]->device || hs[p]->corr_K != hs[0]->corr_K) return SICP_ERR_NOT_READY;
     sicp_context* h = hs[0];
@@ -600,55 +611,81 @@ int sicp_set_covariances(sicp_handle h, int which, const double* cov9) {
     const double kappa = 1.0 - P.epsilon;
     if (!(kappa > 0.0)) { h->last_error = "sicp_set_covariances: params.epsilon must be below 1"; return SICP_ERR_INVALID_ARGUMENT; }
     const int n = c.n;
-    std::vector<double> nrm((size_t)(n > 0 ? n : 1) * 3);
-    // C = I - kappa n n^T  <=>  (I - C) / kappa = n n^T: symmetric, rank one, trace one.  The normal is the column with the
-    // largest diagonal entry, scaled; what is left after taking n n^T away is the distance from the form.
+    const size_t m = (size_t)(n > 0 ? n : 1);
+    std::vector<double> nrm(m * 3, 0.0), c6;
+    // The engine's own form, C = I - kappa n n^T  <=>  (I - C) / kappa = n n^T: symmetric, rank one, trace one.  The normal is
+    // the column with the largest diagonal entry, scaled; what is left after taking n n^T away is the distance from the form.
+    // A cloud whose matrices ALL have it keeps its normals and runs the product kernels.  Otherwise the matrices are kept as
+    // they are (symmetric and finite is all the closed-form Jacobian of SURVEY 8a / a7 needs) and the cloud's registrations
+    // run through the full-matrix evaluation, one pair at a time (solve_kernels.hip: accumulate_general_kernel).
     constexpr double tol = 1e-8;
+    bool normal_form = true;
+    int first_general = -1;
     for (int d = 0; d < n; ++d) {
       const int ci = c.caller_index(d);
       const double* C9 = cov9 + (size_t)ci * 9;
-      double M[3][3];
-      bool ok = true;
+      bool finite = true, symmetric = true;
       for (int a = 0; a < 3; ++a)
         for (int b = 0; b < 3; ++b) {
-          M[a][b] = ((a == b ? 1.0 : 0.0) - C9[3 * a + b]) / kappa;
-          ok = ok && std::isfinite(M[a][b]);
+          finite = finite && std::isfinite(C9[3 * a + b]);
+          symmetric = symmetric && std::fabs(C9[3 * a + b] - C9[3 * b + a]) <= tol * (1.0 + std::fabs(C9[3 * a + b]));
         }
-      int col = 0;
-      if (M[1][1] > M[col][col]) col = 1;
-      if (M[2][2] > M[col][col]) col = 2;
-      double nv[3] = {0, 0, 0};
-      if (ok && M[col][col] > 0.0) {
-        const double s = 1.0 / std::sqrt(M[col][col]);
-        for (int a = 0; a < 3; ++a) nv[a] = M[a][col] * s;
-        const double len = std::sqrt(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]);
-        ok = std::fabs(len - 1.0) <= tol;
-        for (int a = 0; a < 3 && ok; ++a)
-          for (int b = 0; b < 3; ++b) ok = ok && std::fabs(M[a][b] - nv[a] * nv[b]) <= tol && std::fabs(C9[3 * a + b] - C9[3 * b + a]) <= tol;
-        if (ok) for (int a = 0; a < 3; ++a) nv[a] /= len;
-      } else {
-        ok = false;
-      }
-      if (!ok) {
+      if (!finite || !symmetric) {
         char msg[256];
-        std::snprintf(msg, sizeof msg, "sicp_set_covariances: the covariance of point %d is not I - (1 - epsilon) n n^T with a unit n and epsilon = %g "
-                                       "(the form impl/semantic_point_cloud.hpp:25-84 produces and this engine evaluates); nothing was changed", ci, P.epsilon);
+        std::snprintf(msg, sizeof msg, "sicp_set_covariances: the covariance of point %d is not a finite symmetric 3x3 matrix; nothing was changed", ci);
         h->last_error = msg;
         return SICP_ERR_INVALID_ARGUMENT;
       }
+      if (!normal_form) continue;
+      double M[3][3];
+      for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) M[a][b] = ((a == b ? 1.0 : 0.0) - C9[3 * a + b]) / kappa;
+      int col = 0;
+      if (M[1][1] > M[col][col]) col = 1;
+      if (M[2][2] > M[col][col]) col = 2;
+      bool ok = M[col][col] > 0.0;
+      double nv[3] = {0, 0, 0};
+      if (ok) {
+        const double sc = 1.0 / std::sqrt(M[col][col]);
+        for (int a = 0; a < 3; ++a) nv[a] = M[a][col] * sc;
+        const double len = std::sqrt(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]);
+        ok = std::fabs(len - 1.0) <= tol;
+        for (int a = 0; a < 3 && ok; ++a)
+          for (int b = 0; b < 3; ++b) ok = ok && std::fabs(M[a][b] - nv[a] * nv[b]) <= tol;
+        if (ok) for (int a = 0; a < 3; ++a) nv[a] /= len;
+      }
+      if (!ok) { normal_form = false; first_general = ci; continue; }
       nrm[3 * (size_t)d] = nv[0]; nrm[3 * (size_t)d + 1] = nv[1]; nrm[3 * (size_t)d + 2] = nv[2];
     }
-    const size_t m = (size_t)(n > 0 ? n : 1);
+    if (!normal_form) {
+      if (P.mode == SICP_MODE_EM) {  // (its align() recomputes covariances and label histograms together: impl/em_icp.hpp:28-29)
+        char msg[256];
+        std::snprintf(msg, sizeof msg, "sicp_set_covariances: the covariance of point %d is not I - (1 - epsilon) n n^T (epsilon = %g); general matrices are taken "
+                                       "in SICP_MODE_GICP / SICP_MODE_SEMANTIC only; nothing was changed", first_general, P.epsilon);
+        h->last_error = msg;
+        return SICP_ERR_INVALID_ARGUMENT;
+      }
+      std::fill(nrm.begin(), nrm.end(), 0.0);  // (the records of such a cloud carry positions only)
+      c6.assign(m * 6, 0.0);
+      for (int d = 0; d < n; ++d) {
+        const double* C9 = cov9 + (size_t)c.caller_index(d) * 9;
+        double* o = &c6[6 * (size_t)d];
+        o[0] = C9[0]; o[1] = 0.5 * (C9[1] + C9[3]); o[2] = 0.5 * (C9[2] + C9[6]); o[3] = C9[4]; o[4] = 0.5 * (C9[5] + C9[7]); o[5] = C9[8];
+      }
+    }
     HIPCHECK(c.rec.reserve(m));
     HIPCHECK(c.rec_dense.reserve(sicp::dense_rec_bytes(n)));
+    if (!normal_form) HIPCHECK(c.cov6.reserve(m * 6));
     DevBuf<double> d_nrm;
     HIPCHECK(d_nrm.reserve(m * 3));
     if (n == 0) HIPCHECK(hipMemsetAsync(c.rec.p, 0, sizeof(sicp::PointRec), h->stream));  // (compute_features: the record dead slots are evaluated on)
     if (n > 0) HIPCHECK(hipMemcpyAsync(d_nrm.p, nrm.data(), sizeof(double) * 3 * n, hipMemcpyHostToDevice, h->stream));
+    if (n > 0 && !normal_form) HIPCHECK(hipMemcpyAsync(c.cov6.p, c6.data(), sizeof(double) * 6 * n, hipMemcpyHostToDevice, h->stream));
     HIPCHECK(sicp::launch_set_normals(n, c.x.p, c.y.p, c.z.p, d_nrm.p, c.rec.p, c.rec_dense.p, n, h->stream));
-    HIPCHECK(hipStreamSynchronize(h->stream));  // (nrm / d_nrm go out of scope)
+    HIPCHECK(hipStreamSynchronize(h->stream));  // (nrm / c6 / d_nrm go out of scope)
     c.rec_dense_n = n;
     c.feat_valid = true;
+    c.cov_general = !normal_form;
     c.proj_valid = false;
     c.feat_k = P.k_cov; c.feat_C = 0;
     c.feat_float_products = P.quirk_float_products;
@@ -675,6 +712,11 @@ int sicp_covariances(sicp_handle h, int which, double* cov9, double* normal3, ui
     const int n = c.n, k = P.k_cov;
     std::vector<sicp::PointRec> rec(n);
     if (n > 0) HIPCHECK(hipMemcpyAsync(rec.data(), c.rec.p, sizeof(sicp::PointRec) * n, hipMemcpyDeviceToHost, h->stream));
+    std::vector<double> g6;  // caller covariances of general form: what is there is what comes back
+    if (c.cov_general && n > 0) {
+      g6.resize((size_t)n * 6);
+      HIPCHECK(hipMemcpyAsync(g6.data(), c.cov6.p, sizeof(double) * 6 * n, hipMemcpyDeviceToHost, h->stream));
+    }
     std::vector<uint8_t> hh;
     std::vector<int> nn;
     const size_t HS = (size_t)sicp::hist_stride(P.num_classes);  // rows are padded to 16 bytes on the device
@@ -698,10 +740,17 @@ int sicp_covariances(sicp_handle h, int which, double* cov9, double* normal3, ui
     for (int d = 0; d < n; ++d) {
       const int i = c.caller_index(d);
       const double v[3] = {rec[d].nx, rec[d].ny, rec[d].nz};
+      if (!g6.empty()) {  // (no normal belongs to a general matrix)
+        const double* q = &g6[6 * (size_t)d];
+        const double full[9] = {q[0], q[1], q[2], q[1], q[3], q[4], q[2], q[4], q[5]};
+        if (cov9) std::memcpy(cov9 + 9 * (size_t)i, full, sizeof full);
+        if (normal3) for (int a = 0; a < 3; ++a) normal3[3 * (size_t)i + a] = std::numeric_limits<double>::quiet_NaN();
+      } else {
       if (normal3) { normal3[3 * (size_t)i] = v[0]; normal3[3 * (size_t)i + 1] = v[1]; normal3[3 * (size_t)i + 2] = v[2]; }
       if (cov9)  // the covariance the kernels use: C = I - (1-eps) n n^T  (== em_icp.hpp:331-338)
         for (int a = 0; a < 3; ++a)
           for (int b = 0; b < 3; ++b) cov9[9 * (size_t)i + 3 * a + b] = (a == b ? 1.0 : 0.0) - ome * v[a] * v[b];
+      }
       if (hist) std::memcpy(hist + (size_t)i * P.num_classes, hh.data() + (size_t)d * HS, P.num_classes);
       if (nn_idx)
         for (int j = 0; j < k; ++j) {

@@ -33,8 +33,9 @@ bool solo_allowed(sicp_context* h) {
 // the inner ceres::Solve (em_icp.hpp:162-177) on the current correspondences
 int run_solve(sicp_context* h, const double* init_qt, double* out_qt, SolveResult* res) {
   const sicp_params& P = h->params;
-  if (!P.lm_on_device) {
-    // host loop: one kernel pair + one 224-byte read-back + one synchronisation per evaluation
+  if (!P.lm_on_device || general_covariances(h)) {
+    // host loop: one kernel pair + one 224-byte read-back + one synchronisation per evaluation (also the path of a pair with
+    // caller covariances of general form: eval28 evaluates it with the full-matrix kernel)
     sicp::LmState s;
     sicp::lm_init(s, lm_options(P), init_qt);
     while (s.status == sicp::LM_RUNNING) {
@@ -463,6 +464,11 @@ int align_batch(sicp_handle* hs, int32_t n, const double* init_qt, double* out_q
       return SICP_ERR_INVALID_ARGUMENT;
     }
     SICPCHECK(check_ready(h, false));
+    if (general_covariances(h)) {
+      if (n == 1) return align_host_loop(h, init_qt, out_qt, outer_iters, stats);
+      h->last_error = "sicp_align_batch: a handle with caller covariances of general form (not I - (1 - epsilon) n n^T) registers one pair at a time (sicp_align)";
+      return SICP_ERR_INVALID_ARGUMENT;
+    }
   }
   const sicp_params& P = L->params;
   const double t_begin = now_ms();

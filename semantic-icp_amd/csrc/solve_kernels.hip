@@ -1119,6 +1119,107 @@ __global__ __launch_bounds__(BS, 1) void solve_one_kernel(const SoloArgs A) {
 #endif
 }
 
+// ------------------------------------------------------------------------------------------
+// The evaluation on FULL covariance matrices: a pair whose covariances are the caller's own and not of the form
+// I - (1-eps) n n^T (sicp_set_covariances; impl/semantic_icp.hpp:73,77 registers with whatever sits in labeledCovariances).
+// gicp_cost_function.h:27-73 as written there -- A = C_t + R C_s R^T, its inverse by cofactors, r = res^T A^-1 res -- chained
+// with LocalParameterizationSE3 in the closed form that holds for SYMMETRIC covariances:
+// a = A^-1 res, b = R^T a, c = p_s + C_s b, J = [-2 b ; 2 (b x c)].  Losses, Corrector and the 28 sums as in compute_group.
+// One pair at a time, a plain lane-per-slot loop (no staging, no pipelining): the path of an exotic input, not of the metric.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load_cov6(const double* __restrict__ cov6, const PointRec& r, int i, double one_m_eps, double (&C)[6]) {
+  if (cov6) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) C[k] = cov6[6 * (size_t)i + k];
+  } else {  // I - (1 - eps) n n^T
+    C[0] = 1.0 - one_m_eps * r.nx * r.nx; C[1] = -one_m_eps * r.nx * r.ny; C[2] = -one_m_eps * r.nx * r.nz;
+    C[3] = 1.0 - one_m_eps * r.ny * r.ny; C[4] = -one_m_eps * r.ny * r.nz; C[5] = 1.0 - one_m_eps * r.nz * r.nz;
+  }
+}
+
+template <bool SQLOSS>
+__global__ __launch_bounds__(256) void accumulate_general_kernel(GenAccArgs G) {
+  __shared__ double s_w[4][28];
+  const AccArgs& a = G.a;
+  const int total = a.n_s * a.K, chunk = blockIdx.x;
+  const int per = (total + G.n_chunks - 1) / G.n_chunks;
+  const int s0 = chunk * per, s1 = min(total, s0 + per);
+  const double* R = a.pose.R;
+  const double loss_b = a.loss.cauchy_a * a.loss.cauchy_a, loss_c = 1.0 / loss_b;
+  double acc[28];
+#pragma unroll
+  for (int k = 0; k < 28; ++k) acc[k] = 0.0;
+  for (int s = s0 + (int)threadIdx.x; s < s1; s += 256) {
+    const int j = a.idx[s];
+    if (j < 0) continue;
+    const int i = s / a.K;
+    const double w = a.w ? a.w[s] : 1.0;
+    const PointRec sr = a.srec[i], tr = a.trec[j];
+    double Cs[6], Ct[6];
+    load_cov6(G.scov6, sr, i, a.one_m_eps, Cs);
+    load_cov6(G.tcov6, tr, j, a.one_m_eps, Ct);
+    const double ps[3] = {(double)sr.x, (double)sr.y, (double)sr.z};
+    const double res[3] = {(double)tr.x - (R[0] * ps[0] + R[1] * ps[1] + R[2] * ps[2] + a.pose.t[0]),
+                           (double)tr.y - (R[3] * ps[0] + R[4] * ps[1] + R[5] * ps[2] + a.pose.t[1]),
+                           (double)tr.z - (R[6] * ps[0] + R[7] * ps[1] + R[8] * ps[2] + a.pose.t[2])};
+    // T = R C_s (C_s symmetric: xx xy xz yy yz zz), A = C_t + T R^T
+    const double S[3][3] = {{Cs[0], Cs[1], Cs[2]}, {Cs[1], Cs[3], Cs[4]}, {Cs[2], Cs[4], Cs[5]}};
+    double T[3][3], A[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) T[r][c] = R[3 * r] * S[0][c] + R[3 * r + 1] * S[1][c] + R[3 * r + 2] * S[2][c];
+    const double Tm[3][3] = {{Ct[0], Ct[1], Ct[2]}, {Ct[1], Ct[3], Ct[4]}, {Ct[2], Ct[4], Ct[5]}};
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) A[r][c] = Tm[r][c] + (T[r][0] * R[3 * c] + T[r][1] * R[3 * c + 1] + T[r][2] * R[3 * c + 2]);
+    // inverse by cofactors (Eigen's Matrix3d::inverse())
+    const double c00 = A[1][1] * A[2][2] - A[1][2] * A[2][1], c01 = A[1][2] * A[2][0] - A[1][0] * A[2][2], c02 = A[1][0] * A[2][1] - A[1][1] * A[2][0];
+    const double det = A[0][0] * c00 + A[0][1] * c01 + A[0][2] * c02, inv = 1.0 / det;
+    const double I00 = c00 * inv, I01 = (A[0][2] * A[2][1] - A[0][1] * A[2][2]) * inv, I02 = (A[0][1] * A[1][2] - A[0][2] * A[1][1]) * inv;
+    const double I10 = c01 * inv, I11 = (A[0][0] * A[2][2] - A[0][2] * A[2][0]) * inv, I12 = (A[0][2] * A[1][0] - A[0][0] * A[1][2]) * inv;
+    const double I20 = c02 * inv, I21 = (A[0][1] * A[2][0] - A[0][0] * A[2][1]) * inv, I22 = (A[0][0] * A[1][1] - A[0][1] * A[1][0]) * inv;
+    const double av[3] = {I00 * res[0] + I01 * res[1] + I02 * res[2], I10 * res[0] + I11 * res[1] + I12 * res[2],
+                          I20 * res[0] + I21 * res[1] + I22 * res[2]};
+    const double r = res[0] * av[0] + res[1] * av[1] + res[2] * av[2];
+    const double b[3] = {R[0] * av[0] + R[3] * av[1] + R[6] * av[2], R[1] * av[0] + R[4] * av[1] + R[7] * av[2],
+                         R[2] * av[0] + R[5] * av[1] + R[8] * av[2]};
+    const double cv[3] = {ps[0] + (S[0][0] * b[0] + S[0][1] * b[1] + S[0][2] * b[2]), ps[1] + (S[1][0] * b[0] + S[1][1] * b[1] + S[1][2] * b[2]),
+                          ps[2] + (S[2][0] * b[0] + S[2][1] * b[1] + S[2][2] * b[2])};
+    const double J[6] = {-2.0 * b[0], -2.0 * b[1], -2.0 * b[2], 2.0 * (b[1] * cv[2] - b[2] * cv[1]), 2.0 * (b[2] * cv[0] - b[0] * cv[2]),
+                         2.0 * (b[0] * cv[1] - b[1] * cv[0])};
+    double sum, rho1;
+    loss_rho1<SQLOSS>(loss_c, r * r, w, sum, rho1);
+    if (!SQLOSS) rho1 *= w;
+    int o = 0;
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
+      const double jp = rho1 * J[p];
+#pragma unroll
+      for (int q = p; q < 6; ++q, ++o) acc[o] = FMA(jp, J[q], acc[o]);
+      acc[21 + p] = FMA(jp, r, acc[21 + p]);
+    }
+    const unsigned off = log_entry_offset(sum) >> 3;  // (doubles)
+    acc[27] = FMA(0.5 * w, loss_b * log_from_entry(sum, kLogTable[off], kLogTable[off + 1]), acc[27]);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 28; ++k) {
+    const double v = wave_sum(acc[k]);
+    if (lane == 0) s_w[wave][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 28) a.partials[(size_t)threadIdx.x * G.n_chunks + chunk] = (s_w[0][threadIdx.x] + s_w[1][threadIdx.x]) + (s_w[2][threadIdx.x] + s_w[3][threadIdx.x]);
+}
+
+hipError_t launch_accumulate_general(const GenAccArgs& g, hipStream_t st) {
+  if (g.n_chunks <= 0) return hipSuccess;
+  if (g.a.loss.use_sqloss) hipLaunchKernelGGL(accumulate_general_kernel<true>, dim3(g.n_chunks), dim3(256), 0, st, g);
+  else hipLaunchKernelGGL(accumulate_general_kernel<false>, dim3(g.n_chunks), dim3(256), 0, st, g);
+  return hipGetLastError();
+}
+
 __global__ __launch_bounds__(REDUCE_THREADS) void finalize_batch_kernel(const BatchArgs* __restrict__ batch, double* out28) {
   const BatchArgs& B = batch[blockIdx.x];
   __shared__ double s_part[4][28];

@@ -223,6 +223,7 @@ int compute_features(sicp_context* h, Cloud& c, bool with_hist, hipStream_t stre
   if (h->collect) h->collect->cov[h->collect->slice].push_back(a);
   else HIPCHECK(sicp::launch_cov(a, stream));
   c.feat_valid = true;
+  c.cov_general = false;  // (what the engine computes is of its own form)
   c.proj_valid = false;
   c.feat_k = k; c.feat_C = with_hist ? P.num_classes : 0;
   c.feat_float_products = P.quirk_float_products;
@@ -412,6 +413,8 @@ const int kMaxActivePairs = [] { const char* e = std::getenv("SICP_MAX_ACTIVE");
 // One evaluation sweep at pose qt: the batched kernel on a batch of one (every path -- a pair alone, a
 // lock-step batch, the host-loop solve, this hook -- runs the SAME accumulate kernel, so they agree bit
 // for bit), then the fixed-order sum of the chunk partials.
+bool general_covariances(const sicp_context* h) { return h->cloud(0).cov_general || h->cloud(1).cov_general; }
+
 int eval28(sicp_context* h, const double* qt, double* out28) {
   SICPCHECK(batch_reserve(h, 1));
   const int nb = sicp::accumulate_blocks(h->corr_n * h->corr_K, h->corr_K);
@@ -425,7 +428,18 @@ int eval28(sicp_context* h, const double* qt, double* out28) {
   *h->ts[0].h_bhdr = sicp::BatchHeader{1, h->ts[0].epoch_host, {0, 0}};
   HIPCHECK(hipMemcpyAsync(h->ts[0].d_bhdr.p, h->ts[0].h_bhdr, sizeof(sicp::BatchHeader), hipMemcpyHostToDevice, h->stream));
   HIPCHECK(hipMemcpyAsync(h->ts[0].d_batch.p, h->ts[0].h_batch, sizeof(sicp::BatchArgs), hipMemcpyHostToDevice, h->stream));
-  {
+  if (general_covariances(h)) {
+    // caller covariances of general form: the literal cost function on full 3x3 matrices, the same columns for the same sum
+    sicp::GenAccArgs g;
+    g.a = B.a;
+    g.scov6 = h->cloud(0).cov_general ? h->cloud(0).cov6.p : nullptr;
+    g.tcov6 = h->cloud(1).cov_general ? h->cloud(1).cov6.p : nullptr;
+    g.n_chunks = nb;
+    KernelTimer kt(h, SICP_PROFILE_ACC);
+    HIPCHECK(sicp::launch_accumulate_general(g, h->stream));
+    h->st.acc_launches += 1;
+    h->st.acc_kernel_ms += kt.stop();
+  } else {
     KernelTimer kt(h, SICP_PROFILE_ACC);  // the accumulate kernel alone
     HIPCHECK(sicp::launch_accumulate_batch(h->corr_K, h->params.use_sqloss, h->ts[0].d_bhdr.p, h->ts[0].d_batch.p, std::min(h->ts[0].cap, kMaxActivePairs), h->stream));
     h->st.acc_launches += 1;

@@ -147,6 +147,7 @@ static void stream_worker_loop(sicp_stream_ctx* S) {
       }
       FeatureMarks before[2] = {FeatureMarks(h->cl[0].get()), FeatureMarks(h->cl[1].get())};
       int rc = check_ready(h, false);
+      if (rc == SICP_OK && general_covariances(h)) rc = SICP_ERR_INVALID_ARGUMENT;  // (caller covariances of general form: sicp_align, one pair at a time)
       // SICP_SUBMIT_FRESH_FEATURES: this registration recomputes the features of both its clouds, like an align() of
       // the reference (the slot's epoch is new, so align_begin finds them stale)
       h->params.reuse_features = (fresh[k].flags & SICP_SUBMIT_FRESH_FEATURES) ? 0 : 1;

@@ -156,7 +156,8 @@ class GICP {
     if (!shared_target_from_) detail::check(detail::set_cloud(h, SICP_TARGET, *targetCloud_, false), h, "sicp_set_cloud_strided");
     // The covariances of the 3-argument setters.  The reference's align() overwrites them (impl/gicp.hpp:33-34), and so does
     // this engine -- unless keepFeatures(true) asked for a cloud's covariances to be kept across align() calls: then the
-    // caller's are the ones kept, and a matrix the engine cannot take (not I - (1 - epsilon) n n^T) is refused loudly.
+    // caller's are the ones kept: of the engine's form on the product kernels, any other symmetric matrix on the full-matrix
+    // path (sicp_set_covariances); what is no covariance at all (not symmetric, not finite) is refused loudly.
     if (reuse_features_ && source_cov_supplied_) push_covariances(h, SICP_SOURCE, *sourceCovariances_);
     if (reuse_features_ && target_cov_supplied_ && !shared_target_from_) push_covariances(h, SICP_TARGET, *targetCovariances_);
   }

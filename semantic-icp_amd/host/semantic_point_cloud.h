@@ -159,9 +159,10 @@ class SemanticPointCloud {
 
   // impl/semantic_icp.hpp:73,77 registers with whatever sits in labeledCovariances.  A vector that is not the one this class
   // made for its label -- the caller assigned its own, or filled the entry of a label added with computeCov = false -- is
-  // handed to the engine (sicp_set_covariances), which takes covariances of the form I - (1 - epsilon) n n^T and REFUSES
-  // anything else: check() throws, nothing is silently replaced.  (Matrices edited in place inside a vector this class made
-  // are not seen: assign a vector.)
+  // handed to the engine (sicp_set_covariances): matrices of the form I - (1 - epsilon) n n^T keep the product kernels, other
+  // symmetric matrices are evaluated as they are on the full-matrix path (one pair at a time), and what is no covariance at
+  // all (not symmetric, not finite) is REFUSED -- check() throws, nothing is silently replaced.  (Matrices edited in place inside
+  // a vector this class made are not seen: assign a vector.)
   void push_supplied_covariances(sicp_handle h, int n) {
     std::map<SemanticT, MatricesVectorPtr>& plain = labeledCovariances;
     bool any = false;

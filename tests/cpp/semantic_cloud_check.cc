@@ -5,7 +5,8 @@
 //   2. read AFTER transform() they are still the covariances of the cloud as it was added (the reference never updates them)
 //   3. SemanticIterativeClosestPoint::align on the shared device clouds == sicp_align on the flattened clouds, bit for bit,
 //      twice in a row with the same target object (its device cloud and covariances are reused)
-//   5. a caller's own vector in labeledCovariances is handed to the engine (taken when it has the engine's form, refused loudly otherwise)
+//   5. a caller's own vector in labeledCovariances is handed to the engine (the engine's form: product kernels; another symmetric form:
+//      the full-matrix path; no covariance at all: refused loudly)
 //   4. sicp_destroy parks a handle, sicp_create hands it out again, sicp_release_pool lets go of it
 #include <algorithm>
 #include <cmath>
@@ -109,15 +110,29 @@ int main(int argc, char** argv) {
       double dmax = 0;
       for (int i = 0; i < 7; ++i) dmax = std::max(dmax, std::fabs(icp.getFinalTransFormation().data()[i] - want[i]));
       std::printf("supplied_covariances_of_the_engines_form_are_taken %d\n", (int)(dmax < 1e-9));
-      // (b) a matrix the engine cannot evaluate (not I - (1 - eps) n n^T): refused with an exception, never ignored
+      // (b) a matrix that is no covariance (not symmetric): refused with an exception, never ignored
       SemCloud::MatricesVectorPtr bad(new SemCloud::MatricesVector(*copy));
-      (*bad)[3](0, 0) = 2.0; (*bad)[3](1, 1) = 3.0;
+      (*bad)[3](0, 1) += 0.25;
       src2->labeledCovariances[l0] = bad;
       semanticicp::SemanticIterativeClosestPoint<pcl::PointXYZ, uint32_t> icp2;
       icp2.setInputSource(src2); icp2.setInputTarget(sb);
       bool thrown = false;
       try { icp2.align(fin2); } catch (const std::runtime_error& e) { thrown = std::strstr(e.what(), "sicp_set_covariances") != nullptr; }
-      std::printf("supplied_covariances_of_another_form_are_refused_loudly %d\n", (int)thrown);
+      std::printf("supplied_covariances_that_are_no_covariances_are_refused_loudly %d\n", (int)thrown);
+      // (c) symmetric matrices of ANOTHER form (here diag(0.5, 1, 2) everywhere in one label): taken, evaluated on the full
+      //     matrices -- a different registration problem, so a different answer, and still a registration
+      std::shared_ptr<SemCloud> src3(new SemCloud()), fin3(new SemCloud());
+      semanticicp::pcl_2_semantic(A, src3); semanticicp::pcl_2_semantic(A, fin3);
+      SemCloud::MatricesVectorPtr gen(new SemCloud::MatricesVector(*src3->labeledCovariances[l0]));
+      for (auto& M3 : *gen) { M3 = Eigen::Matrix3d::Identity(); M3(0, 0) = 0.5; M3(2, 2) = 2.0; }
+      src3->labeledCovariances[l0] = gen;
+      semanticicp::SemanticIterativeClosestPoint<pcl::PointXYZ, uint32_t> icp3;
+      icp3.setInputSource(src3); icp3.setInputTarget(sb);
+      icp3.align(fin3);
+      double d3 = 0;
+      bool fin_ok = true;
+      for (int i = 0; i < 7; ++i) { d3 = std::max(d3, std::fabs(icp3.getFinalTransFormation().data()[i] - want[i])); fin_ok = fin_ok && std::isfinite(icp3.getFinalTransFormation().data()[i]); }
+      std::printf("supplied_covariances_of_general_form_are_taken %d max_pose_component_difference %.3e\n", (int)(fin_ok && d3 > 1e-9 && d3 < 0.2), d3);
     }
     // ---- 4
     sicp_handle h1 = nullptr, h2 = nullptr;

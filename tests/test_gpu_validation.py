@@ -3,6 +3,7 @@ an organized RGB-D cloud -- pcl::KdTreeFLANN::setInputCloud leaves them out of i
 em_icp.h:50-66 / SURVEY appendix A.3), an all-coincident cloud, a one-point cloud, an empty source.
 The checker is the oracle run on the cloud WITHOUT the non-finite points, with indices mapped back."""
 import importlib
+import os
 
 import numpy as np
 import pytest
@@ -571,16 +572,17 @@ def test_caller_supplied_covariances_are_taken_or_refused():
         osol, oinfo = O.solve(op, src, cs, tgt, ct, idx, w, IDENT)
         rot, trn = pose_delta(osol, sol)
         assert info["lm_iters"] == oinfo["lm_iters"] and rot < 1e-7 and trn < 1e-7
-        # a matrix of another form: refused, named, nothing changed
-        bad = cs.copy()
-        bad[17] = np.diag([1.0, 2.0, 3.0])                  # (the shape of exec/test_gradient.cc:32-50's fixture)
-        with pytest.raises(sicp.SicpError) as err:
-            e.set_covariances(sicp.SOURCE, bad)
-        assert err.value.status == sicp.ERR_INVALID_ARGUMENT and "point 17" in str(err.value)
+        # a matrix that is no covariance at all (not symmetric, not finite): refused, named, nothing changed
         unsym = cs.copy()
         unsym[5, 0, 1] += 1e-3
-        with pytest.raises(sicp.SicpError):
+        with pytest.raises(sicp.SicpError) as err:
             e.set_covariances(sicp.SOURCE, unsym)
+        assert err.value.status == sicp.ERR_INVALID_ARGUMENT and "point 5" in str(err.value)
+        nonfinite = cs.copy()
+        nonfinite[17, 2, 2] = np.nan
+        with pytest.raises(sicp.SicpError) as err:
+            e.set_covariances(sicp.SOURCE, nonfinite)
+        assert "point 17" in str(err.value)
         assert np.array_equal(e.accumulate(qt), out)
         kept, _ = e.align(IDENT)                            # reuse_features = 1: align() keeps the caller's
     with make_engine(sicp.MODE_GICP) as e0:                 # the reference's align(): covariances recomputed from the cloud
@@ -602,3 +604,71 @@ def test_caller_supplied_covariances_are_taken_or_refused():
         es.set_covariances(sicp.SOURCE, c_other)
         other, _ = es.align(IDENT)
         assert np.abs(other - base).max() > 1e-9            # and different covariances give a different answer: they are read
+
+
+def _spd(rng, n, lo=0.05, hi=1.5):
+    """n random symmetric positive definite 3x3 matrices (eigenvalues in [lo, hi]): NOT of the form I - (1-eps) n n^T"""
+    q, _ = np.linalg.qr(rng.normal(size=(n, 3, 3)))
+    lam = rng.uniform(lo, hi, size=(n, 3))
+    return np.einsum("nij,nj,nkj->nik", q, lam, q)
+
+
+def test_caller_covariances_of_general_form_run_on_the_full_matrix_path():
+    """Covariances that are not of the engine's form -- arbitrary symmetric matrices, what impl/semantic_icp.hpp:73,77 would
+    register with if a caller put them into labeledCovariances, and what exec/test_gradient.cc:32-50 feeds the cost function --
+    are taken as they are and evaluated by accumulate_general_kernel (gicp_cost_function.h:27-73 on full 3x3 matrices), with the
+    trust-region loop on the host.  Checked against the oracle's literal Evaluate / LM on the very same matrices: (1) the
+    reference's own gradient-check fixture, one correspondence, 10 poses; (2) 8000-point clouds with random SPD covariances in
+    one cloud and the engine's form in the other: evaluation sweep, inner solve, a whole align(); (3) batches and streams
+    answer with a status, EM mode refuses."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "costfn.npz"))
+    # entries 0..9 of the golden file: exec/test_gradient.cc:32-50's tuple (float32 points, its two matrices -- the target's is
+    # not even positive definite) at ten random poses, with the residual and a central-difference local Jacobian
+    ps, pt, Cs, Ct = g["ps"][0].astype(np.float32), g["pt"][0].astype(np.float32), g["Cs"][0], g["Ct"][0]
+    op = oracle_params(O.MODE_GICP)
+    with make_engine(sicp.MODE_GICP, reuse_features=1, gate_sq=1e12) as e:
+        e.set_source(ps.reshape(1, 3)); e.set_target(pt.reshape(1, 3))
+        e.set_covariances(sicp.SOURCE, Cs.reshape(1, 9)); e.set_covariances(sicp.TARGET, Ct.reshape(1, 9))
+        back, nn_, _, _ = e.covariances(sicp.SOURCE)
+        assert np.array_equal(back.reshape(3, 3), Cs) and np.isnan(nn_).all()
+        for k in range(10):
+            qt = g["qts"][k]
+            idx, d2, w = e.correspondences(qt)
+            assert idx.reshape(-1).tolist() == [0]
+            out = e.accumulate(qt)
+            ref = O.accumulate(op, qt, ps.reshape(1, 3), Cs.reshape(1, 3, 3), pt.reshape(1, 3), Ct.reshape(1, 3, 3), idx, w)
+            assert np.allclose(out, ref, rtol=1e-9, atol=1e-9 * np.abs(ref).max()), (k, out, ref)
+            # one correspondence: g = rho1 r J is parallel to the local Jacobian, which the golden file has by finite differences
+            gv, jfd = out[21:27], g["jac6_fd"][k] * np.sign(g["residual"][k])
+            assert np.allclose(gv / np.linalg.norm(gv), jfd / np.linalg.norm(jfd), atol=1e-5), k
+    src, sl, tgt, tl, T, cm = synth.lidar_pair(seed=9, n_points=8000)
+    rng = np.random.default_rng(11)
+    cs = _spd(rng, len(src))
+    qt = mat_to_qt(T)
+    with make_engine(sicp.MODE_GICP, reuse_features=1) as e:
+        e.set_source(src); e.set_target(tgt)
+        ct, _, _, _ = e.covariances(sicp.TARGET)             # the target keeps the engine's own (normal-form) covariances
+        e.set_covariances(sicp.SOURCE, cs)
+        idx, d2, w = e.correspondences(IDENT)
+        out = e.accumulate(qt)
+        ref = O.accumulate(op, qt, src, cs, tgt, ct, idx, w)
+        assert np.allclose(out, ref, rtol=1e-9, atol=1e-9 * np.abs(ref).max())
+        sol, info = e.solve(IDENT)
+        osol, oinfo = O.solve(op, src, cs, tgt, ct, idx, w, IDENT)
+        rot, trn = pose_delta(osol, sol)
+        assert info["lm_iters"] == oinfo["lm_iters"] and rot < 1e-7 and trn < 1e-7
+        pose, st = e.align(IDENT)                            # the whole outer loop runs (host loop), registers the pair
+        rot, trn = pose_delta(qt, pose)
+        assert st["outer_iters"] >= 2 and rot < 2e-2 and trn < 0.2
+        # one pair at a time: a batch of two and a stream say so
+        with make_engine(sicp.MODE_GICP, reuse_features=1) as e2:
+            e2.set_source(src); e2.set_target(tgt)
+            with pytest.raises(RuntimeError):
+                sicp.align_batch([e, e2])
+            with pytest.raises(RuntimeError):
+                sicp.accumulate_batch([e, e2], np.array([qt, qt]))
+    with make_engine(sicp.MODE_EM, 11, cm) as em:            # EM-ICP recomputes covariances and histograms together
+        em.set_source(src, sl); em.set_target(tgt, tl)
+        with pytest.raises(sicp.SicpError) as err:
+            em.set_covariances(sicp.SOURCE, cs)
+        assert err.value.status == sicp.ERR_INVALID_ARGUMENT and "SICP_MODE_GICP" in str(err.value)

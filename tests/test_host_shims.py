@@ -415,5 +415,6 @@ def test_semantic_point_cloud_lives_on_the_device_and_handles_are_pooled(tmp_pat
     got = {line.split()[0]: int(line.split()[1]) for line in r.stdout.splitlines() if line.strip()}
     assert got == {"lazy_covariances_equal_per_label_clouds": 1, "covariances_after_transform_are_those_of_the_added_cloud": 1,
                    "align_on_shared_device_clouds_equals_flat_c_abi": 1, "destroyed_handle_is_reused_and_fresh": 1,
-                   "supplied_covariances_of_the_engines_form_are_taken": 1, "supplied_covariances_of_another_form_are_refused_loudly": 1,
+                   "supplied_covariances_of_the_engines_form_are_taken": 1, "supplied_covariances_that_are_no_covariances_are_refused_loudly": 1,
+                   "supplied_covariances_of_general_form_are_taken": 1,
                    "release_pool_frees_parked_handles": 1}, r.stdout
