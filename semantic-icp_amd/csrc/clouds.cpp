@@ -106,38 +106,47 @@ int prepare_cloud(sicp_context* h, Cloud& c) {
   // ---- host: segment membership and per-segment bounding boxes (one pass over the cloud)
   c.seg_label.clear();
   std::vector<int> which(want ? n : 0), counts;
+  const float inf = std::numeric_limits<float>::infinity();
+  std::vector<float> lo, hi;  // [3 per segment]
   if (want == 0) {
     c.seg_label.push_back(0);
     counts.push_back(n);
+    lo.assign(3, inf); hi.assign(3, -inf);
+    if (c.bb_valid) {  // one segment: its box came with the staging pass
+      for (int d = 0; d < 3; ++d) { lo[d] = c.bb_lo[d]; hi[d] = c.bb_hi[d]; }
+    } else {
+      for (int i = 0; i < n; ++i) {
+        const float p[3] = {c.hx[i], c.hy[i], c.hz[i]};
+        for (int d = 0; d < 3; ++d) { lo[d] = std::min(lo[d], p[d]); hi[d] = std::max(hi[d], p[d]); }
+      }
+    }
   } else {
-    // pcl_2_semantic.h:24-39: one sub-cloud per label, labels in order of first appearance
-    // (the previous point's segment first: a cloud that arrives label by label -- SemanticPointCloud's -- or in image
-    //  order, where runs of one label are long, then costs one compare per point instead of one per label seen so far)
+    // pcl_2_semantic.h:24-39: one sub-cloud per label, labels in order of first appearance -- and, in the same pass over the
+    // points, every segment's bounding box.  (The previous point's segment first: a cloud that arrives label by label --
+    // SemanticPointCloud's -- or in image order, where runs of one label are long, costs one compare per point instead of
+    // one per label seen so far.)
     int last = -1;
     for (int i = 0; i < n; ++i) {
       const uint32_t l = c.hl[i];
       int sidx = (last >= 0 && c.seg_label[(size_t)last] == l) ? last : -1;
       for (size_t k = 0; sidx < 0 && k < c.seg_label.size(); ++k)
         if (c.seg_label[k] == l) sidx = (int)k;
-      if (sidx < 0) { sidx = (int)c.seg_label.size(); c.seg_label.push_back(l); counts.push_back(0); }
+      if (sidx < 0) {
+        sidx = (int)c.seg_label.size();
+        c.seg_label.push_back(l); counts.push_back(0);
+        lo.insert(lo.end(), 3, inf); hi.insert(hi.end(), 3, -inf);
+      }
       which[i] = sidx;
       counts[sidx]++;
       last = sidx;
+      float* L = &lo[3 * (size_t)sidx];
+      float* H = &hi[3 * (size_t)sidx];
+      const float px = c.hx[i], py = c.hy[i], pz = c.hz[i];
+      L[0] = std::min(L[0], px); L[1] = std::min(L[1], py); L[2] = std::min(L[2], pz);
+      H[0] = std::max(H[0], px); H[1] = std::max(H[1], py); H[2] = std::max(H[2], pz);
     }
   }
   const int n_seg = (int)c.seg_label.size();
-  const float inf = std::numeric_limits<float>::infinity();
-  std::vector<float> lo(3 * n_seg, inf), hi(3 * n_seg, -inf);
-  if (!want && c.bb_valid)  // one segment: its box came with the staging pass
-    for (int d = 0; d < 3; ++d) { lo[d] = c.bb_lo[d]; hi[d] = c.bb_hi[d]; }
-  for (int i = 0; i < ((!want && c.bb_valid) ? 0 : n); ++i) {
-    const int sg = want ? which[i] : 0;
-    const float p[3] = {c.hx[i], c.hy[i], c.hz[i]};
-    for (int d = 0; d < 3; ++d) {
-      if (p[d] < lo[3 * sg + d]) lo[3 * sg + d] = p[d];
-      if (p[d] > hi[3 * sg + d]) hi[3 * sg + d] = p[d];
-    }
-  }
   c.seg_off.assign(n_seg + 1, 0);
   c.trees.assign(n_seg, Cloud::SegTree());
   std::vector<sicp::BuildSegment> segs(n_seg);

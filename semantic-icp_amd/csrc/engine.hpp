@@ -398,6 +398,7 @@ struct sicp_context {
   double* h_out28 = nullptr;      // pinned, 28 doubles
   long long* h_count = nullptr;   // pinned
   DevBuf<float> tmpx, tmpy, tmpz;
+  DevBuf<double> tmp9;  // sicp_covariances: the 3x3 matrices in the caller's order on their way out
   DevBuf<uint32_t> tmpl;
   HostBuf<uint32_t> h_labels;  // pinned: fused labels of a stream slot on their way back
   // lock-step batch (sicp_align_batch), owned by the batch's first handle: one BatchArgs and one LM

@@ -472,6 +472,34 @@ __global__ __launch_bounds__(256) void set_normals_kernel(int n, const float* __
   }
 }
 
+__global__ __launch_bounds__(256) void cov9_caller_order_kernel(int n, const PointRec* __restrict__ rec, const double* __restrict__ cov6,
+                                                                const int* __restrict__ perm, double one_m_eps, double* __restrict__ out9) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= n) return;
+  double* o = out9 + 9 * (size_t)perm[d];
+  if (cov6) {
+    const double* q = cov6 + 6 * (size_t)d;
+    o[0] = q[0]; o[1] = q[1]; o[2] = q[2]; o[3] = q[1]; o[4] = q[3]; o[5] = q[4]; o[6] = q[2]; o[7] = q[4]; o[8] = q[5];
+  } else {
+    const double v[3] = {rec[d].nx, rec[d].ny, rec[d].nz};
+    // the upper triangle, mirrored: bit-symmetric (rows == columns), the host loop's expression and bits
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = a; b < 3; ++b) {
+        const double e = (a == b ? 1.0 : 0.0) - one_m_eps * v[a] * v[b];
+        o[3 * a + b] = e;
+        o[3 * b + a] = e;
+      }
+  }
+}
+
+hipError_t launch_cov9_caller_order(int n, const PointRec* rec, const double* cov6, const int* perm, double one_m_eps, double* out9, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(cov9_caller_order_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, rec, cov6, perm, one_m_eps, out9);
+  return hipGetLastError();
+}
+
 hipError_t launch_set_normals(int n, const float* x, const float* y, const float* z, const double* normal3, PointRec* rec, char* rec_dense,
                               int rec_dense_n, hipStream_t st) {
   if (n <= 0) return hipSuccess;

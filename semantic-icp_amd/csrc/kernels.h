@@ -285,6 +285,9 @@ hipError_t launch_bvh_knn_quad(int K, const KnnArgs& a, hipStream_t st);
 hipError_t launch_bvh_knn_packet(int K, const KnnArgs& a, hipStream_t st);
 hipError_t launch_cov(const CovArgs& a, hipStream_t st);
 hipError_t launch_proj(const ProjArgs& a, hipStream_t st);
+// sicp_covariances' fast path: the n 3x3 matrices (row-major) in the CALLER's point order, formed on the device from the records'
+// normals (C = I - (1 - eps) n n^T) or from the caller's own general matrices (cov6 != nullptr); perm = device -> caller index
+hipError_t launch_cov9_caller_order(int n, const PointRec* rec, const double* cov6, const int* perm, double one_m_eps, double* out9, hipStream_t st);
 // caller-supplied normals (sicp_set_covariances): the point records and their dense copy, as cov_kernel writes them
 hipError_t launch_set_normals(int n, const float* x, const float* y, const float* z, const double* normal3, PointRec* rec, char* rec_dense,
                               int rec_dense_n, hipStream_t st);

@@ -710,6 +710,16 @@ int sicp_covariances(sicp_handle h, int which, double* cov9, double* normal3, ui
     // what align() left behind is returned as it is (getSourceCovariances(), gicp.h:72-90)
     if (!features_current(h, c, with_hist) || (nn_idx && !c.nn.p)) SICPCHECK(compute_features(h, c, with_hist));
     const int n = c.n, k = P.k_cov;
+    if (cov9 && !normal3 && !hist && !nn_idx && c.keep.empty() && n > 0) {
+      // the covariances alone of a cloud without dropped points (getSourceCovariances() / getTargetCovariances(), gicp.h:72-90,
+      // called once per pair by exec/kitti_eval.cc:225-226): formed in the caller's order on the device and copied straight
+      // into the caller's array -- one pass instead of a record read-back, a scatter on the host and the caller's own copy
+      HIPCHECK(h->tmp9.reserve((size_t)n * 9));
+      HIPCHECK(sicp::launch_cov9_caller_order(n, c.rec.p, c.cov_general ? c.cov6.p : nullptr, c.d_perm.p, 1.0 - P.epsilon, h->tmp9.p, h->stream));
+      HIPCHECK(hipMemcpyAsync(cov9, h->tmp9.p, sizeof(double) * 9 * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+      HIPCHECK(hipStreamSynchronize(h->stream));
+      return SICP_OK;
+    }
     std::vector<sicp::PointRec> rec(n);
     if (n > 0) HIPCHECK(hipMemcpyAsync(rec.data(), c.rec.p, sizeof(sicp::PointRec) * n, hipMemcpyDeviceToHost, h->stream));
     std::vector<double> g6;  // caller covariances of general form: what is there is what comes back
@@ -747,9 +757,13 @@ int sicp_covariances(sicp_handle h, int which, double* cov9, double* normal3, ui
         if (normal3) for (int a = 0; a < 3; ++a) normal3[3 * (size_t)i + a] = std::numeric_limits<double>::quiet_NaN();
       } else {
       if (normal3) { normal3[3 * (size_t)i] = v[0]; normal3[3 * (size_t)i + 1] = v[1]; normal3[3 * (size_t)i + 2] = v[2]; }
-      if (cov9)  // the covariance the kernels use: C = I - (1-eps) n n^T  (== em_icp.hpp:331-338)
-        for (int a = 0; a < 3; ++a)
-          for (int b = 0; b < 3; ++b) cov9[9 * (size_t)i + 3 * a + b] = (a == b ? 1.0 : 0.0) - ome * v[a] * v[b];
+      if (cov9)  // the covariance the kernels use: C = I - (1-eps) n n^T  (== em_icp.hpp:331-338); the upper triangle, mirrored:
+        for (int a = 0; a < 3; ++a)  // bit-symmetric, so the rows a caller reads are also the columns Eigen stores
+          for (int b = a; b < 3; ++b) {
+            const double e = (a == b ? 1.0 : 0.0) - ome * v[a] * v[b];
+            cov9[9 * (size_t)i + 3 * a + b] = e;
+            cov9[9 * (size_t)i + 3 * b + a] = e;
+          }
       }
       if (hist) std::memcpy(hist + (size_t)i * P.num_classes, hh.data() + (size_t)d * HS, P.num_classes);
       if (nn_idx)

@@ -181,11 +181,7 @@ class GICP {
     if (!out) out = MatricesVectorPtr(new MatricesVector());
     out->resize(n);
     if (n == 0) return;
-    std::vector<double> c9((size_t)n * 9);
-    detail::check(sicp_covariances(h, which, c9.data(), nullptr, nullptr, nullptr), h, "sicp_covariances");
-    for (int i = 0; i < n; ++i)
-      for (int a = 0; a < 3; ++a)
-        for (int b = 0; b < 3; ++b) (*out)[i](a, b) = c9[(size_t)i * 9 + 3 * a + b];
+    detail::check(sicp_covariances(h, which, detail::matrix3d_storage(out->data()), nullptr, nullptr, nullptr), h, "sicp_covariances");
   }
 
   int kCorrespondences_;

@@ -10,6 +10,7 @@
 #ifndef SEMANTIC_POINT_CLOUD_H_
 #define SEMANTIC_POINT_CLOUD_H_
 #include <algorithm>
+#include <cstring>
 #include <map>
 #include <memory>
 #include <set>
@@ -213,9 +214,7 @@ class SemanticPointCloud {
         MatricesVectorPtr& v = plain[s];
         if (!v) v = MatricesVectorPtr(new MatricesVector());
         v->resize(m);
-        for (size_t i = 0; i < m; ++i)
-          for (int a = 0; a < 3; ++a)
-            for (int b = 0; b < 3; ++b) (*v)[i](a, b) = c9[(at + i) * 9 + 3 * a + b];
+        if (m > 0) std::memcpy(detail::matrix3d_storage(v->data()), &c9[at * 9], sizeof(double) * 9 * m);  // (bit-symmetric: rows == columns)
       }
       at += m;
     }

@@ -84,6 +84,14 @@ inline int stream_add_cloud(sicp_stream s, const pcl::PointCloud<PointT>& c, boo
                                        (int64_t)sizeof(PointT), id);
 }
 
+// sicp_covariances writes n row-major 3x3 matrices; an Eigen::Matrix3d is nine contiguous doubles, column-major -- and the
+// engine's matrices are BIT-symmetric (upper triangle mirrored), so its rows are Eigen's columns: the storage of a
+// std::vector<Eigen::Matrix3d> is the output array, no staging vector and no conversion pass
+inline double* matrix3d_storage(Eigen::Matrix3d* m) {
+  static_assert(sizeof(Eigen::Matrix3d) == 9 * sizeof(double), "Eigen::Matrix3d is nine doubles");
+  return reinterpret_cast<double*>(m);
+}
+
 inline Sophus::SE3d to_se3(const double* qt) {
 #if defined(SICP_HAVE_REAL_DEPS)
   Sophus::SE3d s;
