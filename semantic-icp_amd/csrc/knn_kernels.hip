@@ -187,8 +187,8 @@ __device__ __forceinline__ void quad_merge_round(u64 (&bk)[K]) {
     for (int i = 0; i < 4; ++i) bk[i] = key_min(bk[i], pb[3 - i]);
     key_cswap(bk[0], bk[2]); key_cswap(bk[1], bk[3]); key_cswap(bk[0], bk[1]); key_cswap(bk[2], bk[3]);
   } else {
-    static_assert(K > 16 && K <= 32, "list lengths 20 and 32");
-    constexpr int N = 32;
+    static_assert(K > 4 && K <= 32, "list lengths 20 and 32 (and the 8 / 12 / 16 of timing experiments)");
+    constexpr int N = K <= 8 ? 8 : (K <= 16 ? 16 : 32);
     u64 l[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
@@ -1156,7 +1156,11 @@ hipError_t launch_bvh_knn_packet_jobs(int K, const KnnArgs* jobs, int n, hipStre
     switch (K) {
       case 1: SICP_PKJ(1, 4); break;
       case 4: SICP_PKJ(4, 4); break;
+#if defined(SICP_EXPERIMENT_K20_LISTS)  // timing experiment only: the k = 20 self-search with SHORTER per-lane lists -- wrong beyond that many entries
+      case 20: SICP_PKJ(SICP_EXPERIMENT_K20_LISTS, 2); break;
+#else
       case 20: SICP_PKJ(20, 2); break;
+#endif
       case 32: SICP_PKJ(32, 2); break;
       default: return hipErrorInvalidValue;
     }
