@@ -354,7 +354,8 @@ struct TickSet {
   sicp::LmJoin* h_join = nullptr;  // pinned: the pairs that join with the next tick
   DevBuf<sicp::LmJoin> d_join;
   int cap = 0;
-  sicp::BatchGraph graph;
+  sicp::BatchGraph graph[2];   // [1]: the accumulate nodes carry kAccStaticRanges (static_ranges below)
+  bool static_ranges = false;  // the next ticks' large accumulate launches keep equal chunk ranges (a stream while scans are being uploaded)
   std::vector<int> tick_act;  // the pairs whose arguments d_batch currently holds
   bool tick_valid = false;
   unsigned epoch_host = 0;    // mirror of d_bhdr->epoch_base: tick_prepare_kernel adds kMaxBatchLen per tick, and so does the host
@@ -460,6 +461,7 @@ struct sicp_stream_ctx {
   std::unordered_map<long long, std::shared_ptr<Cloud>> clouds;
   long long next_cloud = 1, next_ticket = 1;
   long long submitted = 0, completed = 0, busy_evals = 0, slot_evals = 0;
+  std::atomic<double> last_add_ms{-1e18};  // when the last scan was added (its upload + tree build run beside the ticks)
   int draining = 0;  // callers blocked in sicp_stream_poll(wait >= 2): nothing new will be submitted by them meanwhile
   int in_flight = 0;
   bool stop = false;
@@ -656,6 +658,7 @@ struct BatchRun {
   int len = 8;                  // LM evaluations per tick
   bool one_launch = true, want_stats = false;
   bool solo = false;            // the last pair still iterating may run its solve as persistent launches (lm_on_device != 2)
+  bool acc_static = false;      // equal chunk ranges in the accumulate launches of the next tick (TickSet::static_ranges)
   hipStream_t side = nullptr;   // searches / features of the pairs between two inner solves
   struct Start { double q[7]; };
   std::vector<OuterState> o;

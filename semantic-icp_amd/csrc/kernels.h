@@ -263,14 +263,15 @@ constexpr int kMaxBatchLen = 32;
 struct BatchGraph {
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
-  int len = 0, K = 0, sqloss = 0, capacity = 0, fold = 0;
+  int len = 0, K = 0, sqloss = 0, capacity = 0, fold = 0, static_ranges = 0;
   const BatchArgs* batch = nullptr;
   const BatchHeader* hdr = nullptr;
 };
 // *built is set to 1 when the graph had to be (re)instantiated
-// fold != 0: [tick_prepare, accumulate x len] (the accumulate launches step the LM machines: AccArgs::ein is set)
+// fold != 0: [tick_prepare, accumulate x len] (the accumulate launches step the LM machines: AccArgs::ein is set);
+// static_ranges: every accumulate node carries kAccStaticRanges
 hipError_t batch_graph_prepare(BatchGraph& g, int K, int use_sqloss, const BatchHeader* hdr, const BatchArgs* batch, int capacity, int len,
-                               int* built, int fold = 0);
+                               int* built, int fold = 0, int static_ranges = 0);
 void batch_graph_destroy(BatchGraph& g);
 
 // neighbour-list length the search kernels run with for a request of k neighbours (the k nearest
@@ -300,7 +301,9 @@ hipError_t launch_em_weight_jobs(const WeightArgs* jobs, int n, hipStream_t st);
 hipError_t launch_count_active_jobs(const CountJob* jobs, int n, hipStream_t st);
 int accumulate_blocks(int total, int K);  // chunks of a pair with `total` slots, K correspondences per source point
 // every pair of the batch in one launch: hdr / batch in HBM, capacity = slots of the batch buffers
-// node = index of the launch inside its tick (its epoch is hdr->epoch_base + node; only read by pairs with AccArgs::ein)
+// node = index of the launch inside its tick (its epoch is hdr->epoch_base + node; only read by pairs with AccArgs::ein),
+// optionally | kAccStaticRanges: equal contiguous chunk ranges even for a large launch (see accumulate_staged_kernel)
+constexpr int kAccStaticRanges = 0x40000000;
 hipError_t launch_accumulate_batch(int K, int use_sqloss, const BatchHeader* hdr, const BatchArgs* batch, int capacity, hipStream_t st, int node = 0);
 hipError_t launch_lm_step_batch(const BatchHeader* hdr, const BatchArgs* batch, int capacity, hipStream_t st);
 // first kernel of a tick whose accumulate launches step the LM machines themselves: advances hdr->epoch_base and

@@ -231,7 +231,8 @@ int destroy_for_real(sicp_context* h) {
       if (S.h_batch) (void)hipHostFree(S.h_batch);
       if (S.h_join) (void)hipHostFree(S.h_join);
       if (S.h_bhdr) (void)hipHostFree(S.h_bhdr);
-      sicp::batch_graph_destroy(S.graph);
+      sicp::batch_graph_destroy(S.graph[0]);
+      sicp::batch_graph_destroy(S.graph[1]);
     }
     if (h->h_bstates) (void)hipHostFree(h->h_bstates);
     if (h->h_solo_flag) (void)hipHostFree(h->h_solo_flag);

@@ -230,15 +230,16 @@ int tick_launch(sicp_context* h, TickSet& S, hipStream_t M, sicp_handle* hs, int
     const int cap = std::min(S.cap, kMaxActivePairs);
     if (fold) HIPCHECK(sicp::launch_tick_prepare(S.d_bhdr.p, S.d_batch.p, M));
     for (int b = 0; b < len; ++b) {
-      HIPCHECK(sicp::launch_accumulate_batch(hs[act[0]]->corr_K, h->params.use_sqloss, S.d_bhdr.p, S.d_batch.p, cap, M, b));
+      HIPCHECK(sicp::launch_accumulate_batch(hs[act[0]]->corr_K, h->params.use_sqloss, S.d_bhdr.p, S.d_batch.p, cap, M, b | (S.static_ranges ? sicp::kAccStaticRanges : 0)));
       if (!fold) HIPCHECK(sicp::launch_lm_step_batch(S.d_bhdr.p, S.d_batch.p, cap, M));
     }
   } else {
     int built = 0;
-    HIPCHECK(sicp::batch_graph_prepare(S.graph, hs[act[0]]->corr_K, h->params.use_sqloss, S.d_bhdr.p, S.d_batch.p, std::min(S.cap, kMaxActivePairs),
-                                       len, &built, fold ? 1 : 0));
+    sicp::BatchGraph& graph = S.graph[S.static_ranges ? 1 : 0];
+    HIPCHECK(sicp::batch_graph_prepare(graph, hs[act[0]]->corr_K, h->params.use_sqloss, S.d_bhdr.p, S.d_batch.p, std::min(S.cap, kMaxActivePairs),
+                                       len, &built, fold ? 1 : 0, S.static_ranges ? 1 : 0));
     h->st.graph_builds += built;
-    HIPCHECK(hipGraphLaunch(S.graph.exec, M));
+    HIPCHECK(hipGraphLaunch(graph.exec, M));
   }
   if (fold) S.epoch_host += (unsigned)sicp::kMaxBatchLen;  // (what tick_prepare_kernel has just been queued to do)
   HIPCHECK(hipMemcpyAsync(h->h_bstates + lo, h->d_bstates.p + lo, sizeof(sicp::LmState) * (hi - lo), hipMemcpyDeviceToHost, M));
@@ -435,6 +436,7 @@ int BatchRun::turn(TickGroup& G, JobCollector& jc) {
   }
   const double dbg_t_launch0 = now_ms();
   dbg_search_ms += dbg_t_launch0 - dbg_t_search0;
+  G.S->static_ranges = acc_static;
   int rc = tick_launch(h, *G.S, G.M, hs, G.lo, G.hi, G.act, G.joining, reinterpret_cast<const double(*)[7]>(starts.data()), len,
                        solo_now ? (n == 1 ? sicp::kSoloMaxEvals : 64) : 0);
   dbg_launch_ms += now_ms() - dbg_t_launch0;

@@ -449,6 +449,7 @@ static_assert(28 % RED_ROWS == 0 && RED_ROWS * 4 <= 64, "one lane per (row, quar
 #define SICP_COMB_CHUNKS 8
 #endif
 constexpr int COMB_CHUNKS = SICP_COMB_CHUNKS;  // chunks whose four wave sums wait in LDS for one combining pass
+constexpr unsigned kRunsPerWorkgroupForDynamic = 8u;  // accumulate launches with at least this many 8-chunk runs per workgroup hand their chunks out dynamically
 __device__ __forceinline__ void wave_reduce(const double (&acc)[28], SICP_LDS double* tile, SICP_LDS double* out28, int lane) {
   const int r = lane >> 2, q = lane & 3;
   const SICP_LDS v2d* mine = (const SICP_LDS v2d*)(tile + min(r, RED_ROWS - 1) * RED_STRIDE + 16 * q);
@@ -694,7 +695,7 @@ __global__ __launch_bounds__(BS, SICP_ACC_OCC) void accumulate_staged_kernel(con
   const int n_pairs = hdr->n_pairs;
   if (n_pairs <= 0) return;
   // this launch's epoch (pairs whose LM machine is stepped inside the launch: AccArgs::ein, see EvalIn in kernels.h)
-  const unsigned epoch = (unsigned)uniform_i32((int)(hdr->epoch_base + (unsigned)node));
+  const unsigned epoch = (unsigned)uniform_i32((int)(hdr->epoch_base + (unsigned)(node & 0xffff)));
   (void)epoch;
   for (int k = threadIdx.x; k < kLogTableEntries; k += BS) reinterpret_cast<v2d*>(log_tab)[k] = reinterpret_cast<const v2d*>(kLogTable)[k];
   for (int p = threadIdx.x; p < n_pairs; p += BS) {
@@ -737,11 +738,54 @@ __global__ __launch_bounds__(BS, SICP_ACC_OCC) void accumulate_staged_kernel(con
   // dispatched to different CUs; spreading b * T / G would put two working groups on some CUs and none
   // on others).  T <= 512 pairs x 1024 chunks and gridDim.x < 2^12: the products fit 32 bits.
   const unsigned T = (unsigned)total_running, G = gridDim.x, b = blockIdx.x;
+  SICP_LDS char* stage = (SICP_LDS char*)stage_all + wave * (SG * STAGE_SLOT_BYTES);
+  SICP_LDS double* tile = (SICP_LDS double*)smem + wave * (RED_ROWS * RED_STRIDE);
+#if !defined(SICP_ACC_STATIC_RANGES) && !defined(SICP_DEV_PROBES)
+  // Work split (round 6): the chunks of the running pairs are handed out in RUNS of consecutive chunks by an agent-scope
+  // counter, not as equal static ranges.  In a tick the accumulate workgroups are dispatched beside the search kernels of the
+  // side stream and start up to hundreds of microseconds apart (an 80 KB / 4 x 196-register workgroup only gets onto a CU as
+  // search workgroups drain), and with static ranges the launch lasts as long as its latest starter: 184.0 -> 177.2 ms per
+  // 256-pair step (+3.8 % correspondences/s), and 805 -> 793 us for the launch alone (profiles/r06/dynamic_runs_ab.json).
+  // A chunk's column does not depend on who computes it: the same bits.  A run is 8 chunks (what is parked in LDS between two
+  // combining passes); the next run's index is requested before the current run is processed (its round trip hides behind
+  // the pipeline fill).  ONLY launches with at least 8 runs per workgroup are split this way: every run pays a pipeline fill and
+  // two barriers, and with few runs per workgroup their granularity unbalances the launch -- shorter runs were measured too
+  // (T / 4G chunks): 16 full-size pairs 56.9 against 44.4 ms per step, the open stream's ramp-up 1.9 K against 2.0 K pairs/s --
+  // so smaller launches keep the equal contiguous ranges of rounds 2-5.  The two counters live in the header
+  // (BatchHeader::pad_) and are reset by the last workgroup to leave -- everyone has made its last fetch by then.
+  // (-DSICP_ACC_STATIC_RANGES: the equal contiguous ranges of rounds 2-5, for A/B.)
+  unsigned* const next_run = reinterpret_cast<unsigned*>(const_cast<int*>(&hdr->pad_[0]));
+  unsigned* const left = reinterpret_cast<unsigned*>(const_cast<int*>(&hdr->pad_[1]));
+  constexpr unsigned run = (unsigned)COMB_CHUNKS;
+  // (the same for every workgroup of the launch; kAccStaticRanges in `node`: the host asks for equal ranges -- a stream while scans
+  //  are being uploaded: a launch whose workgroups all stay to the end leaves the tree-build kernels of the upload stream, whose sorts
+  //  need LDS, no CU to get onto except between launches: 1.9 K instead of 2.0 K pairs/s end to end)
+  const bool by_runs = !(node & kAccStaticRanges) && T >= kRunsPerWorkgroupForDynamic * run * G;
+  __shared__ unsigned s_run;
+  unsigned fetched = 0u;
+  if (by_runs && threadIdx.x == 0) fetched = __hip_atomic_fetch_add(next_run, run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (bool first_pass = true;; first_pass = false) {
+  int item, item_end;
+  if (by_runs) {
+    if (threadIdx.x == 0) s_run = fetched;
+    __syncthreads();
+    item = (int)s_run;
+    if ((unsigned)item >= T) break;
+    if (threadIdx.x == 0) fetched = __hip_atomic_fetch_add(next_run, run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    item_end = (int)min((unsigned)item + run, T);
+  } else {
+    // equal contiguous ranges; with fewer chunks than workgroups, one chunk each for the FIRST workgroups (they are dispatched
+    // to different CUs; spreading b * T / G would put two working groups on some CUs and none on others)
+    if (!first_pass) break;
+    item = T < G ? (int)b : (int)(b * T / G);
+    item_end = T < G ? (b < T ? (int)b + 1 : (int)b) : (int)((b + 1) * T / G);
+    if (item >= item_end) break;
+  }
+#else
   int item = T < G ? (int)b : (int)(b * T / G);
   const int item_end = T < G ? (b < T ? (int)b + 1 : (int)b) : (int)((b + 1) * T / G);
   if (item >= item_end) return;
-  SICP_LDS char* stage = (SICP_LDS char*)stage_all + wave * (SG * STAGE_SLOT_BYTES);
-  SICP_LDS double* tile = (SICP_LDS double*)smem + wave * (RED_ROWS * RED_STRIDE);
+#endif
 
 #ifdef SICP_DEV_PROBES
   // developer build only (-DSICP_DEV_PROBES, tools/corun_probe.py): hdr->pad_[0] > 1 repeats the workgroup's whole range
@@ -833,6 +877,17 @@ __global__ __launch_bounds__(BS, SICP_ACC_OCC) void accumulate_staged_kernel(con
 #endif
   }
 #ifdef SICP_DEV_PROBES
+  }
+#endif
+#if !defined(SICP_ACC_STATIC_RANGES) && !defined(SICP_DEV_PROBES)
+  __syncthreads();  // (s_run is rewritten at the top)
+  }
+  if (by_runs && threadIdx.x == 0) {
+    const unsigned gone = __hip_atomic_fetch_add(left, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (gone + 1u == G) {  // the last one out: the next launch finds the counters at zero
+      __hip_atomic_store(next_run, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(left, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 #endif
 }
@@ -1395,11 +1450,12 @@ void batch_graph_destroy(BatchGraph& g) {
 }
 
 hipError_t batch_graph_prepare(BatchGraph& g, int K, int use_sqloss, const BatchHeader* hdr, const BatchArgs* batch, int capacity, int len,
-                               int* built, int fold) {
+                               int* built, int fold, int static_ranges) {
   *built = 0;
   void* fn = accumulate_fn(K, use_sqloss);
   if (capacity <= 0 || len < 1 || len > kMaxBatchLen || !fn) return hipErrorInvalidValue;
-  if (g.exec && g.K == K && g.sqloss == use_sqloss && g.len == len && g.batch == batch && g.hdr == hdr && g.capacity == capacity && g.fold == fold)
+  if (g.exec && g.K == K && g.sqloss == use_sqloss && g.len == len && g.batch == batch && g.hdr == hdr && g.capacity == capacity && g.fold == fold &&
+      g.static_ranges == static_ranges)
     return hipSuccess;
   batch_graph_destroy(g);
   int node = 0;
@@ -1425,7 +1481,7 @@ hipError_t batch_graph_prepare(BatchGraph& g, int K, int use_sqloss, const Batch
     prev = step;
   }
   for (int b = 0; b < len; ++b) {
-    node = b;
+    node = b | (static_ranges ? kAccStaticRanges : 0);
     e = hipGraphAddKernelNode(&acc, g.graph, prev ? &prev : nullptr, prev ? 1 : 0, &pa);
     if (e != hipSuccess) return e;
     prev = acc;
@@ -1437,7 +1493,7 @@ hipError_t batch_graph_prepare(BatchGraph& g, int K, int use_sqloss, const Batch
   }
   e = hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0);
   if (e != hipSuccess) return e;
-  g.K = K; g.sqloss = use_sqloss; g.len = len; g.batch = batch; g.hdr = hdr; g.capacity = capacity; g.fold = fold;
+  g.K = K; g.sqloss = use_sqloss; g.len = len; g.batch = batch; g.hdr = hdr; g.capacity = capacity; g.fold = fold; g.static_ranges = static_ranges;
   *built = 1;
   return hipSuccess;
 }

@@ -206,6 +206,9 @@ static void stream_worker_loop(sicp_stream_ctx* S) {
     dbg_flush_ms += t_turn0 - t_flush0;
     // ---- one turn
     {
+      // scans still arriving: their tree-build kernels (sorts that need LDS) run beside the ticks, and only get onto a CU when
+      // an accumulate workgroup leaves it -- which the dynamic split of a large launch postpones to the launch's very end
+      run.acc_static = now_ms() - S->last_add_ms.load(std::memory_order_relaxed) < 5.0;
       const int rc = run.turn(G, jc);
       if (rc != SICP_OK) { stream_fail(S, rc, L->last_error); return; }
     }
@@ -469,6 +472,7 @@ static int stream_add_common(sicp_stream S, int32_t n, const StridedCloud& in, i
   SICPCHECK(stage_cloud(h, *c, n, in));
   SICPCHECK(prepare_cloud(h, *c));  // H2D + search-tree build queued on the upload stream; ready_ev recorded
   SICPCHECK(reserve_features(h, *c));  // (here, on the submitting thread: never inside the worker's turn)
+  S->last_add_ms.store(now_ms(), std::memory_order_relaxed);
   std::lock_guard<std::mutex> lock(S->m);
   const long long id = S->next_cloud++;
   S->clouds.emplace(id, std::move(c));
