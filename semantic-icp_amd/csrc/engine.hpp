@@ -594,6 +594,7 @@ struct SolveResult {
   double cost = 0;
 };
 
+hipError_t create_side_stream(hipStream_t* st);  // the stream of a batch's / a stream's searches and feature kernels (SICP_SIDE_PRIORITY: A/B aid)
 bool solo_allowed(sicp_context* h);
 bool general_covariances(const sicp_context* h);  // either cloud carries caller covariances of general form
 int align_host_loop(sicp_context* h, const double* init_qt, double* out_qt, int32_t* outer_iters, sicp_stats* stats);

@@ -119,6 +119,17 @@ int batch_reserve(sicp_context* h, int n) {
 
 // Build-time experiment of round 6 (-DSICP_LM_STEP_IN_LAUNCH, then SICP_LM_STEP_IN_LAUNCH=1): the LM step of a tick inside its
 // accumulate launches (solve_kernels.hip says what it measured: slower).  The product's tick is [accumulate, lm_step_batch] x len.
+// The searches / weights / feature kernels of the pairs between two solves run on a stream of their own beside the ticks.
+// SICP_SIDE_PRIORITY=low|high (developer A/B aid): that stream with the device's lowest / highest queue priority.
+hipError_t create_side_stream(hipStream_t* st) {
+  static const int mode = [] { const char* e = std::getenv("SICP_SIDE_PRIORITY"); return !e ? 0 : (e[0] == 'l' ? 1 : (e[0] == 'h' ? 2 : 0)); }();
+  if (mode == 0) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+  int least = 0, greatest = 0;  // (numerically: greatest priority is the smaller number)
+  hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+  if (e != hipSuccess) return e;
+  return hipStreamCreateWithPriority(st, hipStreamNonBlocking, mode == 1 ? least : greatest);
+}
+
 bool lm_step_in_launch() {
 #if defined(SICP_LM_STEP_IN_LAUNCH)
   static const bool on = std::getenv("SICP_LM_STEP_IN_LAUNCH") != nullptr;
@@ -539,7 +550,7 @@ int align_batch(sicp_handle* hs, int32_t n, const double* init_qt, double* out_q
     SICPCHECK(batch_reserve(h, n));
     h->ts[0].tick_valid = false;
     if (!h->side_stream) {
-      HIPCHECK(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+      HIPCHECK(create_side_stream(&h->side_stream));
       HIPCHECK(hipEventCreateWithFlags(&h->side_done, hipEventDisableTiming));
       HIPCHECK(hipEventCreateWithFlags(&h->main_done, hipEventDisableTiming));
     }

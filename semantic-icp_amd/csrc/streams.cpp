@@ -378,7 +378,7 @@ int sicp_stream_create(int device_id, const sicp_params* params, int32_t max_in_
       if (rc != SICP_OK) return cleanup(rc);
       h->ts[0].tick_valid = false;
       if (!h->side_stream) {
-        if (hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking) != hipSuccess ||
+        if (create_side_stream(&h->side_stream) != hipSuccess ||
             hipEventCreateWithFlags(&h->side_done, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&h->main_done, hipEventDisableTiming) != hipSuccess)
           return cleanup(SICP_ERR_HIP);
