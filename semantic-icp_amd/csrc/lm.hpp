@@ -241,8 +241,9 @@ SICP_HD inline void lm_init(LmState& s, const LmOptions& opt, const double* x0) 
   s.pending = 0; s.pad_ = 0;
 }
 
-// out28 = [H upper 21 | g 6 | cost] evaluated at s.pose
-SICP_HD inline void lm_feed(LmCore& s, const LmOptions& opt, const double* o) {
+// out28 = [H upper 21 | g 6 | cost] evaluated at s.pose.  `finite_known` >= 0: the caller has already tested the 28 sums with
+// the predicate below (the GPU does it with 28 lanes at once instead of 84 instructions of the one lane that runs this).
+SICP_HD inline void lm_feed(LmCore& s, const LmOptions& opt, const double* o, int finite_known = -1) {
   using namespace detail;
   if (s.status != LM_RUNNING) return;
   s.evaluations++;
@@ -251,9 +252,10 @@ SICP_HD inline void lm_feed(LmCore& s, const LmOptions& opt, const double* o) {
   // x0); at a candidate the step is "treated as a step with infinite cost" (trust_region_minimizer.cc:
   // candidate_cost = DBL_MAX), i.e. rejected.  Here a non-finite residual shows up as a non-finite sum.  (The cost
   // entry alone would not do: fast_log.hpp maps NaN / Inf to a finite number; H and g carry the NaN.)
-  bool finite = true;
-  SICP_UNROLL
-  for (int k = 0; k < 28; ++k) finite = finite && (o[k] - o[k] == 0.0);
+  bool finite = finite_known != 0;
+  if (finite_known < 0)
+    SICP_UNROLL
+    for (int k = 0; k < 28; ++k) finite = finite && (o[k] - o[k] == 0.0);
   if (s.phase == 0) {
     if (!finite) { s.status = LM_EVAL_FAILED; return; }
     unpack28(o, s.H, s.g, &s.cost);

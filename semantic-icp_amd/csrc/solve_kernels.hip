@@ -652,6 +652,17 @@ __device__ __forceinline__ void reduce_partials_block(const double* __restrict__
   }
 }
 
+// lm_feed's first test -- are all 28 sums finite -- by the 64 lanes of one wave from the block-shared sums reduce_partials_block
+// has just left in s_part[0] (o[k] IS s_part[0][k]): the same predicate per sum, one compare instead of 28 in the one lane
+// that steps the machine (179 of the LM step's instructions; one pair alone: -0.035 ms per align).  Call with the whole wave,
+// after reduce_partials_block.
+__device__ __forceinline__ int sums_all_finite(const double (&s_part)[4][28]) {
+  static_assert(REDUCE_PARTS == 1, "s_part[0] holds the sums themselves");
+  const int lane = threadIdx.x & 63;
+  const double v = s_part[0][min(lane, 27)];
+  return __all(v - v == 0.0) ? 1 : 0;
+}
+
 // ---- build-time experiment of round 6 (-DSICP_LM_STEP_IN_LAUNCH + SICP_LM_STEP_IN_LAUNCH=1 in the environment): the LM step
 // INSIDE the accumulate launch -- the workgroup that delivers a pair's last columns sums them all and advances the pair's
 // trust-region machine, the tick is [tick_prepare, accumulate x len] instead of [accumulate, lm_step_batch] x len.  Built,
@@ -913,9 +924,12 @@ __global__ __launch_bounds__(REDUCE_THREADS, SICP_LM_STEP_WAVES) void lm_step_ba
   double o[28];
   reduce_partials_block(B.a.partials, B.nb, s_part, o);
   if (status != LM_RUNNING) return;  // (uniform; a finished pair's partial columns are read for nothing: 44 KB)
-  if (threadIdx.x == 0) {
-    lm_feed(st, lm->opt, o);
-    *static_cast<LmCore*>(lm) = st;
+  if (threadIdx.x < 64) {
+    const int finite = sums_all_finite(s_part);
+    if (threadIdx.x == 0) {
+      lm_feed(st, lm->opt, o, finite);
+      *static_cast<LmCore*>(lm) = st;
+    }
   }
 }
 
@@ -1034,8 +1048,9 @@ __global__ __launch_bounds__(BS, 1) void solve_one_kernel(const SoloArgs A) {
       if (threadIdx.x < 64) {
         // thread 0 steps the machine; the new pose leaves as ONE store instruction of 15 lanes (15 stores of one
         // lane reach the other XCDs one after the other: ~1.5 us)
+        const int finite = sums_all_finite(s_part);
         if (threadIdx.x == 0) {
-          lm_feed(st, A.opt, o);
+          lm_feed(st, A.opt, o, finite);
           SOLO_MARK(2);
 #pragma unroll
           for (int k = 0; k < 7; ++k) {
