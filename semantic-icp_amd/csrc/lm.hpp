@@ -160,6 +160,8 @@ SICP_HD inline double gradient_max_norm(const double* x, const double* g) {
 // candidate in s.pose.  The retry loop (an invalid step halves the radius and tries again without a
 // new evaluation) only contains the 6x6 solve: x and g do not change inside it, so the gradient
 // test is done once, before it -- same decisions in the same order as testing it every time.
+// WAVE (GPU only): called by a whole wavefront whose 64 lanes hold the same state (se3.hpp "WAVE variants").
+template <bool WAVE = false>
 SICP_HD inline void lm_propose(LmCore& s, const LmOptions& opt) {
   if (s.iterations >= opt.max_iterations) { s.status = LM_ITERATION_CAP; return; }
   if (!gradient_clearly_above(s.g, opt.gradient_tolerance) && gradient_max_norm(s.x, s.g) <= opt.gradient_tolerance) {
@@ -187,6 +189,18 @@ SICP_HD inline void lm_propose(LmCore& s, const LmOptions& opt) {
     if (!s.reuse_diagonal)
       SICP_UNROLL
       for (int j = 0; j < 6; ++j) s.diag[j] = fmin(fmax(A[6 * j + j], opt.min_lm_diagonal), opt.max_lm_diagonal);
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (WAVE) {  // the six independent division + square root pairs: lane j takes diag[j] (~190 -> ~55 instructions)
+      const int lane = se3::wave::lane_id();
+      double dj = s.diag[0];
+      SICP_UNROLL
+      for (int j = 1; j < 6; ++j) dj = lane == j ? s.diag[j] : dj;
+      const double lm = sqrt(dj / s.radius);
+      const double lm2 = lm * lm;
+      SICP_UNROLL
+      for (int j = 0; j < 6; ++j) A[6 * j + j] += se3::wave::bcast(lm2, j);
+    } else
+#endif
     SICP_UNROLL
     for (int j = 0; j < 6; ++j) {
       const double lm = sqrt(s.diag[j] / s.radius);  // lm_diagonal_
@@ -218,7 +232,7 @@ SICP_HD inline void lm_propose(LmCore& s, const LmOptions& opt) {
   double delta[6];
   SICP_UNROLL
   for (int j = 0; j < 6; ++j) delta[j] = step[j] * s.scale[j];
-  se3::plus(s.x, delta, s.pose);
+  se3::plus<WAVE>(s.x, delta, s.pose);
   s.model_change = model_change;
   s.phase = 1;
 }
@@ -243,6 +257,8 @@ SICP_HD inline void lm_init(LmState& s, const LmOptions& opt, const double* x0) 
 
 // out28 = [H upper 21 | g 6 | cost] evaluated at s.pose.  `finite_known` >= 0: the caller has already tested the 28 sums with
 // the predicate below (the GPU does it with 28 lanes at once instead of 84 instructions of the one lane that runs this).
+// WAVE (GPU only): the caller is a whole wavefront, all 64 lanes with the same s and o; every lane ends with the same s.
+template <bool WAVE = false>
 SICP_HD inline void lm_feed(LmCore& s, const LmOptions& opt, const double* o, int finite_known = -1) {
   using namespace detail;
   if (s.status != LM_RUNNING) return;
@@ -286,10 +302,10 @@ SICP_HD inline void lm_feed(LmCore& s, const LmOptions& opt, const double* o, in
       s.reuse_diagonal = 1;
     }
   }
-  lm_propose(s, opt);
+  lm_propose<WAVE>(s, opt);
 }
 
-SICP_HD inline void lm_feed(LmState& s, const double* o) { lm_feed(s, s.opt, o); }
+SICP_HD inline void lm_feed(LmState& s, const double* o) { lm_feed<false>(s, s.opt, o); }
 
 }  // namespace sicp
 #endif

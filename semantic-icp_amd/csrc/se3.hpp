@@ -38,6 +38,18 @@ SICP_HD inline void sincos_pair(double a, double* s, double* c) {
 #endif
 }
 
+// WAVE variants (GPU only): the caller is a whole 64-lane wavefront whose lanes all hold the SAME operands -- running the one-lane
+// LM step on every lane costs the same instructions -- so independent pieces with the same instruction sequence go to
+// different lanes and come back with v_readlane: the same operations on the same values, the same bits.
+#if defined(__HIP_DEVICE_COMPILE__)
+namespace wave {
+__device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ double bcast(double v, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+}  // namespace wave
+#endif
+
 // Eigen Quaternion::toRotationMatrix (no normalisation), row-major
 SICP_HD inline void rotation(const double* qt, double* R) {
   const double x = qt[0], y = qt[1], z = qt[2], w = qt[3];
@@ -68,18 +80,30 @@ SICP_HD inline void matrix34(const double* qt, double* M) {
   }
 }
 
-// Sophus SE3::exp
+// Sophus SE3::exp.  WAVE: the two sincos -- of theta / 2 for the quaternion, of theta for V -- are one call, lane 1 taking
+// theta and every other lane theta / 2 (~180 of the ~470 instructions of a Plus).
+template <bool WAVE = false>
 SICP_HD inline void exp(const double* a, double* qt) {
   const double* w = a + 3;
   const double theta_sq = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
   const double theta = sqrt(theta_sq);
   double imag, real;
+  double st_w = 0, ct_w = 0;
+  (void)st_w; (void)ct_w;
   if (theta < SICP_SE3_EPS) {
     const double t4 = theta_sq * theta_sq;
     imag = 0.5 - theta_sq / 48.0 + t4 / 3840.0;
     real = 1.0 - theta_sq / 8.0 + t4 / 384.0;
   } else {
     double sh, ch;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (WAVE) {
+      double s2, c2;
+      sincos_pair(wave::lane_id() == 1 ? theta : 0.5 * theta, &s2, &c2);
+      sh = wave::bcast(s2, 0); ch = wave::bcast(c2, 0);
+      st_w = wave::bcast(s2, 1); ct_w = wave::bcast(c2, 1);
+    } else
+#endif
     sincos_pair(0.5 * theta, &sh, &ch);
     imag = sh / theta;
     real = ch;
@@ -91,6 +115,9 @@ SICP_HD inline void exp(const double* a, double* qt) {
     rotation(qt, V);
   } else {
     double st, ct;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (WAVE) { st = st_w; ct = ct_w; } else
+#endif
     sincos_pair(theta, &st, &ct);
     const double c1 = (1 - ct) / theta_sq, c2 = (theta - st) / (theta_sq * theta);
     const double W[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
@@ -174,9 +201,10 @@ SICP_HD inline void inverse(const double* a, double* out) {
 }
 
 // LocalParameterizationSE3::Plus
+template <bool WAVE = false>
 SICP_HD inline void plus(const double* qt, const double* delta, double* out) {
   double e[7];
-  exp(delta, e);
+  exp<WAVE>(delta, e);
   mul(qt, e, out);
 }
 

@@ -917,8 +917,11 @@ __global__ __launch_bounds__(REDUCE_THREADS, SICP_LM_STEP_WAVES) void lm_step_ba
   // One pair alone is a chain of ~120 (accumulate, LM step) launches, so every dependent memory round trip
   // in here is paid ~120 times: the state (thread 0) and the status are requested BEFORE the reduction's own
   // loads and arrive while it runs, instead of status -> partial columns -> state one after the other.
+  // The machine is stepped by the WHOLE first wave, every lane on its own copy of the same state (the same instructions as one
+  // lane): the independent pieces of a step with one instruction sequence -- the six sqrt(diag / radius), the two sincos of a
+  // Plus -- then run in different lanes at once (lm.hpp / se3.hpp, WAVE: ~320 of ~1500 instructions).
   LmCore st;
-  if (threadIdx.x == 0) st = *lm;  // the options stay in memory: uniform, read with scalar loads
+  if (threadIdx.x < 64) st = *lm;  // the options stay in memory: uniform, read with scalar loads
   const int status = lm->status;
   __shared__ double s_part[4][28];
   double o[28];
@@ -926,10 +929,10 @@ __global__ __launch_bounds__(REDUCE_THREADS, SICP_LM_STEP_WAVES) void lm_step_ba
   if (status != LM_RUNNING) return;  // (uniform; a finished pair's partial columns are read for nothing: 44 KB)
   if (threadIdx.x < 64) {
     const int finite = sums_all_finite(s_part);
-    if (threadIdx.x == 0) {
-      lm_feed(st, lm->opt, o, finite);
-      *static_cast<LmCore*>(lm) = st;
-    }
+#pragma unroll
+    for (int k = 0; k < 28; ++k) o[k] = s_part[0][k];
+    lm_feed<true>(st, lm->opt, o, finite);
+    if (threadIdx.x == 0) *static_cast<LmCore*>(lm) = st;
   }
 }
 
@@ -1007,8 +1010,8 @@ __global__ __launch_bounds__(BS, 1) void solve_one_kernel(const SoloArgs A) {
 
   if (blockIdx.x == 0) {
     // ------------------------------------------------------------------ the master
-    LmCore st;
-    if (threadIdx.x == 0) {
+    LmCore st;  // (a copy in every lane of the first wave: lm_feed<true>)
+    if (threadIdx.x < 64) {
       if (A.init) {
         LmState fresh;
         lm_init(fresh, A.opt, A.start);
@@ -1016,7 +1019,7 @@ __global__ __launch_bounds__(BS, 1) void solve_one_kernel(const SoloArgs A) {
       } else {
         st = *lm;
       }
-      s_status = st.status;
+      if (threadIdx.x == 0) s_status = st.status;
     }
     __syncthreads();
     for (int e = 0; e < max_evals; ++e) {
@@ -1046,11 +1049,13 @@ __global__ __launch_bounds__(BS, 1) void solve_one_kernel(const SoloArgs A) {
       reduce_partials_block<true>((const double*)col, n_chunks, s_part, o);
       SOLO_MARK(1);
       if (threadIdx.x < 64) {
-        // thread 0 steps the machine; the new pose leaves as ONE store instruction of 15 lanes (15 stores of one
-        // lane reach the other XCDs one after the other: ~1.5 us)
+        // the first wave steps the machine (every lane the same state: lm_step_batch_kernel); the new pose leaves as ONE store
+        // instruction of 15 lanes (15 stores of one lane reach the other XCDs one after the other: ~1.5 us)
         const int finite = sums_all_finite(s_part);
+#pragma unroll
+        for (int k = 0; k < 28; ++k) o[k] = s_part[0][k];
+        lm_feed<true>(st, A.opt, o, finite);
         if (threadIdx.x == 0) {
-          lm_feed(st, A.opt, o, finite);
           SOLO_MARK(2);
 #pragma unroll
           for (int k = 0; k < 7; ++k) {
