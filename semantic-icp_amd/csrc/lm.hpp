@@ -13,7 +13,10 @@
 //     while (s.status == LM_RUNNING) { evaluate out28 at s.pose;  lm_feed(s, out28); }
 // so the same code drives the host loop (sicp_api.cpp) and the device-resident solve, where
 // lm_feed runs in a one-block kernel right after each accumulate kernel and the host only looks at
-// s.status once per batch of launches (solve_kernels.hip: lm_step_batch_kernel).
+// s.status once per batch of launches (solve_kernels.hip: lm_step_batch_kernel).  On the GPU the step is taken by a whole
+// wavefront (lm_feed<true>): every lane runs the machine on its own copy of the same state, and the independent pieces with
+// one instruction sequence -- the six sqrt(diag / radius), the two sincos of se3::exp -- go to different lanes.  The same
+// operations on the same values: the same bits as the one-lane form the host runs.
 //
 // Unlike Ceres, one evaluation returns cost, gradient and H together, so an accepted step does
 // not need a second sweep at the same point (Ceres evaluates the candidate cost first and the
