@@ -396,8 +396,16 @@ int sicp_solve(sicp_handle h, const double init_qt[7], double out_qt[7], int32_t
  *   SICP_SE3_LOG  in n*7 poses                          -> out n*6
  *   SICP_SE3_PLUS in n*13 = pose (7) | delta (6)        -> out n*7 = pose * exp(delta)
  *   SICP_SE3_MUL  in n*14 = pose a (7) | pose b (7)     -> out n*7
- *   SICP_SE3_INV  in n*7                                -> out n*7 */
-enum { SICP_SE3_EXP = 0, SICP_SE3_LOG = 1, SICP_SE3_PLUS = 2, SICP_SE3_MUL = 3, SICP_SE3_INV = 4 };
+ *   SICP_SE3_INV  in n*7                                -> out n*7
+ * and the device build of csrc/lm.hpp (the inner ceres::Solve's step control, em_icp.hpp:162-177), one wavefront per item:
+ *   SICP_LM_SEQUENCE           in n*679 = start pose (7) | 24 evaluations x 28 sums [H upper 21 | g 6 | cost], fed in turn to
+ *                              the trust-region machine (csrc/lm.hpp, default options) AS THE KERNELS RUN IT -- by a whole
+ *                              wavefront, the finite test by ballot -- until it stops or the sequence ends
+ *                              -> out n*37 = pose 7 | x 7 | diag 6 | scale 6 | radius, cost, model change, decrease factor,
+ *                              |x| | status, iterations, evaluations, invalid steps, reuse_diagonal, phase
+ *   SICP_LM_SEQUENCE_ONE_LANE  the same in the one-lane form the host loop runs: the two must agree bit for bit on ANY
+ *                              sequence (the machine is a pure function of state and evaluation) */
+enum { SICP_SE3_EXP = 0, SICP_SE3_LOG = 1, SICP_SE3_PLUS = 2, SICP_SE3_MUL = 3, SICP_SE3_INV = 4, SICP_LM_SEQUENCE = 5, SICP_LM_SEQUENCE_ONE_LANE = 6 };
 int sicp_se3_device(sicp_handle h, int op, int32_t n, const double* in, double* out);
 
 /* counters accumulated since the last sicp_align() began (the hooks above add to them) */

@@ -25,6 +25,8 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 MODE_GICP, MODE_EM, MODE_SEMANTIC = 0, 1, 2
 SOURCE, TARGET = 0, 1
 SE3_EXP, SE3_LOG, SE3_PLUS, SE3_MUL, SE3_INV = 0, 1, 2, 3, 4
+LM_SEQUENCE, LM_SEQUENCE_ONE_LANE = 5, 6   # sicp_se3_device: the trust-region machine fed with given evaluations
+LM_SEQUENCE_EVALS, LM_SEQUENCE_OUT = 24, 37
 
 OK = 0
 ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_READY = -1, -2, -3, -4
@@ -408,7 +410,7 @@ class Engine:
         """sicp_se3_device: csrc/se3.hpp evaluated on the GPU (op = SE3_EXP / LOG / PLUS / MUL / INV), one row per item."""
         x = np.ascontiguousarray(x, dtype=np.float64)
         n = x.shape[0]
-        out = np.empty((n, 6 if op == SE3_LOG else 7))
+        out = np.empty((n, LM_SEQUENCE_OUT if op >= LM_SEQUENCE else 6 if op == SE3_LOG else 7))
         self._check(lib().sicp_se3_device(self._h, op, n, _ptr(x, _dp), _ptr(out, _dp)), "sicp_se3_device")
         return out
 

@@ -348,6 +348,9 @@ hipError_t launch_solve_one(int K, int use_sqloss, const SoloArgs& args, int n_c
 int solo_wait_ticks();
 hipError_t launch_count_active(const int* idx, int n, unsigned long long* out, hipStream_t st);
 // test hook: csrc/se3.hpp on the device, one lane per item (op = SICP_SE3_*; in/out strides per op)
+// op 5 / 6: the trust-region machine fed with a given sequence of evaluations, as the kernels run it (a whole wave) / as the host
+// runs it (one lane): in = n x kLmSeqIn (start pose | kLmSeqEvals x 28 sums), out = n x kLmSeqOut (the final state)
+constexpr int kLmSeqEvals = 24, kLmSeqIn = 7 + 28 * kLmSeqEvals, kLmSeqOut = 37;
 hipError_t launch_se3_ops(int op, int n, const double* in, double* out, hipStream_t st);
 hipError_t launch_transform_float(int n, const float* x, const float* y, const float* z, const Mat4f& M,
                                   float* ox, float* oy, float* oz, hipStream_t st);

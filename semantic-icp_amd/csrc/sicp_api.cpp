@@ -876,11 +876,12 @@ int sicp_fused_labels(sicp_handle h, const double qt[7], uint32_t* out_labels) {
 
 int sicp_se3_device(sicp_handle h, int op, int32_t n, const double* in, double* out) {
   return abi_guard(h, [&]() -> int {
-    if (!h || op < SICP_SE3_EXP || op > SICP_SE3_INV || n < 0 || (n > 0 && (!in || !out))) return SICP_ERR_INVALID_ARGUMENT;
+    if (!h || op < SICP_SE3_EXP || op > SICP_LM_SEQUENCE_ONE_LANE || n < 0 || (n > 0 && (!in || !out))) return SICP_ERR_INVALID_ARGUMENT;
     if (n == 0) return SICP_OK;
     SICPCHECK(set_device(h));
-    const size_t n_in = op == SICP_SE3_EXP ? 6 : (op == SICP_SE3_PLUS ? 13 : (op == SICP_SE3_MUL ? 14 : 7));
-    const size_t n_out = op == SICP_SE3_LOG ? 6 : 7;
+    const bool lm_seq = op >= SICP_LM_SEQUENCE;
+    const size_t n_in = lm_seq ? (size_t)sicp::kLmSeqIn : op == SICP_SE3_EXP ? 6 : (op == SICP_SE3_PLUS ? 13 : (op == SICP_SE3_MUL ? 14 : 7));
+    const size_t n_out = lm_seq ? (size_t)sicp::kLmSeqOut : op == SICP_SE3_LOG ? 6 : 7;
     DevBuf<double> d_in, d_out;
     HIPCHECK(d_in.reserve(n_in * n));
     HIPCHECK(d_out.reserve(n_out * n));

@@ -1322,9 +1322,49 @@ __global__ __launch_bounds__(64) void se3_ops_kernel(int op, int n, const double
   for (int k = 0; k < n_out; ++k) out[(size_t)i * n_out + k] = o[k];
 }
 
+// test hook: the trust-region machine on the device, fed with a GIVEN sequence of evaluations (lm_feed is a pure function of
+// state and evaluation, so any sequence will do: indefinite H, rejected steps, non-finite sums).  One wave per item; WAVE = the
+// form the kernels run (lm_feed<true>: every lane its own copy of the state, the finite test by ballot), otherwise the one-lane
+// form the host runs.  out = kLmSeqOut doubles of the final state.
+template <bool WAVE>
+__global__ __launch_bounds__(64, 1) void lm_feed_sequence_kernel(int n, const double* __restrict__ in, double* __restrict__ out) {
+  const int i = blockIdx.x, lane = threadIdx.x;
+  if (i >= n || (!WAVE && lane != 0)) return;
+  const double* item = in + (size_t)i * kLmSeqIn;
+  LmState s;
+  LmOptions opt;
+  double x0[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) x0[k] = item[k];
+  lm_init(s, opt, x0);
+  for (int e = 0; e < kLmSeqEvals && s.status == LM_RUNNING; ++e) {
+    double o[28];
+#pragma unroll
+    for (int k = 0; k < 28; ++k) o[k] = item[7 + 28 * e + k];
+    if (WAVE) {
+      const double v = item[7 + 28 * e + min(lane, 27)];
+      lm_feed<true>(s, opt, o, __all(v - v == 0.0) ? 1 : 0);
+    } else {
+      lm_feed<false>(s, opt, o);
+    }
+  }
+  if (lane == 0) {
+    double* r = out + (size_t)i * kLmSeqOut;
+    int k = 0;
+    for (int j = 0; j < 7; ++j) r[k++] = s.pose[j];
+    for (int j = 0; j < 7; ++j) r[k++] = s.x[j];
+    for (int j = 0; j < 6; ++j) r[k++] = s.diag[j];
+    for (int j = 0; j < 6; ++j) r[k++] = s.scale[j];
+    r[k++] = s.radius; r[k++] = s.cost; r[k++] = s.model_change; r[k++] = s.decrease_factor; r[k++] = s.x_norm;
+    r[k++] = s.status; r[k++] = s.iterations; r[k++] = s.evaluations; r[k++] = s.invalid; r[k++] = s.reuse_diagonal; r[k++] = s.phase;
+  }
+}
+
 hipError_t launch_se3_ops(int op, int n, const double* in, double* out, hipStream_t st) {
   if (n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(se3_ops_kernel, dim3((n + 63) / 64), dim3(64), 0, st, op, n, in, out);
+  if (op == 5) hipLaunchKernelGGL(lm_feed_sequence_kernel<true>, dim3(n), dim3(64), 0, st, n, in, out);
+  else if (op == 6) hipLaunchKernelGGL(lm_feed_sequence_kernel<false>, dim3(n), dim3(64), 0, st, n, in, out);
+  else hipLaunchKernelGGL(se3_ops_kernel, dim3((n + 63) / 64), dim3(64), 0, st, op, n, in, out);
   return hipGetLastError();
 }
 

@@ -81,6 +81,100 @@ def test_se3_device_against_expm_logm_golden():
         e.close()
 
 
+
+def lm_sequences(rng, n, wild):
+    """n x (start pose | 24 evaluations x [H upper 21 | g 6 | cost]) for sicp_se3_device(LM_SEQUENCE...): random SPD H
+    over ten decades, sometimes indefinite (the Cholesky fails: invalid steps, halved radius), gradients that make steps
+    from 1e-9 to whole turns (`wild`) or only small ones, a cost that wanders so that steps are accepted and rejected,
+    sometimes a non-finite sum."""
+    E = sicp.LM_SEQUENCE_EVALS
+    items = np.empty((n, 7 + 28 * E))
+    iu = np.triu_indices(6)
+    for i in range(n):
+        q = rng.normal(size=4)
+        items[i, :4] = q / np.linalg.norm(q)
+        items[i, 4:7] = rng.normal(scale=10.0, size=3)
+        cost = 10.0 ** rng.uniform(-3, 6)
+        for e in range(E):
+            A = rng.normal(size=(6, 6))
+            H = (A @ A.T + 1e-3 * np.eye(6)) * 10.0 ** rng.uniform(-4, 6)
+            if rng.uniform() < 0.12:
+                j = rng.integers(6)
+                H[j, j] = -abs(H[j, j])                       # not positive definite
+            g = rng.normal(size=6) * np.sqrt(np.diag(np.abs(H))) * 10.0 ** (rng.uniform(-9, 1) if wild else rng.uniform(-9, -5))
+            cost = cost * (rng.uniform(0.3, 1.0) if rng.uniform() < 0.75 else rng.uniform(1.0, 3.0))
+            o = np.concatenate([H[iu], g, [cost]])
+            r = rng.uniform()
+            if r < 0.02:
+                o[rng.integers(28)] = np.nan
+            elif r < 0.03:
+                o[27] = np.inf
+            items[i, 7 + 28 * e: 7 + 28 * (e + 1)] = o
+    return items
+
+
+def test_lm_step_by_a_wave_equals_the_one_lane_machine_on_any_sequence(tmp_path):
+    """The kernels step the trust-region machine with a whole wavefront (lm_feed<true>: the six sqrt(diag / radius) and the two
+    sincos of a Plus in different lanes, the finite test by ballot); the host loop and the oracle's restatement run it in one
+    lane.  The machine is a pure function of (state, evaluation), so the two forms must agree BIT FOR BIT on any sequence of
+    evaluations, also on ones no registration produces: indefinite H (failed factorisations, invalid steps), rejected
+    steps, non-finite sums, steps of whole turns.  And on sequences with small rotations -- where the host's libm and the
+    device's agree on sin and cos -- both must equal csrc/lm.hpp compiled for the host (what lm_on_device = 0 runs)."""
+    import subprocess
+    rng = np.random.default_rng(20261003)
+    wild = lm_sequences(rng, 3000, True)
+    small = lm_sequences(rng, 1000, False)
+    with make_engine(sicp.MODE_GICP) as e:
+        w_wave, w_lane = e.se3_device(sicp.LM_SEQUENCE, wild), e.se3_device(sicp.LM_SEQUENCE_ONE_LANE, wild)
+        s_wave, s_lane = e.se3_device(sicp.LM_SEQUENCE, small), e.se3_device(sicp.LM_SEQUENCE_ONE_LANE, small)
+    assert w_wave.tobytes() == w_lane.tobytes()
+    assert s_wave.tobytes() == s_lane.tobytes()
+    # the sequences reach the branches they are meant to reach
+    status, iters, evals, invalid = w_wave[:, 31], w_wave[:, 32], w_wave[:, 33], w_wave[:, 34]
+    assert set(np.unique(status).astype(int)) >= {-1, 0, 3}             # still running / converged / failed first evaluation
+    assert (iters > evals).any() and (evals > 3).any()                   # retries inside one feed (invalid steps); long runs
+    assert 2 in set(np.unique(status).astype(int)) or (invalid > 0).any()
+    # the host build of the same header on the small-rotation sequences
+    src = tmp_path / "lm_seq.cc"
+    src.write_text(r"""
+#include <cstdio>
+#include <vector>
+#define SICP_HD
+#include "lm.hpp"
+using namespace sicp;
+int main(int argc, char** argv) {
+  const int E = 24, IN = 7 + 28 * E, OUT = 37;
+  FILE* f = std::fopen(argv[1], "rb"); int n = 0; if (!f || std::fread(&n, 4, 1, f) != 1) return 2;
+  std::vector<double> in((size_t)n * IN), out((size_t)n * OUT);
+  if (std::fread(in.data(), 8, in.size(), f) != in.size()) return 2; std::fclose(f);
+  for (int i = 0; i < n; ++i) {
+    const double* item = &in[(size_t)i * IN];
+    LmState s; LmOptions opt; lm_init(s, opt, item);
+    for (int e = 0; e < E && s.status == LM_RUNNING; ++e) lm_feed(s, item + 7 + 28 * e);
+    double* r = &out[(size_t)i * OUT]; int k = 0;
+    for (int j = 0; j < 7; ++j) r[k++] = s.pose[j];
+    for (int j = 0; j < 7; ++j) r[k++] = s.x[j];
+    for (int j = 0; j < 6; ++j) r[k++] = s.diag[j];
+    for (int j = 0; j < 6; ++j) r[k++] = s.scale[j];
+    r[k++] = s.radius; r[k++] = s.cost; r[k++] = s.model_change; r[k++] = s.decrease_factor; r[k++] = s.x_norm;
+    r[k++] = s.status; r[k++] = s.iterations; r[k++] = s.evaluations; r[k++] = s.invalid; r[k++] = s.reuse_diagonal; r[k++] = s.phase;
+  }
+  f = std::fopen(argv[2], "wb"); std::fwrite(out.data(), 8, out.size(), f); std::fclose(f);
+  return 0;
+}
+""")
+    exe = tmp_path / "lm_seq"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["g++", "-std=c++17", "-O1", "-ffp-contract=off", "-I", os.path.join(root, "semantic-icp_amd", "csrc"), str(src), "-o", str(exe)], check=True)
+    fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
+    with open(fin, "wb") as f:
+        f.write(np.int32(small.shape[0]).tobytes())
+        f.write(small.tobytes())
+    subprocess.run([str(exe), str(fin), str(fout)], check=True)
+    host = np.fromfile(fout).reshape(small.shape[0], sicp.LM_SEQUENCE_OUT)
+    same = np.all((host == s_wave) | (np.isnan(host) & np.isnan(s_wave)), axis=1)
+    assert same.all(), f"{(~same).sum()} of {same.size} sequences differ between the host and the device build; first: {host[~same][0]} / {s_wave[~same][0]}"
+
 # ------------------------------------------------------------------------------------------------
 # a6: GICPCostFunction::Probability as a double (quirk Q1 switched off)
 # ------------------------------------------------------------------------------------------------
