@@ -25,4 +25,3 @@ dec = np.all(host[:, 31:] == dev[:, 31:], axis=1)
 rel = np.nanmax(np.abs(host[:, :14] - dev[:, :14]) / (1e-300 + np.abs(host[:, :14])), axis=1)
 print({"sequences": int(same.size), "bit_equal": int(same.sum()), "same_decisions": int(dec.sum()),
        "max_rel_pose_difference_where_decisions_agree": float(rel[dec].max())})
-# the sincos alone: e.se3_device EXP against the host's exp on the same tangents
